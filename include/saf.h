@@ -1,0 +1,173 @@
+/*
+ * saf.h -- C ABI of the MI355X-native fusion hot path ("saf" = spatially-aware fusion).
+ *
+ * The reference (cy-xu/spatially_aware_AI) has no FFI layer: its boundary for this path is the
+ * Python class API.  This header is the drop-in boundary *underneath* that API:
+ * plain pointers and sizes, no torch types.  Every entry point names the reference code it
+ * replaces.  The Python host classes in spatially_aware_ai_amd/ bind these through ctypes
+ * (see INTEGRATION.md for the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers (HIP, gfx950) unless a parameter says "host";
+ *   - nothing here owns volume memory: the caller (torch) allocates and keeps it alive;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), re-entrant, and keeps no global mutable state besides the thread-local error
+ *     string;
+ *   - return value: 0 = ok, <0 = error (SAF_E_*), text via saf_last_error();
+ *   - voxel flat index n = (x*ny + y)*nz + z, the C-order flattening of meshgrid(ij)
+ *     (clipfusion.py:617-622); 64-bit offsets are used wherever n*D can exceed 2^31.
+ *
+ * oracle/saf_oracle.c implements CPU twins (saf_oracle_*) of the compute entry points with the
+ * same structs and HOST pointers; they are test infrastructure only.
+ */
+#ifndef SAF_H
+#define SAF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAF_ABI_VERSION 1
+
+enum saf_status {
+  SAF_OK = 0,
+  SAF_E_INVALID = -1,   /* bad argument (NULL pointer, non-positive size, misaligned buffer) */
+  SAF_E_WORKSPACE = -2, /* workspace too small */
+  SAF_E_HIP = -3,       /* HIP runtime error (launch failure, ...) */
+  SAF_E_UNSUPPORTED = -4
+};
+
+enum saf_dtype { SAF_F32 = 0, SAF_BF16 = 1, SAF_F16 = 2 };
+
+/* How per-voxel features are folded in (clipfusion.py:715-721). */
+enum saf_accum_mode {
+  SAF_RUNNING_MEAN = 0, /* reference semantics: x <- s*(1/w') + x*(w*(1/w')) in that op order */
+  SAF_SUM = 1           /* x <- x + s ; used by the frame-sharded multi-GPU path, finalised by
+                           saf_merge_finalize after the RCCL reduction */
+};
+
+/*
+ * The dense fusion volume: the registered buffers of ClipFusion (clipfusion.py:605-625) and
+ * ClipSeemFusion (clip_seem_fusion.py:640-672).  `xyz_world` is replaced by three per-axis
+ * coordinate tables (xyz_world[n] = (axis_x[x], axis_y[y], axis_z[z]) for any elementwise
+ * construction from meshgrid(ij)), so the sweep never reads the 12*N-byte buffer.
+ */
+typedef struct saf_volume {
+  int32_t nx, ny, nz;
+  int32_t feat_dim;       /* D = n_clip_feats */
+  int32_t n_classes;      /* width of labels_one_hot (143) or 0 when there is no label histogram */
+  int32_t feat_dtype;     /* saf_dtype of clip_feat; SAF_F32 is the reference layout */
+  int32_t accum_mode;     /* saf_accum_mode */
+  float trunc;            /* truncation distance in metres (self.trunc) */
+  const float* axis_x;    /* [nx] */
+  const float* axis_y;    /* [ny] */
+  const float* axis_z;    /* [nz] */
+  float* tsdf;            /* [N]       f32 */
+  int32_t* tsdf_weight;   /* [N]       i32 */
+  int32_t* weight;        /* [N]       i32 */
+  float* rgb;             /* [N,3]     f32 */
+  void* clip_feat;        /* [N,D]     feat_dtype */
+  int32_t* labels_one_hot;/* [N,n_classes] i32 or NULL */
+} saf_volume;
+
+/*
+ * One posed RGB-D frame plus the backbone outputs that integrate() consumes
+ * (clipfusion.py:627-645, clip_seem_fusion.py:676-695, :755-760).
+ */
+typedef struct saf_frame {
+  int32_t height, width;
+  const float* depth;     /* [H,W]   metres; 0 = missing */
+  const float* rgb;       /* [H,W,3] 0..1, channel-last exactly as the loaders yield it */
+  const float* pose;      /* [4,4]   camera->world, row-major (device memory) */
+  const float* K;         /* [3,3]   intrinsics, row-major (device memory) */
+  const float* feat_map;  /* [Dm,npy,npx] f32, Dm >= D: Clip.img_inference_tiled output for this frame;
+                             only the first D channels are used (clipfusion.py:709) */
+  int32_t npy, npx;
+  const float* label_map; /* [H,W] f32 class ids = pano_seg.float() (clip_seem_fusion.py:760) or NULL */
+  int32_t rgb_bilinear;   /* 0: nearest (clipfusion.py:701-706); 1: bilinear (clip_seem_fusion.py:793-798) */
+} saf_frame;
+
+/* Counters the fuse kernels add to (device memory, 8 x u64, caller zeroes them when it wants):
+ *  [0] sum of Nv (valid voxels)  [1] sum of Nt (tsdf-valid voxels)  [2] frames fused
+ *  [3] labels outside [0,n_classes) that were dropped (the reference raises instead)  [4..7] reserved */
+#define SAF_STATS_WORDS 8
+
+const char* saf_last_error(void);
+int saf_abi_version(void);
+
+/* Bytes of device scratch saf_fuse_frame(s) needs for a volume of n_voxels and a feature map of
+ * feat_dim x npy x npx (compact list of valid voxels + re-laid-out feature map + counters). */
+size_t saf_fuse_workspace_bytes(int64_t n_voxels, int32_t feat_dim, int32_t npy, int32_t npx);
+
+/*
+ * Fuse ONE frame into the volume: replaces the body of ClipFusion.integrate after the CLIP call
+ * (clipfusion.py:647-721) / ClipSeemFusion.integrate (clip_seem_fusion.py:697-822) for batch
+ * element i: projection + depth test (a2), TSDF running mean (a3), valid-voxel compaction (a4),
+ * feature / rgb / label gather (a5), running-mean fuse (a6), label histogram (a7).
+ * `stats` may be NULL.
+ */
+int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspace,
+                   size_t workspace_bytes, uint64_t* stats, void* stream);
+
+/* The same for n_frames frames in order (host array of descriptors); one host call, no host
+ * synchronisation between frames -- the loop of clipfusion.py:1125-1133. */
+int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
+                    void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
+
+/*
+ * Depth un-projection of a lattice of pixels to world points: the per-frame body of
+ * backproject_pcd (clipfusion.py:541-565) with get_pix_vecs (:497-507) folded in.
+ *   u_idx[nu], v_idx[nv] : pixel columns / rows of the lattice (device i32)
+ *   Kinv                 : [3,3] inverse intrinsics (device f32; the host inverts K)
+ * Writes xyz[nv*nu,3] (world), valid[nv*nu] (u8: depth not NaN, >0, <max_depth) in lattice order
+ * (v-major, as meshgrid(xy).view(-1) orders it).
+ */
+int saf_backproject_lattice(const float* depth, int32_t height, int32_t width, const float* pose,
+                            const float* Kinv, const int32_t* u_idx, int32_t nu,
+                            const int32_t* v_idx, int32_t nv, float max_depth, float* xyz,
+                            uint8_t* valid, void* stream);
+
+/* Epilogues of the text-query scan. */
+enum saf_query_epilogue {
+  SAF_Q_SCORES = 0,  /* out[n,l] = scale * <f_n, t_l>                                   */
+  SAF_Q_SOFTMAX = 1, /* Clip.run_query, clipfusion.py:899-904: softmax_l(scale*<f_n,t_l>) */
+  SAF_Q_SURGERY = 2  /* Clip.clip_feature_surgery (redundant_feats=None), clipfusion.py:911-932:
+                        out[n,l] = S[n,l]*w[l] - mean_l(S[n,l]*w[l]), w from row 0 of feats */
+};
+
+/*
+ * Scan n_rows feature rows against n_text text embeddings.
+ *   feats      [n_rows, feat_stride] feat_dtype (row-major; first D columns used)
+ *   text       [n_text, text_stride] f32 (first D columns used: run_query truncates, :901)
+ *   normalize  1: divide each row by its L2 norm first and map NaN -> 0
+ *              (clip_seem_fusion.py:507-511; query_mesh.py:24-25 without the nan_to_num)
+ *   out        [n_rows, n_text] f32
+ *   out_last   optional [n_rows] f32: only the last column (query_mesh.py:38); out may be NULL then
+ */
+int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_t feat_stride,
+                   int32_t feat_dim, const float* text, int32_t n_text, int64_t text_stride,
+                   int32_t epilogue, float scale, int32_t normalize, float* out, float* out_last,
+                   void* stream);
+
+/*
+ * After the cross-rank SUM of SAF_SUM-mode volumes: clip_feat <- F/w,
+ * rgb <- C/w, tsdf <- T/wt over voxels [first, first+count); rows with zero weight stay zero.
+ */
+int saf_merge_finalize(const saf_volume* vol, int64_t first_voxel, int64_t n_voxels, void* stream);
+
+/* Inverse of the above for a volume that was fused in SAF_RUNNING_MEAN mode: mean -> sum
+ * (x*w), so that it can enter the reduction. */
+int saf_mean_to_sum(const saf_volume* vol, int64_t first_voxel, int64_t n_voxels, void* stream);
+
+/* Per-voxel argmax of the label histogram with the all-zero row -> -1 rule
+ * (clip_seem_fusion.py:315-325).  out[N] i32. */
+int saf_label_argmax(const int32_t* labels_one_hot, int64_t n_voxels, int32_t n_classes,
+                     int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAF_H */
