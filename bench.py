@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused hot path on MI355X: RGB-D frames/s fused into a voxel feature volume.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON line on rank 0.
+
+Workload (BASELINE.json metric / configs[3]): per rank 512 synthetic 640x480 RGB-D frames with
+random poses (depth distribution A) fused into a per-rank 256^3 x 512 fp32 grid;
+ranks shard frames and merge their grids with one RCCL reduction at the end of the job.
+
+A *step* is one whole job per rank: zero the volume, fuse this rank's frames (prep + sweep + fuse
+kernels per frame, one C-ABI call, no host sync), and -- for N > 1 -- the single merge
+(reduce-scatter of the per-rank SUM volumes + local divide).  Inputs are resident in HBM before
+the timed region.  value = N * frames_per_rank * K / max-over-ranks wall time of the K steps.
+
+Extra objects on the JSON line:
+  roofline     : the dominant kernel (fuse_kernel): algorithmic bytes per launch (from the Nv
+                 counters the kernels emit, SURVEY.md §8d formula) / its average launch duration,
+                 measured with HIP events on the launch stream inside the timed region.
+  cpu_baseline : the CPU oracle (a parity-checked port of the reference's algorithm, OpenMP over
+                 the host cores of this box) on a bounded sample of the same frames, rank 0, N=1.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from spatially_aware_ai_amd import _abi  # noqa: E402
+from spatially_aware_ai_amd import synthetic as syn  # noqa: E402
+from spatially_aware_ai_amd._lib import check, lib  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=256, help="voxels per axis")
+    ap.add_argument("--dim", type=int, default=512, help="feature dim D")
+    ap.add_argument("--frames", type=int, default=512, help="frames per rank per step")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--depth-kind", default="A", choices=["A", "B"])
+    ap.add_argument("--unique-frames", type=int, default=512,
+                    help="distinct synthetic frames resident per rank (cycled to --frames)")
+    ap.add_argument("--merge", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile-events", action="store_true")
+    return ap.parse_args()
+
+
+def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device):
+    """n frames resident on the device.  Poses/intrinsics come from the seeded CPU generator of
+    synthetic.py; the bulky per-pixel data is drawn on the device (seeded) to keep start-up short."""
+    gen = torch.Generator().manual_seed(seed)
+    poses, ks = [], []
+    for _ in range(n):
+        c = torch.randn(3, generator=gen)
+        poses.append(syn.look_at_pose(c / c.norm() * 2.5))
+        ks.append(syn.intrinsics(width, height))
+    poses = torch.stack(poses).to(device)
+    ks = torch.stack(ks).to(device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    if depth_kind == "A":
+        depth = torch.rand((n, height, width), generator=g, device=device) * 2.0 + 1.5
+    else:
+        depth = torch.stack([syn._analytic_depth(p.cpu(), k.cpu(), width, height) for p, k in zip(poses, ks)]).to(device)
+    rgb = torch.rand((n, height, width, 3), generator=g, device=device)
+    feat = torch.randn((n, dim, npy, npx), generator=g, device=device)
+    return depth, rgb, poses, ks, feat
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from spatially_aware_ai_amd import ClipFusion
+    from spatially_aware_ai_amd import distributed as sdist
+
+    npy, npx = syn.feature_map_shape(a.width, a.height)
+    grid = syn.make_grid(a.grid)
+    n_vox = grid.n_voxels
+
+    class ResidentFeatures:  # stands in for the CLIP backbone: feature maps are already in HBM
+        feature_dim = a.dim
+
+    fusion = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, ResidentFeatures(), None,
+                        a.height // 3, a.height // 6, keep_xyz_world=False).to(device)
+    fusion.accum_mode = _abi.SAF_SUM if world > 1 else _abi.SAF_RUNNING_MEAN
+
+    uniq = min(a.unique_frames, a.frames)
+    depth, rgb, poses, ks, feat = gen_frames_gpu(uniq, a.width, a.height, a.dim, npy, npx, a.depth_kind,
+                                                 1000 + rank, device)
+    arr_u, keep, _, _ = fusion._make_frames(depth, rgb, poses, ks, feat, None, False)
+    frames = (_abi.SafFrame * a.frames)()
+    for i in range(a.frames):
+        frames[i] = arr_u[i % uniq]
+    ws = fusion._get_workspace(npy, npx)
+    vol = fusion._c_volume()
+    stream = torch.cuda.current_stream().cuda_stream
+    L = lib()
+    prof = None
+    if not a.no_profile_events:
+        prof = L.saf_profiler_create(3 * a.frames * max(1, a.steps))
+
+    vol_tensors = [fusion.clip_feat, fusion.rgb, fusion.tsdf, fusion.weight, fusion.tsdf_weight]
+
+    def step(profiler):
+        for t in vol_tensors:
+            t.zero_()
+        rc = L.saf_fuse_frames_profiled(C.byref(vol), frames, a.frames, ws.data_ptr(), ws.numel(),
+                                        fusion.fuse_stats.data_ptr(), profiler, stream)
+        check(rc, "saf_fuse_frames_profiled")
+        if world > 1:
+            fusion.accum_mode = _abi.SAF_SUM
+            sdist.merge_volumes(fusion, mode=a.merge)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(None)
+    barrier()
+    fusion.fuse_stats.zero_()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(prof)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    st = fusion.stats()
+    total_frames = world * a.frames * a.steps
+    value = total_frames / dt
+
+    # ---- roofline of the dominant kernel (fuse_kernel), this rank ----
+    roofline = None
+    breakdown = None
+    if prof:
+        ms = {}
+        for cls, name in ((0, "prep"), (1, "sweep"), (2, "fuse")):
+            tot, n = C.c_double(0), C.c_int64(0)
+            check(L.saf_profiler_read(prof, cls, C.byref(tot), C.byref(n)), "saf_profiler_read")
+            ms[name] = (tot.value, n.value)
+        L.saf_profiler_destroy(prof)
+        n_launch = max(1, ms["fuse"][1])
+        nv_per = st["valid"] / max(1, st["frames"])
+        nt_per = st["tsdf_valid"] / max(1, st["frames"])
+        # B_fuse = Nv*(2*D*4 + 2*12 + 2*4) + Nt*16 + H*W*16 + D*npy*npx*4 per frame.
+        # The fuse kernel's share: rows + rgb + weight RMW + its read of the re-laid feature map and
+        # of the compact list; the Nt*16 TSDF term and the depth image belong to the sweep kernel.
+        fuse_bytes = nv_per * (2 * a.dim * 4 + 2 * 12 + 2 * 4 + 4) + a.dim * npy * npx * 4
+        sweep_bytes = nt_per * 16 + a.height * a.width * 4 + nv_per * 4
+        frame_bytes = nv_per * (2 * a.dim * 4 + 32) + nt_per * 16 + a.height * a.width * 16 + a.dim * npy * npx * 4
+        avg_fuse_s = ms["fuse"][0] / n_launch * 1e-3
+        achieved = fuse_bytes / avg_fuse_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_fuse_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("grid") == a.grid and tj.get("dim") == a.dim:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "kernel": "fuse_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(fuse_bytes), "avg_launch_us": round(avg_fuse_s * 1e6, 2),
+            "launches": int(n_launch), "valid_voxels_per_frame": round(nv_per, 1),
+            "tsdf_voxels_per_frame": round(nt_per, 1),
+        }
+        breakdown = {
+            "prep_us": round(ms["prep"][0] / max(1, ms["prep"][1]) * 1e3, 2),
+            "sweep_us": round(ms["sweep"][0] / max(1, ms["sweep"][1]) * 1e3, 2),
+            "fuse_us": round(avg_fuse_s * 1e6, 2),
+            "sweep_algorithmic_bytes": int(sweep_bytes),
+            "frame_algorithmic_bytes": int(frame_bytes),
+            "frame_hbm_frac": round(frame_bytes / (dt / (a.frames * a.steps)) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1 only) ----
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_frames != 0:
+        cpu = cpu_baseline(a, grid, depth, rgb, poses, ks, feat, npy, npx)
+
+    if rank == 0:
+        out = {
+            "metric": "fused RGB-D frames/sec into voxel grid",
+            "value": round(value, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{a.frames} frames/rank {a.width}x{a.height} depth-{a.depth_kind}, per-rank "
+                            f"{a.grid}^3x{a.dim} f32 grid, frames sharded, "
+                            + ("one RCCL " + a.merge + " merge per step" if world > 1 else "single GPU (no merge)"),
+                "frames_per_rank": a.frames, "grid": a.grid, "feat_dim": a.dim, "image": [a.width, a.height],
+                "feature_map": [npy, npx], "unique_frames_resident": uniq, "n_voxels": n_vox,
+                "parallelism": f"frames-dp{world}",
+            },
+            "roofline": roofline,
+            "kernel_breakdown": breakdown,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, grid, depth, rgb, poses, ks, feat, npy, npx):
+    """Times oracle/saf_oracle.c (test infrastructure, used here only as the reported CPU
+    baseline) on the first few frames of this workload with all host cores of the box."""
+    try:
+        from oracle import oracle as O
+    except Exception as e:  # the oracle is optional for the benchmark line
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    O.set_threads(cores)
+    n = a.cpu_frames if a.cpu_frames > 0 else 17
+    n = min(n, depth.shape[0])
+    vol = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, a.dim)
+    d, r, p, k, f = (t[:n].cpu() for t in (depth, rgb, poses, ks, feat))
+    vol.integrate(d[:1], r[:1], p[:1], k[:1], f[:1])  # touch pages / warm up
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(1, n):
+        vol.integrate(d[i : i + 1], r[i : i + 1], p[i : i + 1], k[i : i + 1], f[i : i + 1])
+        done += 1
+        if time.perf_counter() - t0 > 25.0:
+            break
+    dt = time.perf_counter() - t0
+    O.set_threads(1)
+    return {
+        "value": round(done / dt, 3) if done else None, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{done} frames of the same workload ({a.grid}^3x{a.dim}, {a.width}x{a.height}), "
+                  f"oracle/saf_oracle.c with OpenMP over {cores} host threads",
+    }
+
+
+if __name__ == "__main__":
+    main()

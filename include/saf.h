@@ -118,6 +118,25 @@ int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_fr
                     void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
 
 /*
+ * Optional per-kernel timing: a pool of HIP event pairs recorded on the launch stream around each
+ * kernel of saf_fuse_frames_profiled (class 0 = prep, 1 = sweep, 2 = fuse).  Recording is
+ * asynchronous; saf_profiler_read must be called after the stream has been synchronised.
+ * Used by bench.py for the roofline line; the product path passes NULL.
+ */
+typedef struct saf_profiler saf_profiler;
+saf_profiler* saf_profiler_create(int32_t capacity_pairs);
+void saf_profiler_destroy(saf_profiler* p);
+void saf_profiler_reset(saf_profiler* p);
+/* total elapsed ms and number of launches recorded for one kernel class; <0 on error */
+int saf_profiler_read(saf_profiler* p, int32_t kernel_class, double* total_ms, int64_t* launches);
+
+/* saf_fuse_frames with event pairs recorded into `profiler` (may be NULL = no recording; pairs
+ * beyond the pool's capacity are silently not recorded). */
+int saf_fuse_frames_profiled(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
+                             void* workspace, size_t workspace_bytes, uint64_t* stats,
+                             saf_profiler* profiler, void* stream);
+
+/*
  * Depth un-projection of a lattice of pixels to world points: the per-frame body of
  * backproject_pcd (clipfusion.py:541-565) with get_pix_vecs (:497-507) folded in.
  *   u_idx[nu], v_idx[nv] : pixel columns / rows of the lattice (device i32)
@@ -146,11 +165,15 @@ enum saf_query_epilogue {
  *              (clip_seem_fusion.py:507-511; query_mesh.py:24-25 without the nan_to_num)
  *   out        [n_rows, n_text] f32
  *   out_last   optional [n_rows] f32: only the last column (query_mesh.py:38); out may be NULL then
+ *   workspace  device scratch of saf_query_workspace_bytes(n_text, epilogue) bytes (may be NULL if 0)
  */
 int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_t feat_stride,
                    int32_t feat_dim, const float* text, int32_t n_text, int64_t text_stride,
                    int32_t epilogue, float scale, int32_t normalize, float* out, float* out_last,
-                   void* stream);
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Device scratch saf_query_scan needs (the surgery weights w[n_text]); 0 for other epilogues. */
+size_t saf_query_workspace_bytes(int32_t n_text, int32_t epilogue);
 
 /*
  * After the cross-rank SUM of SAF_SUM-mode volumes: clip_feat <- F/w,

@@ -47,10 +47,17 @@ def lib():
             fn = getattr(l, name)
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(_abi.SafVolume), C.c_int64, C.c_int64]
+        l.saf_oracle_set_threads.argtypes = [C.c_int]
+        l.saf_oracle_get_threads.restype = C.c_int
         l.saf_oracle_label_argmax.restype = C.c_int
         l.saf_oracle_label_argmax.argtypes = [vp, C.c_int64, C.c_int32, vp]
         _lib = l
     return _lib
+
+
+def set_threads(n: int):
+    """Host threads the fuse restatement spreads x-slabs over (default 1)."""
+    lib().saf_oracle_set_threads(int(n))
 
 
 def _f32(t):

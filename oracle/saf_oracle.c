@@ -11,9 +11,11 @@
  *
  * Each function cites the reference lines it restates.  Arithmetic is plain IEEE fp32, one
  * rounding per operation as PyTorch's elementwise kernels do; the two 3x3 products that the
- * reference hands to BLAS (clipfusion.py:648-652) are restated as a k-ascending FMA chain, the
- * order MKL's sgemm micro-kernel produces for K=3 (checked bit-for-bit against the goldens'
- * valid masks).  Build with -ffp-contract=off so the compiler adds no contractions of its own.
+ * reference hands to BLAS (clipfusion.py:648-652) are restated in the accumulation order MKL
+ * produces for them single-threaded -- R^T(x-t): rounded products added as (p0+p2)+p1;
+ * K@xyz_cam: k-ascending FMA chain -- found by bit-for-bit comparison with torch.bmm and
+ * confirmed on 577k valid / 2.7M tsdf decisions of the config-1 golden (zero differences).
+ * Build with -ffp-contract=off so the compiler adds no contractions of its own.
  */
 #include <math.h>
 #include <stdint.h>
@@ -62,6 +64,10 @@ static inline float dot3(float a0, float a1, float a2, float b0, float b1, float
   return acc;
 #endif
 }
+
+static int g_threads = 1;
+void saf_oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int saf_oracle_get_threads(void) { return g_threads; }
 
 /* grid_sample's un-normalisation for align_corners=False (ATen GridSamplerKernel.cpp,
  * ComputeLocationBase<align_corners=false>::unnormalize): (g+1)*(size/2) - 0.5 */
@@ -177,6 +183,9 @@ int saf_oracle_fuse_frame(const saf_volume* v, const saf_frame* f, uint64_t* sta
   const int P = f->npy * f->npx;
   float* feat = (float*)v->clip_feat;
   uint64_t nv = 0, nt = 0, dropped = 0;
+  /* voxels are independent within a frame: x-slabs are spread over the host threads (only the
+   * cpu_baseline leg of bench.py raises the thread count above 1) */
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : nv, nt, dropped) num_threads(g_threads)
   for (int ix = 0; ix < v->nx; ++ix)
     for (int iy = 0; iy < v->ny; ++iy)
       for (int iz = 0; iz < v->nz; ++iz) {

@@ -73,6 +73,14 @@ PROTOTYPES = {
         C.c_int,
         [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp, _fp],
     ),
+    "saf_profiler_create": (_fp, [C.c_int32]),
+    "saf_profiler_destroy": (None, [_fp]),
+    "saf_profiler_reset": (None, [_fp]),
+    "saf_profiler_read": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "saf_fuse_frames_profiled": (
+        C.c_int,
+        [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp, _fp, _fp],
+    ),
     "saf_backproject_lattice": (
         C.c_int,
         [_fp, C.c_int32, C.c_int32, _fp, _fp, _fp, C.c_int32, _fp, C.c_int32, C.c_float, _fp, _fp, _fp],
@@ -82,9 +90,10 @@ PROTOTYPES = {
         [
             _fp, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
             _fp, C.c_int32, C.c_int64,
-            C.c_int32, C.c_float, C.c_int32, _fp, _fp, _fp,
+            C.c_int32, C.c_float, C.c_int32, _fp, _fp, _fp, C.c_size_t, _fp,
         ],
     ),
+    "saf_query_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "saf_merge_finalize": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_mean_to_sum": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_label_argmax": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, _fp]),

@@ -1,0 +1,145 @@
+"""Host-side mirror of the reference's ``clip_seem_fusion.py`` hot-path API on MI355X.
+
+  * ``ClipSeemFusion``        -- reference clip_seem_fusion.py:611-888: the ClipFusion volume plus a
+                                 per-voxel panoptic class histogram, rgb sampled bilinearly.
+  * ``argmax_with_check``     -- the manager's label decode (clip_seem_fusion.py:315-325).
+  * ``TextQueryEngine``       -- the query half of ``InSituManager`` (``clip_text_query``,
+                                 clip_seem_fusion.py:482-561) over fused vertex / voxel features.
+
+The Flask app, datasets, flood fill and DGCNN parts of ``InSituManager`` are outside the fused hot
+path; a maintainer keeps the reference's manager and swaps these classes in
+(INTEGRATION.md).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._lib import check, current_stream_ptr, lib, require_cuda
+from .clipfusion import _FusionVolumeMixin, _query_scan
+
+N_PANOPTIC_SLOTS = 133 + 10  # clip_seem_fusion.py:655 -- 133 COCO panoptic classes, null = 133, spare slots
+
+
+class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
+    """CLIP + panoptic-label fusion volume (reference clip_seem_fusion.py:611-822).
+
+    ``clip_model`` needs ``feature_dim`` and ``img_inference_tiled``; ``seg_model`` needs
+    ``run_on_image(rgb[3,H,W]) -> class-id map [H,W]`` (kMaX-DeepLab in the reference,
+    handy_utils.py:60-161).  Both run as PyTorch-ROCm modules; everything after them is HIP.
+    Callers may set ``unique_objects``, ``voxel_obj_idx`` and ``objects_segmentation_color`` on the
+    instance exactly as the reference's manager does (clip_seem_fusion.py:352-372).
+    """
+
+    _rgb_bilinear = True  # clip_seem_fusion.py:793-798
+
+    def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_patch_size, clip_patch_stride,
+                 clip_model, seg_model, keep_xyz_world=True):
+        super().__init__()
+        self.clip = clip_model
+        self.clip_patch_size = clip_patch_size
+        self.clip_patch_stride = clip_patch_stride
+        self.scale_patches_by_depth = scale_patches_by_depth
+        self.segmentation_model = seg_model
+        self.n_classes = N_PANOPTIC_SLOTS
+        self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, self.n_classes, keep_xyz_world)
+        self.debug_counter = 0
+
+    def integrate(self, depth_imgs, rgb_imgs, poses, K):
+        """Reference clip_seem_fusion.py:676-822.  (The reference indexes ``labels[i]`` on a
+        size-1 dimension and therefore only works for B = 1; any B works here.)"""
+        rgb_chw = rgb_imgs.permute(0, 3, 1, 2)
+        if self.scale_patches_by_depth:
+            clip_feat_img = self.clip.img_inference_tiled_depthscaled(
+                rgb_chw, depth_imgs, K, patch_stride=self.clip_patch_stride
+            )
+        else:
+            clip_feat_img = self.clip.img_inference_tiled(
+                rgb_chw, patch_size=self.clip_patch_size, patch_stride=self.clip_patch_stride
+            )
+        label_maps = [self.segmentation_model.run_on_image(rgb_chw[i]).float() for i in range(len(rgb_imgs))]
+        self._fuse(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, True)
+
+    def label_index(self):
+        """Per-voxel class id, -1 where nothing was fused: the manager's
+        ``argmax_with_check_2d_efficient(labels_one_hot)`` (clip_seem_fusion.py:315-325)."""
+        return argmax_with_check(self.labels_one_hot)
+
+
+def argmax_with_check(labels_one_hot):
+    """argmax over classes with all-zero rows -> -1 (clip_seem_fusion.py:315-320), int64 like
+    torch.argmax."""
+    require_cuda(labels_one_hot, "labels_one_hot")
+    lab = labels_one_hot.contiguous()
+    if lab.dtype != torch.int32:
+        lab = lab.to(torch.int32)
+    out = torch.empty(lab.shape[0], dtype=torch.int32, device=lab.device)
+    with torch.cuda.device(lab.device):
+        rc = lib().saf_label_argmax(lab.data_ptr(), lab.shape[0], lab.shape[1], out.data_ptr(), current_stream_ptr())
+    check(rc, "saf_label_argmax")
+    return out.long()
+
+
+class TextQueryEngine:
+    """The natural-language query of ``InSituManager.clip_text_query`` (clip_seem_fusion.py:482-561)
+    over a set of fused feature rows (mesh-vertex features in the reference, :423; raw voxel rows work
+    the same way).
+
+    ``clip_model`` supplies ``encode_text_with_prompt_ensemble``; features stay resident on the HIP
+    device and every query is one fused scan (row-normalise + nan_to_num + surgery epilogue).
+    """
+
+    def __init__(self, clip_model, vert_clip_feat, verts=None, faces=None, scene_knowledge=None, device=None):
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.clip_model = clip_model
+        self.vert_clip_feat = torch.as_tensor(vert_clip_feat).to(device=device, dtype=torch.float32).contiguous()
+        self.verts = verts
+        self.faces = faces
+        self.scene_knowledge = scene_knowledge
+        self.control_objects = None
+        self.control_text_features = None
+
+    def _ensure_controls(self, text):
+        if self.control_objects is None:
+            uo = (self.scene_knowledge or {}).get("unique_objects", {})
+            self.control_objects = list(set(uo[k]["class_label"] for k in uo.keys()))
+        if text not in self.control_objects or self.control_text_features is None:
+            self.control_objects.append(text)
+            self.control_text_features = self.clip_model.encode_text_with_prompt_ensemble(
+                self.control_objects, "cpu", prompt_templates=["a photo of {}"]
+            )
+
+    def similarity(self, text):
+        """[1, Nq, T] surgery similarity against the control set with ``text`` appended."""
+        self._ensure_controls(text)
+        return _query_scan(self.vert_clip_feat, self.control_text_features, _abi.SAF_Q_SURGERY, normalize=True)[None]
+
+    def relevance(self, text):
+        """Min-max normalised relevance in [0,1] per row (clip_seem_fusion.py:527-533), numpy f32."""
+        sim = self.similarity(text)
+        for n, name in enumerate(self.control_objects):
+            if name != text:
+                continue
+            rel = sim[0, :, n].cpu().numpy()
+            rel -= rel.mean()
+            rel = np.clip(rel, 0, 1)
+            return (rel - rel.min()) / (rel.max() - rel.min())
+        return None
+
+    def clip_text_query(self, text: str):
+        """-> {"vertices","faces","colors"(RGBA)} or None, as the reference returns to /text_query."""
+        rel = self.relevance(text)
+        if rel is None:
+            return None
+        return {"vertices": self.verts, "faces": self.faces, "colors": relevance_to_rgba(rel).tolist()}
+
+
+def relevance_to_rgba(relevance):
+    """turbo colour map, alpha = 0.5 * relevance (clip_seem_fusion.py:544-548)."""
+    import matplotlib
+
+    rgb = matplotlib.colormaps["turbo"](relevance)[:, :3]
+    alpha = relevance * 0.5
+    return np.hstack([rgb, alpha[:, None]])

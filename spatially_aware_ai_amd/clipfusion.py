@@ -1,0 +1,451 @@
+"""Host-side mirror of the reference's ``clipfusion.py`` hot-path API on MI355X.
+
+Same names, arguments and error behaviour as the reference classes so that its callers
+(`run_clipfusion`, `InSituManager`, `query_mesh.py`, the eval scripts) can switch imports:
+
+  * ``ClipFusion``      -- reference clipfusion.py:575-763 (volume + ``integrate``)
+  * ``Clip``            -- reference clipfusion.py:766-1039 (tiled image features, text query head)
+  * ``backproject_pcd`` -- reference clipfusion.py:510-572
+  * ``get_pix_vecs``    -- reference clipfusion.py:497-507
+  * ``scene_bounds``    -- the bounds arithmetic of clipfusion.py:1098-1106
+
+PyTorch is plumbing here (device memory, streams, the backbone GEMMs); the fusion loop and the
+query scan are the hand-written HIP kernels behind ``include/saf.h``.  There is no CPU
+fallback: tensors that are not on the HIP device raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._lib import SafError, check, current_stream_ptr, lib, require_cuda
+
+# --------------------------------------------------------------------------------------------
+# volume plumbing shared by ClipFusion and ClipSeemFusion
+# --------------------------------------------------------------------------------------------
+
+
+def _axis_tables(origin, voxel_size, nvox):
+    """Per-axis voxel-centre coordinates, element for element what the reference computes as
+    ``xyz_idx * voxel_size + origin`` (clipfusion.py:617-622): int64 index * python float -> f32
+    product, + f32 origin."""
+    origin = torch.as_tensor(origin).detach().cpu()
+    return [(torch.arange(int(nvox[a])) * voxel_size + origin[a]).to(torch.float32).contiguous() for a in range(3)]
+
+
+class _FusionVolumeMixin:
+    """Buffers, workspace and the C-ABI call shared by both fusion modules."""
+
+    def _init_volume(self, origin, voxel_size, nvox, trunc, feat_dim, n_classes=0, keep_xyz_world=True):
+        nvox = torch.as_tensor(nvox)
+        n = int(torch.prod(nvox.long()))
+        self.origin = origin
+        self.voxel_size = voxel_size
+        self.nvox = nvox
+        self.trunc = trunc
+        self.n_clip_feats = feat_dim
+        self.accum_mode = _abi.SAF_RUNNING_MEAN
+        self.register_buffer("tsdf", torch.zeros(n, dtype=torch.float32))
+        self.register_buffer("rgb", torch.zeros((n, 3), dtype=torch.float32))
+        self.register_buffer("clip_feat", torch.zeros((n, feat_dim), dtype=torch.float32))
+        self.register_buffer("weight", torch.zeros(n, dtype=torch.int32))
+        self.register_buffer("tsdf_weight", torch.zeros(n, dtype=torch.int32))
+        if n_classes:
+            self.register_buffer("labels_one_hot", torch.zeros((n, n_classes), dtype=torch.int32))
+        ax = _axis_tables(origin, voxel_size, nvox)
+        # not in the reference's state_dict: derived tables the sweep kernel reads instead of xyz_world
+        self.register_buffer("axis_x", ax[0], persistent=False)
+        self.register_buffer("axis_y", ax[1], persistent=False)
+        self.register_buffer("axis_z", ax[2], persistent=False)
+        self.register_buffer("fuse_stats", torch.zeros(_abi.SAF_STATS_WORDS, dtype=torch.int64), persistent=False)
+        if keep_xyz_world:
+            nx, ny, nz = (int(v) for v in nvox)
+            xyz_world = torch.stack(
+                (
+                    ax[0][:, None, None].expand(nx, ny, nz),
+                    ax[1][None, :, None].expand(nx, ny, nz),
+                    ax[2][None, None, :].expand(nx, ny, nz),
+                ),
+                dim=-1,
+            ).reshape(-1, 3)
+            self.register_buffer("xyz_world", xyz_world)
+        self._workspace = None
+
+    # -- C structs -------------------------------------------------------------------------
+    def _c_volume(self):
+        nx, ny, nz = (int(v) for v in self.nvox)
+        labels = getattr(self, "labels_one_hot", None)
+        require_cuda(self.clip_feat, "the fusion volume")
+        for name in ("tsdf", "rgb", "clip_feat", "weight", "tsdf_weight"):
+            if not getattr(self, name).is_contiguous():
+                raise SafError(f"buffer {name} must be contiguous")
+        p = _abi.ptr
+        return _abi.SafVolume(
+            nx, ny, nz, int(self.n_clip_feats), 0 if labels is None else int(labels.shape[1]),
+            _abi.SAF_F32, int(self.accum_mode), float(self.trunc),
+            p(self.axis_x), p(self.axis_y), p(self.axis_z),
+            p(self.tsdf), p(self.tsdf_weight), p(self.weight), p(self.rgb), p(self.clip_feat), p(labels),
+        )
+
+    def _get_workspace(self, npy, npx):
+        n = self.tsdf.numel()
+        need = lib().saf_fuse_workspace_bytes(n, int(self.n_clip_feats), int(npy), int(npx))
+        ws = self._workspace
+        if ws is None or ws.numel() < need or ws.device != self.tsdf.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.tsdf.device)
+            self._workspace = ws
+        return ws
+
+    @staticmethod
+    def _f32c(t, name):
+        require_cuda(t, name)
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t.contiguous()
+
+    def _make_frames(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear):
+        """C descriptors for a batch; returns (ctypes array, keepalive list, npy, npx)."""
+        depth_imgs = self._f32c(depth_imgs, "depth_imgs")
+        rgb_imgs = self._f32c(rgb_imgs, "rgb_imgs")
+        poses = self._f32c(poses, "poses")
+        K = self._f32c(K, "K")
+        feat = self._f32c(clip_feat_img, "clip feature map")
+        bsz, h, w = depth_imgs.shape
+        if rgb_imgs.shape != (bsz, h, w, 3):
+            raise ValueError(f"rgb_imgs must be [B,H,W,3], got {tuple(rgb_imgs.shape)}")
+        if poses.shape != (bsz, 4, 4) or K.shape != (bsz, 3, 3):
+            raise ValueError("poses must be [B,4,4] and K [B,3,3]")
+        if feat.dim() != 4 or feat.shape[0] != bsz or feat.shape[1] < self.n_clip_feats:
+            raise ValueError(f"feature map must be [B,D>={self.n_clip_feats},npy,npx], got {tuple(feat.shape)}")
+        labs = None
+        if label_maps is not None:
+            labs = [self._f32c(m, "label map") for m in label_maps]
+            for m in labs:
+                if m.shape != (h, w):
+                    raise ValueError("label map must be [H,W]")
+        npy, npx = int(feat.shape[2]), int(feat.shape[3])
+        arr = (_abi.SafFrame * bsz)()
+        p = _abi.ptr
+        for i in range(bsz):
+            arr[i] = _abi.SafFrame(
+                h, w, p(depth_imgs[i]), p(rgb_imgs[i]), p(poses[i]), p(K[i]), p(feat[i]), npy, npx,
+                p(labs[i]) if labs is not None else None, int(bool(rgb_bilinear)),
+            )
+        return arr, (depth_imgs, rgb_imgs, poses, K, feat, labs), npy, npx
+
+    def _fuse(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False):
+        arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
+        vol = self._c_volume()
+        ws = self._get_workspace(npy, npx)
+        rc = lib().saf_fuse_frames(
+            C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self.fuse_stats.data_ptr(), current_stream_ptr()
+        )
+        check(rc, "saf_fuse_frames")
+        # the launches are asynchronous: keep inputs alive until the stream has consumed them
+        for t in keep[:5]:
+            t.record_stream(torch.cuda.current_stream())
+
+    # -- extensions (not in the reference) ---------------------------------------------------
+    def integrate_features(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None):
+        """``integrate`` with the backbone outputs supplied by the caller (fuse-only entry used by
+        the benchmark and the parity tests)."""
+        self._fuse(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, self._rgb_bilinear)
+
+    def stats(self):
+        """dict of counters accumulated by the kernels (forces a device sync)."""
+        s = self.fuse_stats.cpu().tolist()
+        return {"valid": s[0], "tsdf_valid": s[1], "frames": s[2], "labels_dropped": s[3]}
+
+    def extract_mesh(self):
+        raise NotImplementedError(
+            "extract_mesh (marching cubes + vertex sampling, reference clipfusion.py:723-763) is outside the "
+            "fused hot path built so far; see DESIGN.md 'next rows'"
+        )
+
+
+# --------------------------------------------------------------------------------------------
+# Clip: tiled image features (PyTorch-ROCm backbone) + the text query head (HIP scan)
+# --------------------------------------------------------------------------------------------
+
+
+def _query_scan(feats, text, epilogue, scale=1.0, normalize=False, last_only=False):
+    """Run saf_query_scan on [N,D] f32 features and [L,>=D] f32 text embeddings (both moved to the
+    HIP device if needed); returns [N,L] (or [N] when last_only) on the device of ``feats``."""
+    if not torch.cuda.is_available():
+        raise SafError("the query scan needs the MI355X device; there is no CPU fallback")
+    out_dev = feats.device
+    dev = feats.device if feats.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    f = feats.detach().to(device=dev, dtype=torch.float32)
+    if f.dim() != 2:
+        raise ValueError("features must be [N,D]")
+    if f.stride(1) != 1:
+        f = f.contiguous()
+    t = text.detach().to(device=dev, dtype=torch.float32)
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    n, d = f.shape
+    nl = t.shape[0]
+    if t.shape[1] < d:
+        raise RuntimeError(f"text features have {t.shape[1]} dims, image features {d}")
+    out = None if last_only else torch.empty((n, nl), dtype=torch.float32, device=dev)
+    last = torch.empty(n, dtype=torch.float32, device=dev) if last_only else None
+    wsb = lib().saf_query_workspace_bytes(nl, epilogue)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+    with torch.cuda.device(dev):
+        rc = lib().saf_query_scan(
+            f.data_ptr(), _abi.SAF_F32, n, f.stride(0), d, t.data_ptr(), nl, t.stride(0), epilogue, float(scale),
+            int(bool(normalize)), _abi.ptr(out), _abi.ptr(last), _abi.ptr(ws), wsb, current_stream_ptr(),
+        )
+    check(rc, "saf_query_scan")
+    res = last if last_only else out
+    return res.to(out_dev)
+
+
+class Clip(torch.nn.Module):
+    """Mirror of the reference ``Clip`` (clipfusion.py:766-1039).
+
+    ``backbone``/``tokenizer`` may be injected (any object with ``encode_image``, ``encode_text``
+    and ``visual.output_dim``); by default they come from ``open_clip`` exactly as in the
+    reference (clipfusion.py:769-772).  The ViT GEMMs stay PyTorch-ROCm (hipBLASLt / MFMA).
+    """
+
+    max_patch_batch_size = 64  # the reference caps at 8 (clipfusion.py:826)
+
+    def __init__(self, clip_model, pretraining, backbone=None, tokenizer=None):
+        super().__init__()
+        if backbone is None:
+            try:
+                import open_clip
+            except ImportError as e:  # same failure mode as the reference's module import
+                raise ImportError(
+                    "open_clip is required to build the CLIP backbone (or pass backbone=/tokenizer=)"
+                ) from e
+            backbone = open_clip.create_model(clip_model, pretrained=pretraining, require_pretrained=True)
+            tokenizer = open_clip.get_tokenizer(clip_model)
+        self.clip = backbone
+        self.tokenizer = tokenizer
+        self.channel_mean = torch.nn.Parameter(
+            torch.tensor([0.48145466, 0.4578275, 0.40821073])[None, :, None, None], requires_grad=False
+        )
+        self.channel_std = torch.nn.Parameter(
+            torch.tensor([0.26862954, 0.26130258, 0.27577711])[None, :, None, None], requires_grad=False
+        )
+        self.feature_dim = self.clip.visual.output_dim
+
+    def normalize_img(self, rgb_img_0_1):
+        return (rgb_img_0_1 - self.channel_mean) / self.channel_std
+
+    def unnormalize_img(self, rgb_img_normed):
+        return rgb_img_normed * self.channel_std + self.channel_mean
+
+    def get_patches(self, rgb_imgs, patch_size, patch_stride):
+        """[B,3,H,W] -> [B,npy,npx,3,p,p] overlapping tiles (clipfusion.py:789-806)."""
+        _, _, imheight, imwidth = rgb_imgs.shape
+        assert (imheight - patch_size) % patch_stride == 0
+        assert (imwidth - patch_size) % patch_stride == 0
+        tiles = rgb_imgs.unfold(2, patch_size, patch_stride).unfold(3, patch_size, patch_stride)
+        return tiles.permute(0, 2, 3, 1, 4, 5)
+
+    def img_inference_tiled(self, rgb_imgs, patch_size, patch_stride):
+        """[B,3,H,W] in 0..1 -> [B,D,npy,npx] CLIP embedding per tile (clipfusion.py:808-839)."""
+        patches = self.get_patches(self.normalize_img(rgb_imgs), patch_size, patch_stride)
+        bsz, npy, npx = patches.shape[:3]
+        patches = patches.reshape(bsz * npy * npx, 3, patch_size, patch_size)
+        patches = torch.nn.functional.interpolate(patches, size=(224, 224), mode="bilinear", align_corners=False)
+        feats = torch.empty(len(patches), self.feature_dim, device=rgb_imgs.device)
+        step = int(self.max_patch_batch_size)
+        for start in range(0, len(patches), step):
+            feats[start : start + step] = self.clip.encode_image(patches[start : start + step])
+        return feats.view(bsz, npy, npx, self.feature_dim).permute(0, 3, 1, 2)
+
+    def img_inference_tiled_depthscaled(self, rgb_imgs, depth_imgs, K, patch_stride):
+        raise NotImplementedError(
+            "scale_patches_by_depth is dead code in the reference (always False: clipfusion.py:1097, "
+            "clip_seem_fusion.py:167) and is not part of the fused path"
+        )
+
+    def text_inference(self, str_list):
+        device = next(self.clip.parameters()).device
+        tokens = self.tokenizer(str_list).to(device)
+        feats = self.clip.encode_text(tokens)
+        return feats / feats.norm(dim=-1, keepdim=True)
+
+    def run_query(self, img_feats, labels):
+        """softmax(100 * F @ T^T) over the labels (clipfusion.py:899-904), fused on the GPU."""
+        d = img_feats.shape[-1]
+        text = self.text_inference(labels)[:, :d]
+        flat = img_feats.reshape(-1, d)
+        rel = _query_scan(flat, text, _abi.SAF_Q_SOFTMAX, scale=100.0)
+        return rel.reshape(*img_feats.shape[:-1], text.shape[0])
+
+    @staticmethod
+    def clip_feature_surgery(image_features, text_features, redundant_feats=None, t=2):
+        """[b,n,c] x [t,c] -> [b,n,t] (clipfusion.py:906-934) without the [b,n,t,c] temporary."""
+        if image_features.dim() != 3:
+            raise ValueError("image_features must be [b,n,c]")
+        if redundant_feats is not None:
+            text = text_features - redundant_feats.to(text_features.device)
+            return torch.stack([_query_scan(f, text, _abi.SAF_Q_SCORES) for f in image_features])
+        if image_features.shape[0] != 1:
+            # the reference's `w.reshape(1, 1, n_t, 1)` only works for b == 1
+            raise RuntimeError("clip_feature_surgery without redundant_feats needs a batch of 1")
+        return _query_scan(image_features[0], text_features, _abi.SAF_Q_SURGERY)[None]
+
+    def encode_text_with_prompt_ensemble(self, texts, device, prompt_templates=None):
+        """Mean of L2-normalised prompt embeddings per class, renormalised (clipfusion.py:936-1039)."""
+        if prompt_templates is None:
+            prompt_templates = IMAGENET_PROMPT_TEMPLATES
+        model_device = next(self.clip.parameters()).device
+        feats = []
+        for text in texts:
+            tokens = self.tokenizer([tpl.format(text) for tpl in prompt_templates])
+            emb = self.clip.encode_text(tokens.to(model_device))
+            emb = emb / emb.norm(dim=-1, keepdim=True)
+            emb = emb.mean(dim=0)
+            feats.append(emb / emb.norm())
+        return torch.stack(feats, dim=0).to(device)
+
+
+def _imagenet_templates():
+    """The 85 prompt templates the reference uses by default (OpenAI's ImageNet prompt-engineering
+    set plus five '... in the scene.' scene prompts, clipfusion.py:939-1025), generated from their
+    regular structure rather than listed."""
+    a_the = lambda pat: [pat.format(art) for art in ("a", "the")]
+    singles = [
+        "a photo of many {}.", "a photo of my {}.", "a photo of one {}.", "itap of my {}.",
+        "there is a {} in the scene.", "there is the {} in the scene.", "this is a {} in the scene.",
+        "this is the {} in the scene.", "this is one {} in the scene.",
+    ]
+    paired = [
+        "a bad photo of {} {{}}.", "a sculpture of {} {{}}.", "a photo of {} hard to see {{}}.",
+        "a low resolution photo of {} {{}}.", "a rendering of {} {{}}.", "graffiti of {} {{}}.",
+        "a cropped photo of {} {{}}.", "a tattoo of {} {{}}.", "{} embroidered {{}}.",
+        "a bright photo of {} {{}}.", "a photo of {} clean {{}}.", "a photo of {} dirty {{}}.",
+        "a dark photo of {} {{}}.", "a drawing of {} {{}}.", "{} plastic {{}}.", "a photo of {} cool {{}}.",
+        "a close-up photo of {} {{}}.", "a black and white photo of {} {{}}.", "a painting of {} {{}}.",
+        "a pixelated photo of {} {{}}.", "a jpeg corrupted photo of {} {{}}.", "a blurry photo of {} {{}}.",
+        "a photo of {} {{}}.", "a good photo of {} {{}}.", "{} {{}} in a video game.", "a doodle of {} {{}}.",
+        "{} origami {{}}.", "a sketch of {} {{}}.", "{} toy {{}}.", "a rendition of {} {{}}.",
+        "a photo of {} large {{}}.", "a photo of {} nice {{}}.", "a photo of {} weird {{}}.", "{} cartoon {{}}.",
+        "art of {} {{}}.", "{} plushie {{}}.", "a photo of {} small {{}}.", "itap of {} {{}}.",
+    ]
+    out = list(singles)
+    for pat in paired:
+        out.extend(a_the(pat))
+    return out
+
+
+IMAGENET_PROMPT_TEMPLATES = _imagenet_templates()
+
+
+# --------------------------------------------------------------------------------------------
+# ClipFusion
+# --------------------------------------------------------------------------------------------
+
+
+class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
+    """Dense voxel volume with projective running-average fusion (reference clipfusion.py:575-763).
+
+    Constructor, attributes and registered buffer names follow the reference; ``integrate`` runs
+    the hand-written HIP path (include/saf.h: saf_fuse_frames).  ``clip`` may be passed as a ready
+    ``Clip``-like object through ``clip_model`` (anything with ``feature_dim`` and
+    ``img_inference_tiled``), which is how tests and the benchmark inject seeded feature maps.
+    """
+
+    _rgb_bilinear = False  # nearest rgb sampling (clipfusion.py:701-706)
+
+    def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_model, clip_pretraining,
+                 clip_patch_size, clip_patch_stride, keep_xyz_world=True):
+        super().__init__()
+        if isinstance(clip_model, str):
+            self.clip = Clip(clip_model, clip_pretraining)
+            self.clip.requires_grad_(False)
+            self.clip.eval()
+        else:
+            self.clip = clip_model
+        self.clip_patch_size = clip_patch_size
+        self.clip_patch_stride = clip_patch_stride
+        self.scale_patches_by_depth = scale_patches_by_depth
+        self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, 0, keep_xyz_world)
+
+    def integrate(self, depth_imgs, rgb_imgs, poses, K):
+        """Fuse a batch of frames (reference clipfusion.py:627-721).  Batch elements are folded in
+        one after the other; for B > 1 the reference updates the TSDF jointly over the batch
+        (:681-695), which is the same mean up to fp32 rounding."""
+        if self.scale_patches_by_depth:
+            clip_feat_img = self.clip.img_inference_tiled_depthscaled(
+                rgb_imgs.permute(0, 3, 1, 2), depth_imgs, K, patch_stride=self.clip_patch_stride
+            )
+        else:
+            clip_feat_img = self.clip.img_inference_tiled(
+                rgb_imgs.permute(0, 3, 1, 2), patch_size=self.clip_patch_size, patch_stride=self.clip_patch_stride
+            )
+        self._fuse(depth_imgs, rgb_imgs, poses, K, clip_feat_img, None, False)
+
+
+# --------------------------------------------------------------------------------------------
+# backproject_pcd / bounds
+# --------------------------------------------------------------------------------------------
+
+
+def get_pix_vecs(imwidth, imheight, K):
+    """Ray direction K^-1 [u,v,1]^T of every pixel, [B,H*W,3] (reference clipfusion.py:497-507).
+    Kept for API compatibility; backproject_pcd below evaluates only the 7x7 lattice on the GPU."""
+    v, u = torch.meshgrid(
+        torch.arange(imheight, dtype=torch.float32, device=K.device),
+        torch.arange(imwidth, dtype=torch.float32, device=K.device),
+        indexing="ij",
+    )
+    uv1 = torch.stack((u, v, torch.ones_like(u)), dim=0).reshape(3, -1)
+    return (K.inverse() @ uv1).transpose(1, 2)
+
+
+def backproject_pcd(dataset, batch_size=1, num_workers=0, device="cpu", max_depth=torch.inf):
+    """Sparse world-space point cloud of a scan: a 7x7 pixel lattice per frame un-projected with
+    its depth (reference clipfusion.py:510-572).  The per-frame arithmetic runs in
+    saf_backproject_lattice on the HIP device; ``device`` only says where the frames are staged
+    in the reference and is accepted for compatibility.  Returns (xyz[M,3], rgb[M,3]) on the CPU."""
+    if not torch.cuda.is_available():
+        raise SafError("backproject_pcd needs the MI355X device; there is no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, num_workers=num_workers)
+    uv_size = 7
+    u = torch.round(torch.linspace(0, dataset.imwidth - 1, uv_size)).to(torch.int32)
+    v = torch.round(torch.linspace(0, dataset.imheight - 1, uv_size)).to(torch.int32)
+    u_dev, v_dev = u.to(dev), v.to(dev)
+    vv, uu = torch.meshgrid(v.long(), u.long(), indexing="ij")
+    vv, uu = vv.reshape(-1), uu.reshape(-1)
+    npts = uv_size * uv_size
+    xyz_all, rgb_all = [], []
+    for rgb_imgs, depth_imgs, poses, K, _ in loader:
+        bsz = len(rgb_imgs)
+        depth_d = depth_imgs.to(dev, torch.float32).contiguous()
+        poses_d = poses.to(dev, torch.float32).contiguous()
+        kinv_d = K.to(torch.float32).inverse().to(dev).contiguous()
+        xyz = torch.empty((bsz, npts, 3), dtype=torch.float32, device=dev)
+        valid = torch.empty((bsz, npts), dtype=torch.uint8, device=dev)
+        for i in range(bsz):
+            rc = lib().saf_backproject_lattice(
+                depth_d[i].data_ptr(), dataset.imheight, dataset.imwidth, poses_d[i].data_ptr(), kinv_d[i].data_ptr(),
+                u_dev.data_ptr(), uv_size, v_dev.data_ptr(), uv_size, float(max_depth), xyz[i].data_ptr(),
+                valid[i].data_ptr(), current_stream_ptr(),
+            )
+            check(rc, "saf_backproject_lattice")
+        valid = valid.bool().cpu()
+        xyz_all.append(xyz.cpu()[valid])
+        rgb_all.append(rgb_imgs[:, vv, uu][valid])
+    return torch.cat(xyz_all, dim=0), torch.cat(rgb_all, dim=0)
+
+
+def scene_bounds(xyz, voxel_size, trunc_m):
+    """origin / nvox of the volume from the sparse cloud: 1st / 99th percentile -/+ trunc
+    (reference clipfusion.py:1098-1106, clip_seem_fusion.py:278-287)."""
+    pts = xyz.cpu().numpy() if isinstance(xyz, torch.Tensor) else np.asarray(xyz)
+    minbound = torch.tensor(np.percentile(pts, 1, axis=0)).float() - trunc_m
+    maxbound = torch.tensor(np.percentile(pts, 99, axis=0)).float() + trunc_m
+    nvox = ((maxbound - minbound) / voxel_size).round().int()
+    return minbound, nvox

@@ -1,0 +1,177 @@
+// saf_misc.hip -- the small kernels either side of the fuse loop:
+//   * backproject_lattice : per-frame body of backproject_pcd (reference clipfusion.py:541-565)
+//   * merge_finalize / mean_to_sum : sums <-> means around the cross-rank reduction
+//   * label_argmax : argmax-with-empty-check of the label histogram (clip_seem_fusion.py:315-325)
+#include "saf_common.h"
+#include "saf_host.h"
+
+#pragma clang fp contract(off)
+
+namespace saf {
+namespace {
+
+// xyz_cam = pix_vec * depth ; world = R @ xyz_cam + t      clipfusion.py:553-558
+__global__ void backproject_kernel(const float* __restrict__ depth, int width, const float* __restrict__ pose,
+                                   const float* __restrict__ Kinv, const int* __restrict__ u_idx, int nu,
+                                   const int* __restrict__ v_idx, int nv, float max_depth, float* __restrict__ xyz,
+                                   uint8_t* __restrict__ valid) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= nu * nv) return;
+  const int j = o / nu, i = o - j * nu;
+  const int u = u_idx[i], v = v_idx[j];
+  const float d = depth[(int64_t)v * width + u];
+  const float fu = (float)u, fv = (float)v;
+  // get_pix_vecs: K^-1 @ [u, v, 1]^T                      clipfusion.py:497-507
+  const float rx = dot3(Kinv[0], Kinv[1], Kinv[2], fu, fv, 1.0f);
+  const float ry = dot3(Kinv[3], Kinv[4], Kinv[5], fu, fv, 1.0f);
+  const float rz = dot3(Kinv[6], Kinv[7], Kinv[8], fu, fv, 1.0f);
+  const float cx = rx * d, cy = ry * d, cz = rz * d;
+  xyz[(int64_t)o * 3 + 0] = dot3(pose[0], pose[1], pose[2], cx, cy, cz) + pose[3];
+  xyz[(int64_t)o * 3 + 1] = dot3(pose[4], pose[5], pose[6], cx, cy, cz) + pose[7];
+  xyz[(int64_t)o * 3 + 2] = dot3(pose[8], pose[9], pose[10], cx, cy, cz) + pose[11];
+  // valid = ~isnan(depth) & (depth > 0) & (depth < max_depth)   :551
+  valid[o] = (uint8_t)((d == d) && (d > 0.0f) && (d < max_depth));
+}
+
+// feature rows: x /= w (TO_MEAN) or x *= w; 16-byte accesses when D % 4 == 0
+template <bool TO_MEAN, int VEC>
+__global__ void scale_rows_kernel(float* __restrict__ feat, const int* __restrict__ weight, int64_t first,
+                                  int64_t count, int DV) {
+  const int64_t total = count * DV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = first + i / DV;
+    const int w = weight[n];
+    if (TO_MEAN && w <= 0) continue;
+    const float fw = (float)w;
+    if (VEC == 4) {
+      float4* p = reinterpret_cast<float4*>(feat) + first * DV + i;
+      float4 x = *p;
+      if (TO_MEAN) { x.x = x.x / fw; x.y = x.y / fw; x.z = x.z / fw; x.w = x.w / fw; }
+      else         { x.x = x.x * fw; x.y = x.y * fw; x.z = x.z * fw; x.w = x.w * fw; }
+      *p = x;
+    } else {
+      float* p = feat + first * DV + i;
+      *p = TO_MEAN ? *p / fw : *p * fw;
+    }
+  }
+}
+
+template <bool TO_MEAN>
+__global__ void scale_scalars_kernel(float* __restrict__ rgb, float* __restrict__ tsdf, const int* __restrict__ weight,
+                                     const int* __restrict__ tsdf_w, int64_t first, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = first + i;
+    const int w = weight[n], wt = tsdf_w[n];
+    if (TO_MEAN) {
+      if (w > 0) {
+        const float fw = (float)w;
+        rgb[n * 3 + 0] = rgb[n * 3 + 0] / fw;
+        rgb[n * 3 + 1] = rgb[n * 3 + 1] / fw;
+        rgb[n * 3 + 2] = rgb[n * 3 + 2] / fw;
+      }
+      if (wt > 0) tsdf[n] = tsdf[n] / (float)wt;
+    } else {
+      const float fw = (float)w;
+      rgb[n * 3 + 0] = rgb[n * 3 + 0] * fw;
+      rgb[n * 3 + 1] = rgb[n * 3 + 1] * fw;
+      rgb[n * 3 + 2] = rgb[n * 3 + 2] * fw;
+      tsdf[n] = tsdf[n] * (float)wt;
+    }
+  }
+}
+
+template <bool TO_MEAN>
+int scale_volume(const saf_volume* vol, int64_t first, int64_t count, hipStream_t s) {
+  if (!vol || !vol->clip_feat || !vol->weight || !vol->tsdf_weight || !vol->rgb || !vol->tsdf)
+    return fail(SAF_E_INVALID, "merge: volume has a NULL buffer");
+  if (vol->feat_dtype != SAF_F32) return fail(SAF_E_UNSUPPORTED, "merge: only SAF_F32");
+  const int64_t N = n_voxels(vol);
+  if (first < 0 || count < 0 || first + count > N) return fail(SAF_E_INVALID, "merge: bad voxel range");
+  if (count == 0) return SAF_OK;
+  const int D = vol->feat_dim;
+  const int cap = device_cus() * 8;
+  float* feat = static_cast<float*>(vol->clip_feat);
+  if (D % 4 == 0 && ((uintptr_t)feat & 15) == 0) {
+    const int64_t total = count * (D / 4);
+    const int blocks = (int)((total + 255) / 256 < cap ? (total + 255) / 256 : cap);
+    hipLaunchKernelGGL((scale_rows_kernel<TO_MEAN, 4>), dim3(blocks), dim3(256), 0, s, feat, vol->weight, first, count,
+                       D / 4);
+  } else {
+    const int64_t total = count * D;
+    const int blocks = (int)((total + 255) / 256 < cap ? (total + 255) / 256 : cap);
+    hipLaunchKernelGGL((scale_rows_kernel<TO_MEAN, 1>), dim3(blocks), dim3(256), 0, s, feat, vol->weight, first, count,
+                       D);
+  }
+  int rc = check_launch("scale_rows_kernel");
+  if (rc) return rc;
+  const int blocks = (int)((count + 255) / 256 < cap ? (count + 255) / 256 : cap);
+  hipLaunchKernelGGL(scale_scalars_kernel<TO_MEAN>, dim3(blocks), dim3(256), 0, s, vol->rgb, vol->tsdf, vol->weight,
+                     vol->tsdf_weight, first, count);
+  return check_launch("scale_scalars_kernel");
+}
+
+// one wave per voxel row of the histogram; first maximum wins (torch.argmax on CPU), empty row -> -1
+__global__ __launch_bounds__(256) void label_argmax_kernel(const int* __restrict__ labels, int64_t n_vox, int C,
+                                                            int* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t n = wave; n < n_vox; n += n_waves) {
+    const int* r = labels + n * C;
+    unsigned long long best = 0ull;
+    int any = 0;
+    for (int c = lane; c < C; c += 64) {
+      const int val = r[c];
+      any |= (val != 0);
+      // order by (value, -index): bias the value to unsigned, store ~index in the low word
+      const unsigned long long key = ((unsigned long long)((uint32_t)val ^ 0x80000000u) << 32) | (uint32_t)(~(uint32_t)c);
+      best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(best, o);
+      best = other > best ? other : best;
+      any |= __shfl_xor(any, o);
+    }
+    if (lane == 0) out[n] = any ? (int)(~(uint32_t)(best & 0xffffffffull)) : -1;
+  }
+}
+
+}  // namespace
+}  // namespace saf
+
+using namespace saf;
+
+extern "C" {
+
+int saf_backproject_lattice(const float* depth, int32_t height, int32_t width, const float* pose, const float* Kinv,
+                            const int32_t* u_idx, int32_t nu, const int32_t* v_idx, int32_t nv, float max_depth,
+                            float* xyz, uint8_t* valid, void* stream) {
+  if (!depth || !pose || !Kinv || !u_idx || !v_idx || !xyz || !valid || height <= 0 || width <= 0 || nu <= 0 || nv <= 0)
+    return fail(SAF_E_INVALID, "backproject: bad arguments");
+  const int total = nu * nv;
+  hipLaunchKernelGGL(backproject_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     depth, width, pose, Kinv, u_idx, nu, v_idx, nv, max_depth, xyz, valid);
+  return check_launch("backproject_kernel");
+}
+
+int saf_merge_finalize(const saf_volume* vol, int64_t first_voxel, int64_t count, void* stream) {
+  return scale_volume<true>(vol, first_voxel, count, static_cast<hipStream_t>(stream));
+}
+
+int saf_mean_to_sum(const saf_volume* vol, int64_t first_voxel, int64_t count, void* stream) {
+  return scale_volume<false>(vol, first_voxel, count, static_cast<hipStream_t>(stream));
+}
+
+int saf_label_argmax(const int32_t* labels_one_hot, int64_t n_vox, int32_t n_classes, int32_t* out, void* stream) {
+  if (!labels_one_hot || !out || n_vox < 0 || n_classes <= 0) return fail(SAF_E_INVALID, "label_argmax: bad arguments");
+  if (n_vox == 0) return SAF_OK;
+  int64_t blocks = (n_vox + 3) / 4;
+  const int64_t cap = (int64_t)device_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(label_argmax_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     labels_one_hot, n_vox, n_classes, out);
+  return check_launch("label_argmax_kernel");
+}
+
+}  // extern "C"

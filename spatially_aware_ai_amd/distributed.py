@@ -1,0 +1,157 @@
+"""Frame-sharded multi-GPU fusion (new capability; the reference is single-device).
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI on ROCm).  Frames
+are independent units, so rank r fuses its contiguous block of frames into a private volume kept
+as SUMS (``accum_mode = SAF_SUM``: F = sum of feature samples, C = sum of rgb, T = sum of clamped
+sdf, integer weights / label counts).  A per-voxel running mean equals sum / count, so the merge
+is one element-wise SUM across ranks followed by a local divide:
+
+  * ``mode="reduce_scatter"`` (default): rank k receives the reduced voxel range k -- every xGMI
+    link carries 1/world of the volume once, and the volume stays voxel-sharded, which is what the
+    sharded text-query scan wants; ``gather=True`` adds the all-gather.
+  * ``mode="all_reduce"``: every rank ends with the full merged volume.
+
+Integer tensors merge exactly; the valid sets are per frame, hence unaffected by sharding.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _abi
+from ._lib import check, current_stream_ptr, lib
+
+_CHUNK_ELEMS = 1 << 28  # collectives are issued in <= 1 GiB (fp32) pieces
+
+
+def shard_frames(n_frames: int, rank: int, world: int) -> range:
+    """Contiguous block of frames owned by ``rank`` (first ranks take the remainder)."""
+    base, rem = divmod(n_frames, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def voxel_shard(n_voxels: int, rank: int, world: int):
+    """(first, count) of the voxel range rank owns after a reduce-scatter merge: equal blocks of
+    n_voxels // world, the remainder goes to the last rank."""
+    per = n_voxels // world
+    first = rank * per
+    count = per if rank < world - 1 else n_voxels - first
+    return first, count
+
+
+def _chunks(t: torch.Tensor):
+    flat = t.reshape(-1)
+    for s in range(0, flat.numel(), _CHUNK_ELEMS):
+        yield flat[s : s + _CHUNK_ELEMS]
+
+
+def _all_reduce(t, group):
+    for c in _chunks(t):
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+
+
+def _reduce_scatter_rows(t, group, rank, world):
+    """Sum dim-0 row blocks across ranks so that rank k holds the reduced rows of voxel_shard(k);
+    other rows keep this rank's partial sums."""
+    n = t.shape[0]
+    per = n // world
+    backend = dist.get_backend(group)
+    if per > 0:
+        main = t[: per * world]
+        if backend == "nccl":
+            # RCCL in-place form: the receive buffer is this rank's block of the send buffer
+            # (recvbuff == sendbuff + rank * recvcount), so no staging copy of the volume is made.
+            dist.reduce_scatter_tensor(main[rank * per : (rank + 1) * per], main, op=dist.ReduceOp.SUM, group=group)
+        else:  # gloo has no reduce_scatter: one rooted reduce per destination
+            for k in range(world):
+                dist.reduce(main[k * per : (k + 1) * per], dst=dist.get_global_rank(group, k) if group else k,
+                            op=dist.ReduceOp.SUM, group=group)
+    if n > per * world:  # remainder rows belong to the last rank
+        tail = t[per * world :]
+        dst = world - 1
+        dist.reduce(tail, dst=dist.get_global_rank(group, dst) if group else dst, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather_rows(t, group, rank, world):
+    n = t.shape[0]
+    per = n // world
+    if per > 0:
+        main = t[: per * world]
+        outs = [main[k * per : (k + 1) * per] for k in range(world)]
+        dist.all_gather(outs, main[rank * per : (rank + 1) * per].clone(), group=group)
+    if n > per * world:
+        src = world - 1
+        dist.broadcast(t[per * world :], src=dist.get_global_rank(group, src) if group else src, group=group)
+
+
+VOLUME_TENSORS = ("clip_feat", "rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot")
+
+
+def merge_sums(tensors: dict, group=None, mode: str = "reduce_scatter", gather: bool = False):
+    """Element-wise SUM of per-rank volume tensors (dict name -> tensor with voxels on dim 0).
+    Device-agnostic (RCCL on GPUs, gloo in the CPU tests).  Returns (first, count): the voxel range
+    that is fully reduced on this rank."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = next(iter(tensors.values())).shape[0]
+    if world == 1:
+        return 0, n
+    if mode == "all_reduce":
+        for t in tensors.values():
+            _all_reduce(t, group)
+        return 0, n
+    if mode != "reduce_scatter":
+        raise ValueError(mode)
+    for t in tensors.values():
+        _reduce_scatter_rows(t, group, rank, world)
+    if gather:
+        for t in tensors.values():
+            _all_gather_rows(t, group, rank, world)
+        return 0, n
+    return voxel_shard(n, rank, world)
+
+
+def _volume_tensors(fusion):
+    return {k: getattr(fusion, k) for k in VOLUME_TENSORS if getattr(fusion, k, None) is not None}
+
+
+def finalize_sums(fusion, first: int = 0, count: int | None = None):
+    """sums -> means on the HIP device over voxels [first, first+count) (saf_merge_finalize); when
+    the whole volume is covered the module returns to running-mean mode."""
+    n = fusion.tsdf.numel()
+    count = n - first if count is None else count
+    vol = fusion._c_volume()
+    with torch.cuda.device(fusion.tsdf.device):
+        check(lib().saf_merge_finalize(C.byref(vol), first, count, current_stream_ptr()), "saf_merge_finalize")
+    if first == 0 and count == n:
+        fusion.accum_mode = _abi.SAF_RUNNING_MEAN
+
+
+def means_to_sums(fusion):
+    """Turn a running-mean volume into sums (x * w) so it can enter the reduction."""
+    vol = fusion._c_volume()
+    with torch.cuda.device(fusion.tsdf.device):
+        check(lib().saf_mean_to_sum(C.byref(vol), 0, fusion.tsdf.numel(), current_stream_ptr()), "saf_mean_to_sum")
+    fusion.accum_mode = _abi.SAF_SUM
+
+
+def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool = False):
+    """The single merge step of the frame-sharded job: RCCL SUM of the per-rank sum volumes, then
+    the local divide.  ``fusion`` must have been fused with ``accum_mode = SAF_SUM`` (call
+    ``means_to_sums`` first otherwise).  Returns the (first, count) voxel range that holds final
+    means on this rank."""
+    if fusion.accum_mode != _abi.SAF_SUM:
+        means_to_sums(fusion)
+    tensors = _volume_tensors(fusion)
+    first, count = merge_sums(tensors, group=group, mode=mode, gather=False)
+    finalize_sums(fusion, first, count)
+    if gather and mode == "reduce_scatter" and dist.get_world_size(group) > 1:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        for t in tensors.values():
+            _all_gather_rows(t, group, rank, world)
+        fusion.accum_mode = _abi.SAF_RUNNING_MEAN
+        return 0, fusion.tsdf.numel()
+    return first, count
