@@ -242,6 +242,19 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """Host threads this process may really use: the scheduler affinity capped by the cgroup CPU
+    quota (the GPU boxes expose 256 hardware threads but grant a 16-CPU share per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(a, grid, depth, rgb, poses, ks, feat, npy, npx):
     """Times oracle/saf_oracle.c (test infrastructure, used here only as the reported CPU
     baseline) on the first few frames of this workload with all host cores of the box."""
@@ -249,7 +262,7 @@ def cpu_baseline(a, grid, depth, rgb, poses, ks, feat, npy, npx):
         from oracle import oracle as O
     except Exception as e:  # the oracle is optional for the benchmark line
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     O.set_threads(cores)
     n = a.cpu_frames if a.cpu_frames > 0 else 17
     n = min(n, depth.shape[0])

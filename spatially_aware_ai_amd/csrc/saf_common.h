@@ -22,6 +22,20 @@ constexpr int kSweepPerThread = 16;  // voxels per thread -> 4096 voxels per swe
 constexpr int kSweepChunk = kSweepThreads * kSweepPerThread;
 constexpr int kFuseThreads = 512;
 
+// Streamed volume rows are touched once per frame and the volume (GBs) dwarfs every cache:
+// non-temporal accesses bypass the 32 KiB vector L1, whose line count otherwise caps the misses a
+// CU can keep in flight (measured: TCP pending-stall 81 %, ~11 KB in flight per CU with plain loads).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+  const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream(float4* p, const float4 x) {
+  v4f_t v;
+  v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(p));
+}
+
 // n / d for n < 2^31 by multiply-shift (exact; see saf_fuse.hip make_fastdiv).
 struct FastDiv {
   uint32_t mul, shift, d, pad;
