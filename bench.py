@@ -182,7 +182,7 @@ def main():
         avg_fuse_s = ms["fuse"][0] / n_launch * 1e-3
         achieved = fuse_bytes / avg_fuse_s / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_fuse_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01", "fuse_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -204,6 +204,29 @@ def main():
             "sweep_algorithmic_bytes": int(sweep_bytes),
             "frame_algorithmic_bytes": int(frame_bytes),
             "frame_hbm_frac": round(frame_bytes / (dt / (a.frames * a.steps)) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+
+    # ---- the same kernel timed alone (one frame per call = no sweep running beside it) ----
+    if roofline is not None and rank == 0:
+        n_iso = min(32, a.frames)
+        prof2 = L.saf_profiler_create(3 * n_iso)
+        torch.cuda.synchronize()
+        for i in range(n_iso):
+            check(L.saf_fuse_frames_profiled(C.byref(vol), C.byref(frames[i]), 1, ws.data_ptr(), ws.numel(),
+                                             fusion.fuse_stats.data_ptr(), prof2, stream), "isolated pass")
+        torch.cuda.synchronize()
+        tot, n = C.c_double(0), C.c_int64(0)
+        check(L.saf_profiler_read(prof2, 2, C.byref(tot), C.byref(n)), "saf_profiler_read")
+        tot_s, n_s = C.c_double(0), C.c_int64(0)
+        check(L.saf_profiler_read(prof2, 1, C.byref(tot_s), C.byref(n_s)), "saf_profiler_read")
+        L.saf_profiler_destroy(prof2)
+        iso_s = tot.value / max(1, n.value) * 1e-3
+        roofline["isolated"] = {
+            "avg_launch_us": round(iso_s * 1e6, 2), "achieved": round(fuse_bytes / iso_s / 1e9, 1),
+            "frac": round(fuse_bytes / iso_s / 1e9 / HBM_PEAK_GBS, 4), "launches": int(n.value),
+            "sweep_us": round(tot_s.value / max(1, n_s.value) * 1e3, 2),
+            "note": "fuse kernel alone on the chip (2 workgroups/CU); the timed region overlaps it with the next "
+                    "frame's sweep",
         }
 
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1 only) ----

@@ -21,6 +21,7 @@ constexpr int kSweepThreads = 256;
 constexpr int kSweepPerThread = 16;  // voxels per thread -> 4096 voxels per sweep block
 constexpr int kSweepChunk = kSweepThreads * kSweepPerThread;
 constexpr int kFuseThreads = 512;
+constexpr int kAxisLds = 1024;       // axis tables staged in LDS by the sweep when nx+ny+nz fits (4 KiB)
 
 // Streamed volume rows are touched once per frame and the volume (GBs) dwarfs every cache:
 // non-temporal accesses bypass the 32 KiB vector L1, whose line count otherwise caps the misses a
@@ -89,17 +90,26 @@ struct Proj {
   float gx, gy, z;
 };
 
-// clipfusion.py:647-659: voxel centre -> normalised image coordinates + camera depth.
-__device__ __forceinline__ Proj project(const Cam& c, float xw, float yw, float zw) {
+// uvz = K @ (R^T (x - t))   (clipfusion.py:648-653): homogeneous pixel coordinates, no division yet.
+struct Uvz {
+  float u, v, z;
+};
+__device__ __forceinline__ Uvz project_uvz(const Cam& c, float xw, float yw, float zw) {
   float dx = xw - c.tx, dy = yw - c.ty, dz = zw - c.tz;
   float cx = dot3_rt(c.r00, c.r10, c.r20, dx, dy, dz);
   float cy = dot3_rt(c.r01, c.r11, c.r21, dx, dy, dz);
   float cz = dot3_rt(c.r02, c.r12, c.r22, dx, dy, dz);
-  float u = dot3(c.k00, c.k01, c.k02, cx, cy, cz);
-  float v = dot3(c.k10, c.k11, c.k12, cx, cy, cz);
-  float z = dot3(c.k20, c.k21, c.k22, cx, cy, cz);
+  Uvz r;
+  r.u = dot3(c.k00, c.k01, c.k02, cx, cy, cz);
+  r.v = dot3(c.k10, c.k11, c.k12, cx, cy, cz);
+  r.z = dot3(c.k20, c.k21, c.k22, cx, cy, cz);
+  return r;
+}
+
+// clipfusion.py:654-659: uv = uvz[:2] / z ; grid = ((uv + 0.5) / [W, H]) * 2 - 1
+__device__ __forceinline__ Proj finish_projection(const Cam& c, const Uvz& h) {
   Proj p;
-  float gx = u / z, gy = v / z;
+  float gx = h.u / h.z, gy = h.v / h.z;
   gx = gx + 0.5f;
   gy = gy + 0.5f;
   gx = gx / c.fw;
@@ -108,8 +118,13 @@ __device__ __forceinline__ Proj project(const Cam& c, float xw, float yw, float 
   gy = gy * 2.0f;
   p.gx = gx - 1.0f;
   p.gy = gy - 1.0f;
-  p.z = z;
+  p.z = h.z;
   return p;
+}
+
+// clipfusion.py:647-659: voxel centre -> normalised image coordinates + camera depth.
+__device__ __forceinline__ Proj project(const Cam& c, float xw, float yw, float zw) {
+  return finish_projection(c, project_uvz(c, xw, yw, zw));
 }
 
 // Nearest-neighbour grid_sample tap (zeros padding): pixel offset or -1.

@@ -17,6 +17,7 @@
 //
 // All arithmetic that selects voxels is shared with the oracle's restatement via saf_common.h.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "saf_common.h"
@@ -76,126 +77,227 @@ __device__ __forceinline__ void voxel_coords(const KVol& v, uint32_t n, int& ix,
   ix = (int)x;
 }
 
+// Workspace: a 512-byte header with four rotating sets of list counters (frame i uses set i & 3
+// and zeroes set (i+1) & 3 for its successor), then TWO halves (double buffering for the
+// sweep/fuse pipeline of saf_fuse_frames), each holding the compact lists of one frame and -- only
+// for feature maps too large for LDS -- a re-laid-out copy of the map.
+constexpr size_t kHdrBytes = 512;
+constexpr int kCounterSets = 4;
 struct WsLayout {
-  size_t counts_off, map_off, lists_off, total;
+  size_t map_off, lists_off, half, total;
   uint32_t n_blocks, list_cap;
+  bool lds_map;
 };
+
+// Feature-map image used by the fuse kernels: [D/VEC][Ppad][VEC] floats, i.e. channel-major like
+// the backbone's [D][P] output but with channels grouped per lane access (VEC = 4 when D % 4 == 0)
+// and each group padded to an ODD number of tap positions Ppad >= P + 1.  Position P (and the
+// padding) holds zeros = grid_sample's zero padding.  Lane l reads 16 bytes at
+// ((ch_l * Ppad + tap) * 16): consecutive lanes are 4*Ppad words apart, and 4*odd is
+// conflict-free over the 64 LDS banks for every 16-lane group of a ds_read_b128.
+__host__ __device__ inline int map_ppad(int P) { return (P + 1) | 1; }
+size_t lds_map_bytes(int D, int P) { return (size_t)D * map_ppad(P) * sizeof(float); }
 
 WsLayout ws_layout(int64_t n_vox, int D, int P) {
   WsLayout w;
   w.n_blocks = (uint32_t)((n_vox + kSweepChunk - 1) / kSweepChunk);
   uint32_t per_list = (w.n_blocks + kNumLists - 1) / kNumLists;
   w.list_cap = per_list * kSweepChunk;
-  w.counts_off = 0;
-  w.map_off = 256;
-  size_t map_bytes = ((size_t)D * (P + 1) * sizeof(float) + 255) & ~(size_t)255;
+  w.lds_map = lds_map_bytes(D, P) <= 144 * 1024;
+  w.map_off = 0;  // the map image, used when !lds_map
+  size_t map_bytes = w.lds_map ? 0 : ((lds_map_bytes(D, P) + 255) & ~(size_t)255);
   w.lists_off = w.map_off + map_bytes;
-  w.total = w.lists_off + (size_t)kNumLists * w.list_cap * sizeof(uint32_t);
+  w.half = w.lists_off + (size_t)kNumLists * w.list_cap * sizeof(uint32_t);
+  w.half = (w.half + 255) & ~(size_t)255;
+  w.total = kHdrBytes + 2 * w.half;
   return w;
 }
 
 // ------------------------------------------------------------------------------------------
-// prep: feature map [Dm>=D][P] -> [P][D]; zero list counters
+// Feature-map image: element (c, p) of the backbone's [D][P] map goes to float index
+// ((c / VEC) * Ppad + p) * VEC + c % VEC; everything else is zero.
 // ------------------------------------------------------------------------------------------
-__global__ void prep_kernel(const float* __restrict__ feat_map, float* __restrict__ map_t, int D, int P,
-                            unsigned long long* __restrict__ counts) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kNumLists) counts[i] = 0ull;
-  if (i < D * P) {
-    int p = i / D, c = i - p * D;
-    map_t[i] = feat_map[(size_t)c * P + p];
-  } else if (i < D * (P + 1)) {
-    map_t[i] = 0.0f;  // row P: the zero padding every out-of-map tap reads
+__device__ __forceinline__ void fill_map_image(float* __restrict__ dst, const float* __restrict__ feat_map, int D,
+                                               int P, int vec, int tid, int nthreads) {
+  const int ppad = map_ppad(P);
+  const int total = D * ppad;
+  const int vshift = vec == 4 ? 2 : 0;
+  const float rp = 1.0f / (float)ppad;
+  for (int o = tid; o < total; o += nthreads) {
+    const int k = o & (vec - 1), t = o >> vshift;  // t = cv * ppad + p
+    // t / ppad via floor((t + 0.5) * fl(1/ppad)): exact for t < 2^22 (see sdiv)
+    const int cv = (int)(((float)t + 0.5f) * rp), p = t - cv * ppad;
+    dst[o] = p < P ? feat_map[(size_t)((cv << vshift) + k) * P + p] : 0.0f;
   }
 }
 
+// Only when the image does not fit LDS: build it once per frame in the workspace.
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ feat_map, float* __restrict__ map_img,
+                                                   int D, int P, int vec) {
+  fill_map_image(map_img, feat_map, D, P, vec, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
 // ------------------------------------------------------------------------------------------
-// sweep: classify every voxel, TSDF running mean, compact the valid ones
+// sweep: classify every voxel, TSDF running mean, compact the valid ones.
+//
+// A block owns kSweepChunk = 4096 consecutive voxels; a thread owns 4 runs of 4 CONSECUTIVE
+// voxels (flat index n..n+3, i.e. along z), so the TSDF value / weight of a run is one 16-byte
+// access and a wave covers 256 consecutive voxels.  The four voxels of a run are processed in
+// lock step (ILP 4): all depth gathers, then all TSDF loads, are in flight together.
 // ------------------------------------------------------------------------------------------
-constexpr int kSweepIlp = 4;  // voxels in flight per thread: hides table / depth / TSDF latency
+constexpr int kRun = 4;
+constexpr int kRunsPerThread = kSweepPerThread / kRun;
+
+// t / d for 0 <= t < 2^13, 1 <= d: floor((t + 0.5) * fl(1/d)) -- the product's error (< 2^-10/d) is
+// far below the 0.5/d distance of (t + 0.5)/d from any integer.  Divisors above 4096 take compares
+// (t < 4096 + d <= 2d there).
+struct SmallDiv {
+  float r;
+  uint32_t d;
+};
+__device__ __forceinline__ uint32_t sdiv(uint32_t t, const SmallDiv& f) {
+  if (f.d > 4096u) return t >= f.d ? 1u : 0u;
+  return (uint32_t)(((float)t + 0.5f) * f.r);
+}
 
 __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(KVol v, KFrame f,
                                                                unsigned long long* __restrict__ counts,
+                                                               unsigned long long* __restrict__ next_counts,
                                                                uint32_t* __restrict__ lists, uint32_t list_cap) {
   __shared__ uint32_t s_buf[kSweepChunk];
+  __shared__ float s_axes[kAxisLds];
   __shared__ uint32_t s_count, s_base, s_nt;
   const int tid = threadIdx.x, lane = tid & 63;
   const Cam cam = load_cam(f.pose, f.K, f.W, f.H);
+  const bool lds_axes = v.nx + v.ny + v.nz <= kAxisLds;
+  if (lds_axes) {
+    for (int i = tid; i < v.nx + v.ny + v.nz; i += kSweepThreads)
+      s_axes[i] = i < v.nx ? v.ax[i] : (i < v.nx + v.ny ? v.ay[i - v.nx] : v.az[i - v.nx - v.ny]);
+  }
   if (tid == 0) {
     s_count = 0;
     s_nt = 0;
   }
+  if (blockIdx.x == 0 && tid < kNumLists) next_counts[tid] = 0ull;  // the successor frame's counters
   __syncthreads();
+  const float* ax = lds_axes ? s_axes : v.ax;
+  const float* ay = lds_axes ? s_axes + v.nx : v.ay;
+  const float* az = lds_axes ? s_axes + v.nx + v.ny : v.az;
+  // coordinates of the block's first voxel (uniform), then small per-thread offsets
   const uint32_t chunk_base = blockIdx.x * (uint32_t)kSweepChunk;
+  int bx, by, bz;
+  voxel_coords(v, chunk_base < v.N ? chunk_base : 0u, bx, by, bz);
+  const SmallDiv dz{1.0f / (float)v.nz, (uint32_t)v.nz}, dy{1.0f / (float)v.ny, (uint32_t)v.ny};
+  const bool aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
   uint32_t nt_local = 0;
-  for (int k0 = 0; k0 < kSweepPerThread; k0 += kSweepIlp) {
-    uint32_t n[kSweepIlp];
-    Proj p[kSweepIlp];
-    int pix[kSweepIlp];
-    bool in_view[kSweepIlp], valid[kSweepIlp], tv[kSweepIlp];
-    float depth[kSweepIlp], sdf[kSweepIlp], told[kSweepIlp];
-    int w0[kSweepIlp];
-    // phase 1: voxel centre -> image (clipfusion.py:647-659); all table loads issued together
-    float xw[kSweepIlp], yw[kSweepIlp], zw[kSweepIlp];
+  for (int g = 0; g < kRunsPerThread; ++g) {
+    const uint32_t off = (uint32_t)g * (kSweepThreads * kRun) + (uint32_t)tid * kRun;  // < 4096
+    const uint32_t n0 = chunk_base + off;
+    uint32_t n[kRun];
+    Proj p[kRun];
+    int pix[kRun];
+    bool in_view[kRun], valid[kRun], tv[kRun];
+    float depth[kRun], sdf[kRun];
+    float xw[kRun], yw[kRun], zw[kRun];
+    // phase A: voxel centre -> image (clipfusion.py:647-659)
 #pragma unroll
-    for (int j = 0; j < kSweepIlp; ++j) {
-      n[j] = chunk_base + (uint32_t)(k0 + j) * kSweepThreads + tid;
-      const uint32_t nc = n[j] < v.N ? n[j] : v.N - 1;
-      int ix, iy, iz;
-      voxel_coords(v, nc, ix, iy, iz);
-      xw[j] = v.ax[ix];
-      yw[j] = v.ay[iy];
-      zw[j] = v.az[iz];
+    for (int j = 0; j < kRun; ++j) {
+      n[j] = n0 + j;
+      const uint32_t tz = (uint32_t)bz + off + j;  // < 4096 + nz
+      const uint32_t qz = sdiv(tz, dz);
+      const uint32_t ty = (uint32_t)by + qz;
+      const uint32_t qy = sdiv(ty, dy);
+      const int iz = (int)(tz - qz * (uint32_t)v.nz), iy = (int)(ty - qy * (uint32_t)v.ny);
+      const int ix = min(bx + (int)qy, v.nx - 1);  // clamped only for the (unused) lanes past N
+      xw[j] = ax[ix];
+      yw[j] = ay[iy];
+      zw[j] = az[iz];
     }
 #pragma unroll
-    for (int j = 0; j < kSweepIlp; ++j) {
+    for (int j = 0; j < kRun; ++j) {
       p[j] = project(cam, xw[j], yw[j], zw[j]);
       // _valid = (grid.abs() <= 1).all(dim=1) & (z > 0)            clipfusion.py:673
       in_view[j] = (n[j] < v.N) && (fabsf(p[j].gx) <= 1.0f) && (fabsf(p[j].gy) <= 1.0f) && (p[j].z > 0.0f);
       pix[j] = in_view[j] ? nearest_index(p[j].gx, p[j].gy, cam, f.W) : -1;
     }
-    // phase 2: nearest-pixel depth (zeros padding), all gathers in flight together
+    // phase B: nearest-pixel depth (zeros padding), all gathers in flight together
 #pragma unroll
-    for (int j = 0; j < kSweepIlp; ++j) depth[j] = pix[j] >= 0 ? f.depth[pix[j]] : 0.0f;
-    // phase 3: classify, issue the TSDF loads
+    for (int j = 0; j < kRun; ++j) depth[j] = pix[j] >= 0 ? f.depth[pix[j]] : 0.0f;
+    // phase C: classify (clipfusion.py:669-679)
+    bool any_tv = false;
 #pragma unroll
-    for (int j = 0; j < kSweepIlp; ++j) {
-      sdf[j] = (depth[j] - p[j].z) / v.trunc;        // clipfusion.py:669
-      valid[j] = in_view[j] && fabsf(sdf[j]) <= 1.0f;  // :678
-      tv[j] = in_view[j] && sdf[j] > -1.0f;           // tsdf_valid, :679
-      if (tv[j]) {
-        w0[j] = v.tsdf_w[n[j]];
-        told[j] = v.tsdf[n[j]];
-      }
+    for (int j = 0; j < kRun; ++j) {
+      sdf[j] = (depth[j] - p[j].z) / v.trunc;
+      valid[j] = in_view[j] && fabsf(sdf[j]) <= 1.0f;
+      tv[j] = in_view[j] && sdf[j] > -1.0f;
+      any_tv |= tv[j];
     }
-    // phase 4: running mean of the clamped sdf, clipfusion.py:681-695 with B = 1
+    // phase D: TSDF running mean of the clamped sdf, clipfusion.py:681-695 with B = 1.  The run's
+    // four values travel as one 16-byte vector; untouched elements are written back unchanged
+    // (this thread is the only writer of its run).
+    if (any_tv) {
+      float told[kRun];
+      int w0[kRun];
+      const bool vec = aligned && (n0 + kRun <= v.N);
+      if (vec) {
+        const float4 t4 = *reinterpret_cast<const float4*>(v.tsdf + n0);
+        const int4 w4 = *reinterpret_cast<const int4*>(v.tsdf_w + n0);
+        told[0] = t4.x; told[1] = t4.y; told[2] = t4.z; told[3] = t4.w;
+        w0[0] = w4.x; w0[1] = w4.y; w0[2] = w4.z; w0[3] = w4.w;
+      } else {
 #pragma unroll
-    for (int j = 0; j < kSweepIlp; ++j) {
-      if (tv[j]) {
-        const float t = sdf[j] > 1.0f ? 1.0f : sdf[j];
-        const int w1 = w0[j] + 1;
-        float nt;
-        if (v.accum == SAF_SUM) {
-          nt = told[j] + t;
-        } else {
-          const float a = (float)w1;
-          const float b = (float)w0[j] / (float)w1;
-          nt = t / a + told[j] * b;
+        for (int j = 0; j < kRun; ++j) {
+          told[j] = tv[j] ? v.tsdf[n[j]] : 0.0f;
+          w0[j] = tv[j] ? v.tsdf_w[n[j]] : 0;
         }
-        v.tsdf[n[j]] = nt;
-        v.tsdf_w[n[j]] = w1;
-        ++nt_local;
+      }
+#pragma unroll
+      for (int j = 0; j < kRun; ++j) {
+        if (tv[j]) {
+          const float t = sdf[j] > 1.0f ? 1.0f : sdf[j];
+          const int w1 = w0[j] + 1;
+          if (v.accum == SAF_SUM) {
+            told[j] = told[j] + t;
+          } else {
+            // batch_tsdf / new_weight + tsdf * (tsdf_weight / new_weight)
+            const float a = (float)w1;
+            const float b = (float)w0[j] / (float)w1;
+            told[j] = t / a + told[j] * b;
+          }
+          w0[j] = w1;
+          ++nt_local;
+        }
+      }
+      if (vec) {
+        *reinterpret_cast<float4*>(v.tsdf + n0) = make_float4(told[0], told[1], told[2], told[3]);
+        *reinterpret_cast<int4*>(v.tsdf_w + n0) = make_int4(w0[0], w0[1], w0[2], w0[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+          if (tv[j]) {
+            v.tsdf[n[j]] = told[j];
+            v.tsdf_w[n[j]] = w0[j];
+          }
+        }
       }
     }
-    // phase 5: wave64 ballot + prefix popcount -> slots in the block's LDS buffer
+    // phase E: compaction -- wave64 ballots + prefix popcounts, ONE LDS atomic per wave and run
+    unsigned long long m[kRun];
+    uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < kSweepIlp; ++j) {
-      const unsigned long long m = __ballot(valid[j]);
-      if (m) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s_count, (uint32_t)__popcll(m));
-        base = __shfl(base, 0);
-        if (valid[j]) s_buf[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = n[j];
+    for (int j = 0; j < kRun; ++j) {
+      m[j] = __ballot(valid[j]);
+      cnt += (uint32_t)__popcll(m[j]);
+    }
+    if (cnt) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&s_count, cnt);
+      base = __shfl(base, 0);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int j = 0; j < kRun; ++j) {
+        if (valid[j]) s_buf[base + (uint32_t)__popcll(m[j] & lt)] = n[j];
+        base += (uint32_t)__popcll(m[j]);
       }
     }
   }
@@ -262,19 +364,17 @@ __device__ __forceinline__ float4 vzero(float4) { return make_float4(0.f, 0.f, 0
 __device__ __forceinline__ float vzero(float) { return 0.f; }
 
 struct Taps {
-  int o_nw, o_ne, o_sw, o_se;  // offsets (in vector units) of the four taps in the [P+1][DV] map
+  int o_nw, o_ne, o_sw, o_se;  // tap positions in [0, P]; P = the zero column (outside the map)
 };
-// Taps outside the map read row P, which holds zeros: grid_sample's padding_mode="zeros" with
-// unconditional loads (no branches in the row loop).
-__device__ __forceinline__ Taps tap_offsets(const Bilin& b, int npx, int npy, int DV) {
+__device__ __forceinline__ Taps tap_offsets(const Bilin& b, int npx, int npy) {
   const bool x0 = b.x0 >= 0 && b.x0 < npx, x1 = b.x0 + 1 >= 0 && b.x0 + 1 < npx;
   const bool y0 = b.y0 >= 0 && b.y0 < npy, y1 = b.y0 + 1 >= 0 && b.y0 + 1 < npy;
-  const int zero_row = npx * npy;
+  const int zero = npx * npy;
   Taps t;
-  t.o_nw = ((x0 && y0) ? b.y0 * npx + b.x0 : zero_row) * DV;
-  t.o_ne = ((x1 && y0) ? b.y0 * npx + b.x0 + 1 : zero_row) * DV;
-  t.o_sw = ((x0 && y1) ? (b.y0 + 1) * npx + b.x0 : zero_row) * DV;
-  t.o_se = ((x1 && y1) ? (b.y0 + 1) * npx + b.x0 + 1 : zero_row) * DV;
+  t.o_nw = (x0 && y0) ? b.y0 * npx + b.x0 : zero;
+  t.o_ne = (x1 && y0) ? b.y0 * npx + b.x0 + 1 : zero;
+  t.o_sw = (x0 && y1) ? (b.y0 + 1) * npx + b.x0 : zero;
+  t.o_se = (x1 && y1) ? (b.y0 + 1) * npx + b.x0 + 1 : zero;
   return t;
 }
 
@@ -409,20 +509,19 @@ template <int VEC, int CPL, int U, bool LDS_MAP>
 __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(KVol v, KFrame f,
                                                              const unsigned long long* __restrict__ counts,
                                                              const uint32_t* __restrict__ lists, uint32_t list_cap,
-                                                             const float* __restrict__ map_t, int g_log2,
+                                                             const float* __restrict__ feat_map, const float* __restrict__ map_t, int g_log2,
                                                              unsigned long long* __restrict__ stats) {
   using V = typename VecT<VEC>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int tid = threadIdx.x;
   const int DV = v.D / VEC;  // vector chunks per row
   const int P = f.npy * f.npx;
+  const int ppad = map_ppad(P);
   const V* map;
   if (LDS_MAP) {
-    V* s_map = reinterpret_cast<V*>(s_raw);
-    const V* src = reinterpret_cast<const V*>(map_t);
-    for (int i = tid; i < (P + 1) * DV; i += kFuseThreads) s_map[i] = src[i];
+    fill_map_image(reinterpret_cast<float*>(s_raw), feat_map, v.D, P, VEC, tid, kFuseThreads);
     __syncthreads();
-    map = s_map;
+    map = reinterpret_cast<const V*>(s_raw);
   } else {
     map = reinterpret_cast<const V*>(map_t);
   }
@@ -483,7 +582,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(KVol v, KFrame f,
         gx[j] = p.gx;
         gy[j] = p.gy;
         bf[j] = bilinear_setup(p.gx, p.gy, half_px, half_py);
-        tp[j] = tap_offsets(bf[j], f.npx, f.npy, DV);
+        tp[j] = tap_offsets(bf[j], f.npx, f.npy);
       }
     }
     // phase 4: blend + store
@@ -499,13 +598,15 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(KVol v, KFrame f,
           for (int c = 0; c < C; ++c) {
             const int ch = gl + c * G;
             if (ch < DV) {
-              const V s = lerp_taps(map[t.o_nw + ch], map[t.o_ne + ch], map[t.o_sw + ch], map[t.o_se + ch], bf[j]);
+              const int mb = ch * ppad;
+              const V s = lerp_taps(map[mb + t.o_nw], map[mb + t.o_ne], map[mb + t.o_sw], map[mb + t.o_se], bf[j]);
               feat[(int64_t)n[j] * DV + ch] = blend(s, old[j][c], a[j], b[j], sum);
             }
           }
         } else {
           for (int ch = gl; ch < DV; ch += G) {
-            const V s = lerp_taps(map[t.o_nw + ch], map[t.o_ne + ch], map[t.o_sw + ch], map[t.o_se + ch], bf[j]);
+            const int mb = ch * ppad;
+            const V s = lerp_taps(map[mb + t.o_nw], map[mb + t.o_ne], map[mb + t.o_sw], map[mb + t.o_se], bf[j]);
             V* dst = feat + (int64_t)n[j] * DV + ch;
             *dst = blend(s, *dst, a[j], b[j], sum);
           }
@@ -546,7 +647,7 @@ struct RowCtx {
 
 template <bool G64>
 __device__ __forceinline__ RowCtx fetch_row(int src, uint32_t n_l, float a_l, float b_l, int xy_l, float wx_l,
-                                            float wy_l, int npx, int npy, int DV) {
+                                            float wy_l, int npx, int npy) {
   RowCtx c;
   c.n = (uint32_t)bcast_i<G64>((int)n_l, src);
   c.a = bcast_f<G64>(a_l, src);
@@ -561,7 +662,7 @@ __device__ __forceinline__ RowCtx fetch_row(int src, uint32_t n_l, float a_l, fl
   c.w.ne = sy * wx;
   c.w.sw = wy * ex;
   c.w.se = wy * wx;
-  c.t = tap_offsets(c.w, npx, npy, DV);
+  c.t = tap_offsets(c.w, npx, npy);
   return c;
 }
 
@@ -569,38 +670,41 @@ __device__ __forceinline__ RowCtx fetch_row(int src, uint32_t n_l, float a_l, fl
 // counted waits: lanes whose chunk index would fall past the row re-do the last chunk (identical
 // value to the same address), and lane groups past the end of a batch re-do the batch's last
 // row inside the SAME wave instruction as its owner (same loads, same stores).
-template <int CPL, int R, bool G64, bool LDS_MAP>
+template <int CPL, int R, bool G64, bool LDS_MAP, bool SUM>
 __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame f,
                                                                   const unsigned long long* __restrict__ counts,
                                                                   const uint32_t* __restrict__ lists,
-                                                                  uint32_t list_cap, const float* __restrict__ map_t,
-                                                                  int g_log2, unsigned long long* __restrict__ stats) {
+                                                                  uint32_t list_cap, const float* __restrict__ feat_map,
+                                                                  const float* __restrict__ map_t, int g_log2,
+                                                                  unsigned long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int tid = threadIdx.x;
   const int DV = v.D >> 2;
   const int P = f.npy * f.npx;
+  const int ppad = map_ppad(P);
   const float4* map;
   if (LDS_MAP) {
-    float4* s_map = reinterpret_cast<float4*>(s_raw);
-    const float4* src = reinterpret_cast<const float4*>(map_t);
-    for (int i = tid; i < (P + 1) * DV; i += kFuseThreads) s_map[i] = src[i];
+    fill_map_image(reinterpret_cast<float*>(s_raw), feat_map, v.D, P, 4, tid, kFuseThreads);
     __syncthreads();
-    map = s_map;
+    map = reinterpret_cast<const float4*>(s_raw);
   } else {
     map = reinterpret_cast<const float4*>(map_t);
   }
   const Cam cam = load_cam(f.pose, f.K, f.W, f.H);
   const float half_px = (float)f.npx / 2.0f, half_py = (float)f.npy / 2.0f;
-  const bool sum = v.accum == SAF_SUM;
+  constexpr bool sum = SUM;
   add_frame_stats(counts, stats);
 
   const int G = G64 ? 64 : (1 << g_log2);
   const int lane = tid & 63, wave = tid >> 6;
   const int slot = G64 ? 0 : (lane >> g_log2), gl = lane & (G - 1);
   const int epw = G64 ? 1 : (64 >> g_log2);  // rows per wave step
-  int chs[CPL];
+  int chs[CPL], mbs[CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) chs[c] = min(gl + c * G, DV - 1);
+  for (int c = 0; c < CPL; ++c) {
+    chs[c] = min(gl + c * G, DV - 1);
+    mbs[c] = chs[c] * ppad;
+  }
   const uint32_t list = blockIdx.x % kNumLists;
   const uint32_t count = (uint32_t)counts[list];
   const uint32_t* lst = lists + (size_t)list * list_cap;
@@ -639,13 +743,13 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
     // ---------------- row loop: groups of G lanes, R rows in flight per group ----------------
     const int steps = (nb + epw - 1) / epw;
     const int last = nb - 1;
-#define SAF_FETCH(i) fetch_row<G64>(min((i) * epw + slot, last), n_l, a_l, b_l, xy_l, wx_l, wy_l, f.npx, f.npy, DV)
+#define SAF_FETCH(i) fetch_row<G64>(min((i) * epw + slot, last), n_l, a_l, b_l, xy_l, wx_l, wy_l, f.npx, f.npy)
 #define SAF_LOAD(ctx_, old_)                                                           \
   _Pragma("unroll") for (int c = 0; c < CPL; ++c) old_[c] = ld_stream(&feat[(int64_t)(ctx_).n * DV + chs[c]]);
 #define SAF_STORE(ctx_, old_)                                                                                      \
   _Pragma("unroll") for (int c = 0; c < CPL; ++c) {                                                                \
-    const float4 sv = lerp_taps(map[(ctx_).t.o_nw + chs[c]], map[(ctx_).t.o_ne + chs[c]],                          \
-                                map[(ctx_).t.o_sw + chs[c]], map[(ctx_).t.o_se + chs[c]], (ctx_).w);               \
+    const float4 sv = lerp_taps(map[mbs[c] + (ctx_).t.o_nw], map[mbs[c] + (ctx_).t.o_ne],                          \
+                                map[mbs[c] + (ctx_).t.o_sw], map[mbs[c] + (ctx_).t.o_se], (ctx_).w);               \
     st_stream(&feat[(int64_t)(ctx_).n * DV + chs[c]], blend(sv, old_[c], (ctx_).a, (ctx_).b, sum));               \
   }
     int i0 = 0;
@@ -685,22 +789,27 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
   }
 }
 
-using FuseFn = void (*)(KVol, KFrame, const unsigned long long*, const uint32_t*, uint32_t, const float*, int,
-                        unsigned long long*);
+using FuseFn = void (*)(KVol, KFrame, const unsigned long long*, const uint32_t*, uint32_t, const float*,
+                        const float*, int, unsigned long long*);
 
 template <int VEC, int CPL, int U>
 FuseFn pick_lds(bool lds) {
   return lds ? fuse_kernel<VEC, CPL, U, true> : fuse_kernel<VEC, CPL, U, false>;
 }
 
+template <int CPL, int R, bool SUM>
+FuseFn pick_rows2(bool g64, bool lds) {
+  if (g64) return lds ? fuse_rows_kernel<CPL, R, true, true, SUM> : fuse_rows_kernel<CPL, R, true, false, SUM>;
+  return lds ? fuse_rows_kernel<CPL, R, false, true, SUM> : fuse_rows_kernel<CPL, R, false, false, SUM>;
+}
 template <int CPL, int R>
-FuseFn pick_rows(bool g64, bool lds) {
-  if (g64) return lds ? fuse_rows_kernel<CPL, R, true, true> : fuse_rows_kernel<CPL, R, true, false>;
-  return lds ? fuse_rows_kernel<CPL, R, false, true> : fuse_rows_kernel<CPL, R, false, false>;
+FuseFn pick_rows(bool g64, bool lds, bool sum) {
+  return sum ? pick_rows2<CPL, R, true>(g64, lds) : pick_rows2<CPL, R, false>(g64, lds);
 }
 
-int launch_fuse(const KVol& kv, const KFrame& kf, const WsLayout& w, unsigned char* ws, unsigned long long* stats,
-                hipStream_t s) {
+int launch_fuse(const KVol& kv, const KFrame& kf, const WsLayout& w, const float* feat_map,
+                const unsigned long long* counts, const unsigned char* half, unsigned long long* stats,
+                bool shared_cus, hipStream_t s) {
   const int D = kv.D, P = kf.npy * kf.npx;
   const int VEC = (D % 4 == 0) ? 4 : 1;
   const int DV = D / VEC;
@@ -708,39 +817,44 @@ int launch_fuse(const KVol& kv, const KFrame& kf, const WsLayout& w, unsigned ch
   while ((1 << g_log2) < DV && g_log2 < 6) ++g_log2;
   const int G = 1 << g_log2;
   const int cpl = (DV + G - 1) / G;
-  const size_t map_bytes = (size_t)D * (P + 1) * sizeof(float);
-  const bool lds = map_bytes <= 144 * 1024;
+  const bool lds = w.lds_map;
+  const bool sum = kv.accum == SAF_SUM;
   FuseFn fn;
   if (VEC == 4 && cpl >= 1 && cpl <= 4) {
     const bool g64 = G == 64;
     switch (cpl) {
-      case 1: fn = pick_rows<1, 4>(g64, lds); break;
-      case 2: fn = pick_rows<2, 4>(g64, lds); break;
-      case 3: fn = pick_rows<3, 2>(g64, lds); break;
-      default: fn = pick_rows<4, 2>(g64, lds); break;
+      case 1: fn = pick_rows<1, 4>(g64, lds, sum); break;
+      case 2: fn = pick_rows<2, 4>(g64, lds, sum); break;
+      case 3: fn = pick_rows<3, 2>(g64, lds, sum); break;
+      default: fn = pick_rows<4, 2>(g64, lds, sum); break;
     }
   } else if (VEC == 4) {
     fn = pick_lds<4, 0, 1>(lds);
   } else {
     fn = (cpl == 1) ? pick_lds<1, 1, 4>(lds) : pick_lds<1, 0, 1>(lds);
   }
-  const size_t shmem = lds ? map_bytes : 0;
+  const size_t shmem = lds ? lds_map_bytes(D, P) : 0;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", shmem, hipGetErrorString(e));
   }
-  // workgroups resident per CU: limited by the LDS image (160 KiB / CU) and 2048 threads / CU
-  int per_cu = shmem ? (int)((160 * 1024) / (shmem + 64)) : 4;
-  if (per_cu > 4) per_cu = 4;
-  if (per_cu < 1) per_cu = 1;
-  int grid = device_cus() * per_cu;
+  // 512-thread workgroups (8 waves at <= 128 VGPRs = half of each SIMD's register file, one LDS
+  // image of the map).  Alone on the chip two of them share a CU; in the saf_fuse_frames pipeline
+  // ONE per CU is launched so that the other half of the registers, ~80 KB of LDS and 16 wave slots
+  // stay free for four sweep blocks of the next frame: both kernels are then resident on every CU
+  // and neither can starve the other at dispatch.
+  static const int grid_env = getenv("SAF_FUSE_GRID") ? atoi(getenv("SAF_FUSE_GRID")) : 0;
+  int per_cu = shmem ? (int)((160 * 1024) / (shmem + 1024)) : 2;
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1 || shared_cus) per_cu = 1;
+  // pipeline mode: 13/16 of the CUs (208 on MI355X) measured best; the plateau 192..256 is flat
+  int grid = grid_env > 0 ? grid_env : (shared_cus ? (device_cus() * 13) / 16 : device_cus() * per_cu);
   grid = ((grid + kNumLists - 1) / kNumLists) * kNumLists;
-  const unsigned long long* counts = reinterpret_cast<const unsigned long long*>(ws + w.counts_off);
-  const uint32_t* lists = reinterpret_cast<const uint32_t*>(ws + w.lists_off);
-  const float* map_t = reinterpret_cast<const float*>(ws + w.map_off);
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kFuseThreads), shmem, s, kv, kf, counts, lists, w.list_cap, map_t, g_log2,
-                     stats);
+  const uint32_t* lists = reinterpret_cast<const uint32_t*>(half + w.lists_off);
+  const float* map_t = reinterpret_cast<const float*>(half + w.map_off);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kFuseThreads), shmem, s, kv, kf, counts, lists, w.list_cap, feat_map, map_t,
+                     g_log2, stats);
   return check_launch("fuse_kernel");
 }
 
@@ -821,36 +935,115 @@ struct ScopedPair {
   }
 };
 
-int fuse_one(const KVol& kv, const saf_frame* frame, void* workspace, size_t workspace_bytes, uint64_t* stats,
-             saf_profiler* prof, hipStream_t s) {
+struct FrameJob {
   KFrame kf;
-  int rc = make_kframe(frame, &kf);
-  if (rc) return rc;
-  const int P = kf.npy * kf.npx;
-  const WsLayout w = ws_layout(kv.N, kv.D, P);
-  if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
-  if (workspace_bytes < w.total)
-    return fail(SAF_E_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, w.total);
-  unsigned char* ws = static_cast<unsigned char*>(workspace);
-  unsigned long long* counts = reinterpret_cast<unsigned long long*>(ws + w.counts_off);
-  uint32_t* lists = reinterpret_cast<uint32_t*>(ws + w.lists_off);
-  float* map_t = reinterpret_cast<float*>(ws + w.map_off);
-  unsigned long long* st = reinterpret_cast<unsigned long long*>(stats);
+  WsLayout w;
+  const float* feat_map;
+};
 
-  const int prep_items = kv.D * (P + 1) > kNumLists ? kv.D * (P + 1) : kNumLists;
-  {
+int make_job(const KVol& kv, const saf_frame* frame, void* workspace, size_t workspace_bytes, FrameJob* job) {
+  int rc = make_kframe(frame, &job->kf);
+  if (rc) return rc;
+  job->feat_map = frame->feat_map;
+  job->w = ws_layout(kv.N, kv.D, job->kf.npy * job->kf.npx);
+  if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
+  if (workspace_bytes < job->w.total)
+    return fail(SAF_E_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, job->w.total);
+  return SAF_OK;
+}
+
+inline unsigned long long* counter_set(unsigned char* ws, int64_t frame_no) {
+  return reinterpret_cast<unsigned long long*>(ws) + (size_t)(frame_no & (kCounterSets - 1)) * kNumLists;
+}
+
+// sweep (and, for maps too large for LDS, the map re-layout) of frame `frame_no` into workspace half `half`
+int launch_classify(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned char* half, int64_t frame_no,
+                    saf_profiler* prof, hipStream_t s) {
+  const WsLayout& w = job.w;
+  uint32_t* lists = reinterpret_cast<uint32_t*>(half + w.lists_off);
+  int rc;
+  if (!w.lds_map) {
+    const int P = job.kf.npy * job.kf.npx;
+    const int items = kv.D * map_ppad(P);
     ScopedPair t(prof, 0, s);
-    hipLaunchKernelGGL(prep_kernel, dim3((prep_items + 255) / 256), dim3(256), 0, s, frame->feat_map, map_t, kv.D, P,
-                       counts);
+    hipLaunchKernelGGL(prep_kernel, dim3((items + 255) / 256), dim3(256), 0, s, job.feat_map,
+                       reinterpret_cast<float*>(half + w.map_off), kv.D, P, (kv.D % 4 == 0) ? 4 : 1);
+    if ((rc = check_launch("prep_kernel"))) return rc;
   }
-  if ((rc = check_launch("prep_kernel"))) return rc;
-  {
-    ScopedPair t(prof, 1, s);
-    hipLaunchKernelGGL(sweep_kernel, dim3(w.n_blocks), dim3(kSweepThreads), 0, s, kv, kf, counts, lists, w.list_cap);
-  }
-  if ((rc = check_launch("sweep_kernel"))) return rc;
+  ScopedPair t(prof, 1, s);
+  hipLaunchKernelGGL(sweep_kernel, dim3(w.n_blocks), dim3(kSweepThreads), 0, s, kv, job.kf, counter_set(ws, frame_no),
+                     counter_set(ws, frame_no + 1), lists, w.list_cap);
+  return check_launch("sweep_kernel");
+}
+
+int launch_rows(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned char* half, int64_t frame_no,
+                uint64_t* stats, bool shared_cus, saf_profiler* prof, hipStream_t s) {
   ScopedPair t(prof, 2, s);
-  return launch_fuse(kv, kf, w, ws, st, s);
+  return launch_fuse(kv, job.kf, job.w, job.feat_map, counter_set(ws, frame_no), half,
+                     reinterpret_cast<unsigned long long*>(stats), shared_cus, s);
+}
+
+#define SAF_HIP_TRY(call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) { rc = fail(SAF_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); goto done; } \
+  } while (0)
+
+// Frames in order.  A single frame runs prep -> sweep -> fuse on the caller's stream.  For two or
+// more frames the classification of frame i+1 (prep + sweep: VALU-bound, touches only the TSDF
+// buffers and its own workspace half) runs on an auxiliary stream while the caller's stream runs
+// the HBM-bound row fuse of frame i; events order sweep(i) -> fuse(i) and fuse(i) -> the reuse of
+// its workspace half by frame i+2.  All work is ordered after what the caller already queued on
+// `s` (fork event) and is complete, as far as `s` is concerned, when the last fuse kernel is.
+int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
+              uint64_t* stats, saf_profiler* prof, hipStream_t s) {
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  int rc = SAF_OK;
+  // all four counter sets start at zero; afterwards every sweep zeroes its successor's set
+  if (hipMemsetAsync(ws, 0, kHdrBytes, s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
+  // SAF_PIPELINE=0 keeps everything on the caller's stream (debugging / per-kernel timing)
+  static const bool pipeline = !(getenv("SAF_PIPELINE") && getenv("SAF_PIPELINE")[0] == '0');
+  if (n_frames == 1 || !pipeline) {
+    for (int32_t i = 0; i < n_frames; ++i) {
+      FrameJob job;
+      if ((rc = make_job(kv, &frames[i], workspace, workspace_bytes, &job))) return rc;
+      unsigned char* half = ws + kHdrBytes;
+      if ((rc = launch_classify(kv, job, ws, half, i, prof, s))) return rc;
+      if ((rc = launch_rows(kv, job, ws, half, i, stats, false, prof, s))) return rc;
+    }
+    return SAF_OK;
+  }
+  hipStream_t aux = nullptr;
+  hipEvent_t fork = nullptr, swept[2] = {nullptr, nullptr}, fused[2] = {nullptr, nullptr};
+  SAF_HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+  SAF_HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+  for (int b = 0; b < 2; ++b) {
+    SAF_HIP_TRY(hipEventCreateWithFlags(&swept[b], hipEventDisableTiming));
+    SAF_HIP_TRY(hipEventCreateWithFlags(&fused[b], hipEventDisableTiming));
+  }
+  SAF_HIP_TRY(hipEventRecord(fork, s));
+  SAF_HIP_TRY(hipStreamWaitEvent(aux, fork, 0));
+  for (int32_t i = 0; i < n_frames; ++i) {
+    const int b = i & 1;
+    FrameJob job;
+    if ((rc = make_job(kv, &frames[i], workspace, workspace_bytes, &job))) goto done;
+    unsigned char* half = ws + kHdrBytes + (size_t)b * job.w.half;
+    if (i >= 2) SAF_HIP_TRY(hipStreamWaitEvent(aux, fused[b], 0));  // half b is free again
+    if ((rc = launch_classify(kv, job, ws, half, i, prof, aux))) goto done;
+    SAF_HIP_TRY(hipEventRecord(swept[b], aux));
+    SAF_HIP_TRY(hipStreamWaitEvent(s, swept[b], 0));
+    if ((rc = launch_rows(kv, job, ws, half, i, stats, true, prof, s))) goto done;
+    SAF_HIP_TRY(hipEventRecord(fused[b], s));
+  }
+done:
+  // destroying a stream / event with work in flight is deferred by the runtime until it drains
+  if (fork) (void)hipEventDestroy(fork);
+  for (int b = 0; b < 2; ++b) {
+    if (swept[b]) (void)hipEventDestroy(swept[b]);
+    if (fused[b]) (void)hipEventDestroy(fused[b]);
+  }
+  if (aux) (void)hipStreamDestroy(aux);
+  return rc;
 }
 
 }  // namespace
@@ -868,30 +1061,25 @@ size_t saf_fuse_workspace_bytes(int64_t n_vox, int32_t feat_dim, int32_t npy, in
   return ws_layout(n_vox, feat_dim, npy * npx).total;
 }
 
-int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspace, size_t workspace_bytes,
-                   uint64_t* stats, void* stream) {
-  KVol kv;
-  int rc = make_kvol(vol, &kv);
-  if (rc) return rc;
-  return fuse_one(kv, frame, workspace, workspace_bytes, stats, nullptr, static_cast<hipStream_t>(stream));
-}
-
 int saf_fuse_frames_profiled(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,
                              size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream) {
   KVol kv;
   int rc = make_kvol(vol, &kv);
   if (rc) return rc;
   if (n_frames < 0 || (n_frames > 0 && !frames)) return fail(SAF_E_INVALID, "bad frame array");
-  for (int32_t i = 0; i < n_frames; ++i) {
-    rc = fuse_one(kv, &frames[i], workspace, workspace_bytes, stats, profiler, static_cast<hipStream_t>(stream));
-    if (rc) return rc;
-  }
-  return SAF_OK;
+  if (n_frames == 0) return SAF_OK;
+  return fuse_many(kv, frames, n_frames, workspace, workspace_bytes, stats, profiler, static_cast<hipStream_t>(stream));
 }
 
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,
                     size_t workspace_bytes, uint64_t* stats, void* stream) {
   return saf_fuse_frames_profiled(vol, frames, n_frames, workspace, workspace_bytes, stats, nullptr, stream);
+}
+
+int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspace, size_t workspace_bytes,
+                   uint64_t* stats, void* stream) {
+  if (!frame) return fail(SAF_E_INVALID, "frame is NULL");
+  return saf_fuse_frames_profiled(vol, frame, 1, workspace, workspace_bytes, stats, nullptr, stream);
 }
 
 saf_profiler* saf_profiler_create(int32_t capacity_pairs) {

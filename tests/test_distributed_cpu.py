@@ -1,0 +1,116 @@
+"""CPU, world_size 2, gloo: the frame-sharded job of SURVEY.md §8e.
+
+Each rank fuses its contiguous block of frames into a private SUM-mode volume (with the CPU
+oracle standing in for the HIP kernels -- this test covers the sharding + merge logic of
+spatially_aware_ai_amd.distributed, which is device-agnostic), the ranks merge with one
+collective, and the result must equal the single-process running-mean volume over all frames:
+index sets / integer tensors exactly, fp32 within 1e-4 relative."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from spatially_aware_ai_amd import _abi
+from spatially_aware_ai_amd import distributed as sdist
+from spatially_aware_ai_amd import synthetic as syn
+
+NVOX = (9, 7, 5)  # 315 voxels: not divisible by the world size -> exercises the remainder path
+DIM, W, H = 8, 40, 30
+N_FRAMES = 7
+
+
+def _frames():
+    npy, npx = syn.feature_map_shape(W, H)
+    return syn.make_frames(321, N_FRAMES, width=W, height=H, feat_dim=DIM, npy=npy, npx=npx, depth_kind="A"), (npy, npx)
+
+
+def _fuse(vol, frames, seem):
+    for f in frames:
+        vol.integrate(f["depth"], f["rgb"], f["pose"], f["K"], f["feat"],
+                      [f["labels"].float()] if seem else None, rgb_bilinear=seem)
+
+
+def _tensors(vol):
+    t = {"clip_feat": vol.clip_feat, "rgb": vol.rgb, "tsdf": vol.tsdf, "weight": vol.weight,
+         "tsdf_weight": vol.tsdf_weight}
+    if vol.labels_one_hot is not None:
+        t["labels_one_hot"] = vol.labels_one_hot
+    return t
+
+
+def _worker(rank, world, port, mode, gather, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+
+        grid = syn.make_grid(NVOX, side=1.2)
+        frames, _ = _frames()
+        mine = sdist.shard_frames(len(frames), rank, world)
+        vol = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM, 143, _abi.SAF_SUM)
+        _fuse(vol, [frames[i] for i in mine], seem=True)
+        first, count = sdist.merge_sums(_tensors(vol), mode=mode, gather=gather)
+        # local divide over the range this rank owns (the HIP path calls saf_merge_finalize here)
+        c = vol.c_volume()
+        import ctypes as C
+
+        assert O.lib().saf_oracle_merge_finalize(C.byref(c), first, count) == 0
+        if gather and mode == "reduce_scatter":
+            pass  # gathered tensors are sums; finalize the rest too for comparison
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), first=first, count=count,
+                 **{k: v.numpy() for k, v in _tensors(vol).items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_frames_partitions():
+    for n, w in ((7, 2), (512, 8), (5, 8), (4096, 8)):
+        blocks = [sdist.shard_frames(n, r, w) for r in range(w)]
+        assert sum(len(b) for b in blocks) == n
+        flat = [i for b in blocks for i in b]
+        assert flat == list(range(n))
+    assert len(sdist.shard_frames(4096, 3, 8)) == 512
+    assert sdist.voxel_shard(315, 0, 2) == (0, 157) and sdist.voxel_shard(315, 1, 2) == (157, 158)
+
+
+@pytest.mark.parametrize("mode", ["reduce_scatter", "all_reduce"])
+def test_two_rank_merge_equals_single_process(tmp_path, oracle, mode):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), mode, False, str(tmp_path)), nprocs=world, join=True)
+    grid = syn.make_grid(NVOX, side=1.2)
+    frames, _ = _frames()
+    ref = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM, 143)
+    _fuse(ref, frames, seem=True)
+    n = ref.n
+    covered = np.zeros(n, dtype=np.int32)
+    for r in range(world):
+        g = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        first, count = int(g["first"]), int(g["count"])
+        if mode == "all_reduce":
+            assert (first, count) == (0, n)
+        else:
+            assert (first, count) == sdist.voxel_shard(n, r, world)
+        sl = slice(first, first + count)
+        covered[sl] += 1
+        assert np.array_equal(g["weight"][sl], ref.weight.numpy()[sl]), "merged valid counts differ"
+        assert np.array_equal(g["tsdf_weight"][sl], ref.tsdf_weight.numpy()[sl])
+        assert np.array_equal(g["labels_one_hot"][sl], ref.labels_one_hot.numpy()[sl])
+        np.testing.assert_allclose(g["clip_feat"][sl], ref.clip_feat.numpy()[sl], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(g["rgb"][sl], ref.rgb.numpy()[sl], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(g["tsdf"][sl], ref.tsdf.numpy()[sl], rtol=1e-4, atol=2e-6)
+    expect = world if mode == "all_reduce" else 1
+    assert (covered == expect).all(), "every voxel must be finalised by exactly the ranks that own it"
+    assert int(ref.weight.sum()) > 0

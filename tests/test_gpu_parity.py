@@ -206,6 +206,45 @@ def test_empty_frame_touches_nothing(oracle):
     assert fusion.stats()["valid"] == 0 and int(fusion.weight.sum()) == 0
 
 
+def test_weird_depth_and_large_weights(oracle):
+    """Edge cases of the culling / fast-division paths: NaN, +inf, negative and huge depths, and
+    running-mean weights beyond the reciprocal table (>= 4096 prior observations)."""
+    from spatially_aware_ai_amd import ClipFusion
+
+    grid = syn.make_grid((20, 18, 16))
+    frames = syn.make_frames(9, 4, width=40, height=30, feat_dim=16, npy=2, npx=3, depth_kind="A")
+    d = frames[0]["depth"]
+    d[0, 3:6, :] = float("nan")
+    d[0, 10:12, :] = float("inf")
+    d[0, 20:22, :] = -1.0
+    frames[1]["depth"][0, ::3, ::2] = 1.0e30
+    frames[2]["depth"][:] = 0.0  # nothing but the missing-depth quirk (0 < z <= trunc)
+    frames[3]["depth"][0, 5, 7] = float("inf")
+    vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, 16)
+    clip = FakeClip(16)
+    fusion = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, 10, 10).cuda()
+    # pretend 5000 / 4094 earlier observations so both sides of the table boundary are crossed
+    g = torch.Generator().manual_seed(0)
+    prior = torch.randn(vol.n, 16, generator=g)
+    for w_init in (5000, 4094):
+        vol.weight.fill_(w_init); vol.tsdf_weight.fill_(w_init)
+        vol.clip_feat.copy_(prior); vol.tsdf.fill_(0.25); vol.rgb.fill_(0.5)
+        fusion.weight.fill_(w_init); fusion.tsdf_weight.fill_(w_init)
+        fusion.clip_feat.copy_(prior.cuda()); fusion.tsdf.fill_(0.25); fusion.rgb.fill_(0.5)
+        vol.stats[:] = 0
+        fusion.fuse_stats.zero_()
+        for f in frames:
+            vol.integrate(f["depth"], f["rgb"], f["pose"], f["K"], f["feat"])
+            fusion.integrate_features(*(f[k].cuda() for k in ("depth", "rgb", "pose", "K", "feat")))
+        assert torch.equal(fusion.weight.cpu(), vol.weight)
+        assert torch.equal(fusion.tsdf_weight.cpu(), vol.tsdf_weight)
+        assert torch.equal(torch.isnan(fusion.tsdf.cpu()), torch.isnan(vol.tsdf))
+        _close(torch.nan_to_num(fusion.tsdf.cpu()), torch.nan_to_num(vol.tsdf), "tsdf")
+        _close(fusion.clip_feat, vol.clip_feat, "clip_feat")
+        _close(fusion.rgb, vol.rgb, "rgb")
+        assert int(vol.stats[0]) > 0 and fusion.stats()["valid"] == int(vol.stats[0])
+
+
 def test_sum_mode_and_finalize(oracle):
     """SAF_SUM accumulation + saf_merge_finalize == running mean, and mean_to_sum
     is its inverse."""
