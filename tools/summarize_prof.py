@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/<tag>/: the rocprofv3 kernel
+stats table, the bench line produced under the profiler, and the per-launch HBM traffic of the
+fuse / sweep kernels from the PMC passes (FETCH_SIZE doubled: on gfx950 it reports half the bytes
+of wide coalesced reads, guides/MI355X_MICROARCH.md §HBM; WRITE_SIZE is exact)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+dst = f"profiles/{tag}"
+os.makedirs(dst, exist_ok=True)
+ks = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+if ks:
+    shutil.copy(ks[0], f"{dst}/kernel_stats.csv")
+    for r in csv.DictReader(open(ks[0])):
+        if "saf::" in r["Name"]:
+            short = r["Name"].split("saf::(anonymous namespace)::")[-1].split("(")[0]
+            print(f"{short:40s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.2f} pct {r['Percentage']}")
+if os.path.exists(f"{src}/bench_under_rocprof.json"):
+    shutil.copy(f"{src}/bench_under_rocprof.json", f"{dst}/bench_under_rocprof.json")
+
+
+def name_of(k):
+    for n in ("fuse_rows_kernel", "fuse_kernel", "sweep_kernel", "prep_kernel", "query_kernel"):
+        if n in k:
+            return "fuse_kernel" if n.startswith("fuse") else n
+    return None
+
+
+out = {}
+for d, cn in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+    if not fs:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        k = name_of(r["Kernel_Name"])
+        if k and r["Counter_Name"] == cn:
+            agg[k].append(float(r["Counter_Value"]))
+    out[cn] = {k: {"launches": len(v), "mean_KiB": sum(v) / len(v)} for k, v in agg.items()}
+if out:
+    json.dump(out, open(f"{dst}/pmc_fetch_write.json", "w"), indent=1)
+    try:
+        cfg = json.load(open(f"{src}/pmc_fetch.json"))["config"]
+        f = out["FETCH_SIZE"]["fuse_kernel"]["mean_KiB"] * 1024 * 2
+        w = out["WRITE_SIZE"]["fuse_kernel"]["mean_KiB"] * 1024
+        t = {"grid": cfg["grid"], "dim": cfg["feat_dim"], "hbm_read_bytes_per_launch": int(f),
+             "hbm_write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w),
+             "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 24 launches each; "
+                       "FETCH_SIZE x2 (gfx950 correction), KiB -> bytes"}
+        json.dump(t, open(f"{dst}/fuse_traffic.json", "w"), indent=1)
+        print("fuse traffic per launch: read %.1f MB write %.1f MB" % (f / 1e6, w / 1e6))
+    except Exception as e:  # noqa: BLE001
+        print("no traffic summary:", e)
