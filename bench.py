@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--merge", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="record HIP events around the kernels of every n-th frame of the timed region")
     return ap.parse_args()
 
 
@@ -122,6 +124,7 @@ def main():
     prof = None
     if not a.no_profile_events:
         prof = L.saf_profiler_create(3 * a.frames * max(1, a.steps))
+        L.saf_profiler_set_stride(prof, a.profile_stride)
 
     vol_tensors = [fusion.clip_feat, fusion.rgb, fusion.tsdf, fusion.weight, fusion.tsdf_weight]
 

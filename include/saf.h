@@ -92,7 +92,8 @@ typedef struct saf_frame {
 
 /* Counters the fuse kernels add to (device memory, 8 x u64, caller zeroes them when it wants):
  *  [0] sum of Nv (valid voxels)  [1] sum of Nt (tsdf-valid voxels)  [2] frames fused
- *  [3] labels outside [0,n_classes) that were dropped (the reference raises instead)  [4..7] reserved */
+ *  [3] labels outside [0,n_classes) that were dropped (the reference raises instead)
+ *  [4] fuse workgroups that gave up waiting for their frame's sweep (must stay 0)  [5..7] reserved */
 #define SAF_STATS_WORDS 8
 
 const char* saf_last_error(void);
@@ -127,6 +128,9 @@ typedef struct saf_profiler saf_profiler;
 saf_profiler* saf_profiler_create(int32_t capacity_pairs);
 void saf_profiler_destroy(saf_profiler* p);
 void saf_profiler_reset(saf_profiler* p);
+/* record only every stride-th frame of a saf_fuse_frames_profiled call (event packets between the
+ * kernels cost a few microseconds each; 1 = every frame) */
+void saf_profiler_set_stride(saf_profiler* p, int32_t stride);
 /* total elapsed ms and number of launches recorded for one kernel class; <0 on error */
 int saf_profiler_read(saf_profiler* p, int32_t kernel_class, double* total_ms, int64_t* launches);
 

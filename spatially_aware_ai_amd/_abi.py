@@ -76,6 +76,7 @@ PROTOTYPES = {
     "saf_profiler_create": (_fp, [C.c_int32]),
     "saf_profiler_destroy": (None, [_fp]),
     "saf_profiler_reset": (None, [_fp]),
+    "saf_profiler_set_stride": (None, [_fp, C.c_int32]),
     "saf_profiler_read": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "saf_fuse_frames_profiled": (
         C.c_int,

@@ -158,6 +158,8 @@ class _FusionVolumeMixin:
     def stats(self):
         """dict of counters accumulated by the kernels (forces a device sync)."""
         s = self.fuse_stats.cpu().tolist()
+        if s[4]:
+            raise SafError(f"{s[4]} fuse workgroups timed out waiting for their frame's sweep; the volume is incomplete")
         return {"valid": s[0], "tsdf_valid": s[1], "frames": s[2], "labels_dropped": s[3]}
 
     def extract_mesh(self):

@@ -77,12 +77,15 @@ __device__ __forceinline__ void voxel_coords(const KVol& v, uint32_t n, int& ix,
   ix = (int)x;
 }
 
-// Workspace: a 512-byte header with four rotating sets of list counters (frame i uses set i & 3
-// and zeroes set (i+1) & 3 for its successor), then TWO halves (double buffering for the
-// sweep/fuse pipeline of saf_fuse_frames), each holding the compact lists of one frame and -- only
-// for feature maps too large for LDS -- a re-laid-out copy of the map.
-constexpr size_t kHdrBytes = 512;
+// Workspace: a header with four rotating sets of list counters (frame i uses set i & 3 and zeroes
+// set (i+1) & 3 for its successor) and the sweep-completion counter, then kListBuffers buffers
+// (the sweep/fuse pipeline of saf_fuse_frames lets the sweep run ahead), each holding the compact
+// lists of one frame and -- only for feature maps too large for LDS -- the map image.
+constexpr size_t kHdrBytes = 1024;
 constexpr int kCounterSets = 4;
+constexpr int kListBuffers = 4;      // the sweep may run up to 4 frames ahead of the fuse
+constexpr size_t kSweepDoneOff = 512;  // kDoneShards x u64: sweep blocks finished since the call started
+constexpr int kDoneShards = 8;
 struct WsLayout {
   size_t map_off, lists_off, half, total;
   uint32_t n_blocks, list_cap;
@@ -109,7 +112,7 @@ WsLayout ws_layout(int64_t n_vox, int D, int P) {
   w.lists_off = w.map_off + map_bytes;
   w.half = w.lists_off + (size_t)kNumLists * w.list_cap * sizeof(uint32_t);
   w.half = (w.half + 255) & ~(size_t)255;
-  w.total = kHdrBytes + 2 * w.half;
+  w.total = kHdrBytes + kListBuffers * w.half;
   return w;
 }
 
@@ -163,7 +166,8 @@ __device__ __forceinline__ uint32_t sdiv(uint32_t t, const SmallDiv& f) {
 __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(KVol v, KFrame f,
                                                                unsigned long long* __restrict__ counts,
                                                                unsigned long long* __restrict__ next_counts,
-                                                               uint32_t* __restrict__ lists, uint32_t list_cap) {
+                                                               uint32_t* __restrict__ lists, uint32_t list_cap,
+                                                               unsigned long long* __restrict__ sweep_done) {
   __shared__ uint32_t s_buf[kSweepChunk];
   __shared__ float s_axes[kAxisLds];
   __shared__ uint32_t s_count, s_base, s_nt;
@@ -316,8 +320,18 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(KVol v, KFrame f,
   if (total) {
     __syncthreads();
     uint32_t* dst = lists + (size_t)list * list_cap + s_base;
-    for (uint32_t i = tid; i < total; i += kSweepThreads) dst[i] = s_buf[i];
+    // write-through (sc1) stores: the entries are the only thing the concurrently running fuse
+    // kernel reads from this kernel, and it reads them with sc1 loads
+    for (uint32_t i = tid; i < total; i += kSweepThreads)
+      __hip_atomic_store(&dst[i], s_buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // Publish (CDNA guide, inter-workgroup hand-off without a release fence): every storing wave
+  // drains its write-through stores, the workgroup joins, then ONE lane bumps a shard of the
+  // completion counter that the fuse kernel polls.  No L2 write-back is forced.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+    (void)__hip_atomic_fetch_add(&sweep_done[blockIdx.x % kDoneShards], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -427,13 +441,47 @@ __device__ __forceinline__ void fuse_scalars(const KVol& v, const KFrame& f, con
   }
 }
 
+// Block until the sweep of this frame has published all its blocks (device-side dependency: no
+// event packet sits between consecutive fuse kernels on the caller's stream).  The sweep never
+// waits on anything and always fits beside a fuse workgroup, so this cannot deadlock; the spin is
+// bounded anyway (~2 s of the 100 MHz wall clock) and reports through stats[4].
+__device__ __forceinline__ unsigned long long sweep_blocks_done(const unsigned long long* __restrict__ sweep_done) {
+  unsigned long long n = 0;
+#pragma unroll
+  for (int k = 0; k < kDoneShards; ++k) n += __hip_atomic_load(&sweep_done[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return n;
+}
+__device__ __forceinline__ bool wait_for_sweep(const unsigned long long* __restrict__ sweep_done,
+                                               unsigned long long target, unsigned long long* __restrict__ stats) {
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    if (sweep_blocks_done(sweep_done) < target) {
+      const unsigned long long t0 = wall_clock64();
+      while (sweep_blocks_done(sweep_done) < target) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 200000000ull) {
+          ok = 0;
+          if (stats) atomicAdd(&stats[4], 1ull);
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
 // Once per frame (block 0, thread 0): fold the per-list counters into the caller's statistics.
 __device__ __forceinline__ void add_frame_stats(const unsigned long long* __restrict__ counts,
                                                 unsigned long long* __restrict__ stats) {
   if (stats && blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long nv = 0, nt = 0;
     for (int l = 0; l < kNumLists; ++l) {
-      const unsigned long long c = counts[l];
+      const unsigned long long c = __hip_atomic_load(&counts[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       nv += c & 0xffffffffull;
       nt += c >> 32;
     }
@@ -510,7 +558,9 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(KVol v, KFrame f,
                                                              const unsigned long long* __restrict__ counts,
                                                              const uint32_t* __restrict__ lists, uint32_t list_cap,
                                                              const float* __restrict__ feat_map, const float* __restrict__ map_t, int g_log2,
-                                                             unsigned long long* __restrict__ stats) {
+                                                             unsigned long long* __restrict__ stats,
+                                                             const unsigned long long* __restrict__ sweep_done,
+                                                             unsigned long long sweep_target) {
   using V = typename VecT<VEC>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int tid = threadIdx.x;
@@ -525,6 +575,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(KVol v, KFrame f,
   } else {
     map = reinterpret_cast<const V*>(map_t);
   }
+  if (!wait_for_sweep(sweep_done, sweep_target, stats)) return;  // lists + counters are published
   const Cam cam = load_cam(f.pose, f.K, f.W, f.H);
   const float half_px = (float)f.npx / 2.0f, half_py = (float)f.npy / 2.0f;
   const bool sum = v.accum == SAF_SUM;
@@ -535,7 +586,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(KVol v, KFrame f,
   const int epw = 64 >> g_log2;  // entries per wave per step
   const uint32_t list = blockIdx.x % kNumLists;
   const uint32_t wg_in_list = blockIdx.x / kNumLists, wgs_per_list = gridDim.x / kNumLists;
-  const uint32_t count = (uint32_t)counts[list];
+  const uint32_t count = (uint32_t)__hip_atomic_load(&counts[list], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t* lst = lists + (size_t)list * list_cap;
   add_frame_stats(counts, stats);
   const uint32_t sid = (wg_in_list * (kFuseThreads / 64) + wave) * epw + slot;
@@ -556,7 +607,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_kernel(KVol v, KFrame f,
     for (int j = 0; j < U; ++j) {
       const uint32_t e = e0 + (uint32_t)j * stride;
       act[j] = e < count;
-      n[j] = act[j] ? lst[e] : 0u;
+      n[j] = act[j] ? __hip_atomic_load(&lst[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     // phase 2: issue the row loads of all U rows
 #pragma unroll
@@ -676,7 +727,9 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
                                                                   const uint32_t* __restrict__ lists,
                                                                   uint32_t list_cap, const float* __restrict__ feat_map,
                                                                   const float* __restrict__ map_t, int g_log2,
-                                                                  unsigned long long* __restrict__ stats) {
+                                                                  unsigned long long* __restrict__ stats,
+                                                                  const unsigned long long* __restrict__ sweep_done,
+                                                                  unsigned long long sweep_target) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int tid = threadIdx.x;
   const int DV = v.D >> 2;
@@ -690,6 +743,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
   } else {
     map = reinterpret_cast<const float4*>(map_t);
   }
+  if (!wait_for_sweep(sweep_done, sweep_target, stats)) return;  // lists + counters are published
   const Cam cam = load_cam(f.pose, f.K, f.W, f.H);
   const float half_px = (float)f.npx / 2.0f, half_py = (float)f.npy / 2.0f;
   constexpr bool sum = SUM;
@@ -706,7 +760,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
     mbs[c] = chs[c] * ppad;
   }
   const uint32_t list = blockIdx.x % kNumLists;
-  const uint32_t count = (uint32_t)counts[list];
+  const uint32_t count = (uint32_t)__hip_atomic_load(&counts[list], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t* lst = lists + (size_t)list * list_cap;
   // static, balanced partition of the list over the waves that serve it
   const uint32_t waves_per_list = (gridDim.x / kNumLists) * (kFuseThreads / 64);
@@ -723,7 +777,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
     float a_l = 0.f, b_l = 0.f, wx_l = 0.f, wy_l = 0.f;
     int xy_l = 0;
     if (lane < nb) {
-      n_l = lst[b0 + lane];
+      n_l = __hip_atomic_load(&lst[b0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int ix, iy, iz;
       voxel_coords(v, n_l, ix, iy, iz);
       const Proj p = project(cam, v.ax[ix], v.ay[iy], v.az[iz]);
@@ -790,7 +844,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
 }
 
 using FuseFn = void (*)(KVol, KFrame, const unsigned long long*, const uint32_t*, uint32_t, const float*,
-                        const float*, int, unsigned long long*);
+                        const float*, int, unsigned long long*, const unsigned long long*, unsigned long long);
 
 template <int VEC, int CPL, int U>
 FuseFn pick_lds(bool lds) {
@@ -809,7 +863,8 @@ FuseFn pick_rows(bool g64, bool lds, bool sum) {
 
 int launch_fuse(const KVol& kv, const KFrame& kf, const WsLayout& w, const float* feat_map,
                 const unsigned long long* counts, const unsigned char* half, unsigned long long* stats,
-                bool shared_cus, hipStream_t s) {
+                const unsigned long long* sweep_done, unsigned long long sweep_target, bool shared_cus,
+                hipStream_t s) {
   const int D = kv.D, P = kf.npy * kf.npx;
   const int VEC = (D % 4 == 0) ? 4 : 1;
   const int DV = D / VEC;
@@ -845,16 +900,14 @@ int launch_fuse(const KVol& kv, const KFrame& kf, const WsLayout& w, const float
   // stay free for four sweep blocks of the next frame: both kernels are then resident on every CU
   // and neither can starve the other at dispatch.
   static const int grid_env = getenv("SAF_FUSE_GRID") ? atoi(getenv("SAF_FUSE_GRID")) : 0;
-  int per_cu = shmem ? (int)((160 * 1024) / (shmem + 1024)) : 2;
-  if (per_cu > 2) per_cu = 2;
-  if (per_cu < 1 || shared_cus) per_cu = 1;
-  // pipeline mode: 13/16 of the CUs (208 on MI355X) measured best; the plateau 192..256 is flat
-  int grid = grid_env > 0 ? grid_env : (shared_cus ? (device_cus() * 13) / 16 : device_cus() * per_cu);
+  // one workgroup per CU is enough in-flight rows to saturate HBM (alone: 276 us with 208..256
+  // workgroups, 286 us with 512); in the pipeline 13/16 of the CUs (208 on MI355X) measured best
+  int grid = grid_env > 0 ? grid_env : (shared_cus ? (device_cus() * 13) / 16 : device_cus());
   grid = ((grid + kNumLists - 1) / kNumLists) * kNumLists;
   const uint32_t* lists = reinterpret_cast<const uint32_t*>(half + w.lists_off);
   const float* map_t = reinterpret_cast<const float*>(half + w.map_off);
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kFuseThreads), shmem, s, kv, kf, counts, lists, w.list_cap, feat_map, map_t,
-                     g_log2, stats);
+                     g_log2, stats, sweep_done, sweep_target);
   return check_launch("fuse_kernel");
 }
 
@@ -914,6 +967,7 @@ struct saf_profiler {
   };
   Pair* pairs;
   int capacity, used;
+  int stride;  // record only frames whose index within the call is a multiple of this
 };
 
 namespace saf {
@@ -923,8 +977,8 @@ struct ScopedPair {
   saf_profiler* p;
   hipStream_t s;
   int idx;
-  ScopedPair(saf_profiler* prof, int cls, hipStream_t stream) : p(prof), s(stream), idx(-1) {
-    if (p && p->used < p->capacity) {
+  ScopedPair(saf_profiler* prof, int cls, int64_t frame_no, hipStream_t stream) : p(prof), s(stream), idx(-1) {
+    if (p && p->used < p->capacity && frame_no % p->stride == 0) {
       idx = p->used++;
       p->pairs[idx].cls = cls;
       (void)hipEventRecord(p->pairs[idx].a, s);
@@ -955,32 +1009,37 @@ int make_job(const KVol& kv, const saf_frame* frame, void* workspace, size_t wor
 inline unsigned long long* counter_set(unsigned char* ws, int64_t frame_no) {
   return reinterpret_cast<unsigned long long*>(ws) + (size_t)(frame_no & (kCounterSets - 1)) * kNumLists;
 }
+inline unsigned long long* sweep_done_ptr(unsigned char* ws) {
+  return reinterpret_cast<unsigned long long*>(ws + kSweepDoneOff);
+}
 
-// sweep (and, for maps too large for LDS, the map re-layout) of frame `frame_no` into workspace half `half`
-int launch_classify(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned char* half, int64_t frame_no,
+// sweep (and, for maps too large for LDS, the map image) of frame `frame_no` into list buffer `buf`
+int launch_classify(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned char* buf, int64_t frame_no,
                     saf_profiler* prof, hipStream_t s) {
   const WsLayout& w = job.w;
-  uint32_t* lists = reinterpret_cast<uint32_t*>(half + w.lists_off);
+  uint32_t* lists = reinterpret_cast<uint32_t*>(buf + w.lists_off);
   int rc;
   if (!w.lds_map) {
     const int P = job.kf.npy * job.kf.npx;
     const int items = kv.D * map_ppad(P);
-    ScopedPair t(prof, 0, s);
+    ScopedPair t(prof, 0, frame_no, s);
     hipLaunchKernelGGL(prep_kernel, dim3((items + 255) / 256), dim3(256), 0, s, job.feat_map,
-                       reinterpret_cast<float*>(half + w.map_off), kv.D, P, (kv.D % 4 == 0) ? 4 : 1);
+                       reinterpret_cast<float*>(buf + w.map_off), kv.D, P, (kv.D % 4 == 0) ? 4 : 1);
     if ((rc = check_launch("prep_kernel"))) return rc;
   }
-  ScopedPair t(prof, 1, s);
+  ScopedPair t(prof, 1, frame_no, s);
   hipLaunchKernelGGL(sweep_kernel, dim3(w.n_blocks), dim3(kSweepThreads), 0, s, kv, job.kf, counter_set(ws, frame_no),
-                     counter_set(ws, frame_no + 1), lists, w.list_cap);
+                     counter_set(ws, frame_no + 1), lists, w.list_cap, sweep_done_ptr(ws));
   return check_launch("sweep_kernel");
 }
 
-int launch_rows(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned char* half, int64_t frame_no,
+int launch_rows(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned char* buf, int64_t frame_no,
                 uint64_t* stats, bool shared_cus, saf_profiler* prof, hipStream_t s) {
-  ScopedPair t(prof, 2, s);
-  return launch_fuse(kv, job.kf, job.w, job.feat_map, counter_set(ws, frame_no), half,
-                     reinterpret_cast<unsigned long long*>(stats), shared_cus, s);
+  ScopedPair t(prof, 2, frame_no, s);
+  // the fuse kernel starts once the sweeps of frames 0..frame_no have published all their blocks
+  const unsigned long long target = (unsigned long long)(frame_no + 1) * job.w.n_blocks;
+  return launch_fuse(kv, job.kf, job.w, job.feat_map, counter_set(ws, frame_no), buf,
+                     reinterpret_cast<unsigned long long*>(stats), sweep_done_ptr(ws), target, shared_cus, s);
 }
 
 #define SAF_HIP_TRY(call)                                                                  \
@@ -989,17 +1048,20 @@ int launch_rows(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned
     if (e_ != hipSuccess) { rc = fail(SAF_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); goto done; } \
   } while (0)
 
-// Frames in order.  A single frame runs prep -> sweep -> fuse on the caller's stream.  For two or
-// more frames the classification of frame i+1 (prep + sweep: VALU-bound, touches only the TSDF
-// buffers and its own workspace half) runs on an auxiliary stream while the caller's stream runs
-// the HBM-bound row fuse of frame i; events order sweep(i) -> fuse(i) and fuse(i) -> the reuse of
-// its workspace half by frame i+2.  All work is ordered after what the caller already queued on
-// `s` (fork event) and is complete, as far as `s` is concerned, when the last fuse kernel is.
+// Frames in order.  A single frame runs sweep -> fuse on the caller's stream.  For two or more
+// frames the sweeps (VALU-bound; they touch only the TSDF buffers and their own list buffer) are
+// queued back to back on an auxiliary stream and may run up to kListBuffers frames ahead, while the
+// caller's stream carries the HBM-bound fuse kernels back to back:
+//   sweep(i) -> fuse(i)        device-side: fuse workgroups poll the sweep-completion counter
+//   fuse(i)  -> sweep(i + 4)   reuse of list buffer i & 3: an event recorded on the caller's
+//                              stream after every second fuse kernel (few packets between them)
+// Everything is ordered after what the caller already queued on `s` (fork event), and complete,
+// as far as `s` is concerned, when the last fuse kernel is (it has waited for every sweep).
 int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
               uint64_t* stats, saf_profiler* prof, hipStream_t s) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
-  // all four counter sets start at zero; afterwards every sweep zeroes its successor's set
+  // counters and the completion counter start at zero; afterwards every sweep zeroes its successor's set
   if (hipMemsetAsync(ws, 0, kHdrBytes, s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
   // SAF_PIPELINE=0 keeps everything on the caller's stream (debugging / per-kernel timing)
   static const bool pipeline = !(getenv("SAF_PIPELINE") && getenv("SAF_PIPELINE")[0] == '0');
@@ -1007,41 +1069,39 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
     for (int32_t i = 0; i < n_frames; ++i) {
       FrameJob job;
       if ((rc = make_job(kv, &frames[i], workspace, workspace_bytes, &job))) return rc;
-      unsigned char* half = ws + kHdrBytes;
-      if ((rc = launch_classify(kv, job, ws, half, i, prof, s))) return rc;
-      if ((rc = launch_rows(kv, job, ws, half, i, stats, false, prof, s))) return rc;
+      unsigned char* buf = ws + kHdrBytes;
+      if ((rc = launch_classify(kv, job, ws, buf, i, prof, s))) return rc;
+      if ((rc = launch_rows(kv, job, ws, buf, i, stats, false, prof, s))) return rc;
     }
     return SAF_OK;
   }
+  constexpr int kEvRing = 4;
   hipStream_t aux = nullptr;
-  hipEvent_t fork = nullptr, swept[2] = {nullptr, nullptr}, fused[2] = {nullptr, nullptr};
+  hipEvent_t fork = nullptr, fused[kEvRing] = {nullptr, nullptr, nullptr, nullptr};
   SAF_HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
   SAF_HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-  for (int b = 0; b < 2; ++b) {
-    SAF_HIP_TRY(hipEventCreateWithFlags(&swept[b], hipEventDisableTiming));
-    SAF_HIP_TRY(hipEventCreateWithFlags(&fused[b], hipEventDisableTiming));
-  }
+  for (int b = 0; b < kEvRing; ++b) SAF_HIP_TRY(hipEventCreateWithFlags(&fused[b], hipEventDisableTiming));
   SAF_HIP_TRY(hipEventRecord(fork, s));
   SAF_HIP_TRY(hipStreamWaitEvent(aux, fork, 0));
   for (int32_t i = 0; i < n_frames; ++i) {
-    const int b = i & 1;
     FrameJob job;
     if ((rc = make_job(kv, &frames[i], workspace, workspace_bytes, &job))) goto done;
-    unsigned char* half = ws + kHdrBytes + (size_t)b * job.w.half;
-    if (i >= 2) SAF_HIP_TRY(hipStreamWaitEvent(aux, fused[b], 0));  // half b is free again
-    if ((rc = launch_classify(kv, job, ws, half, i, prof, aux))) goto done;
-    SAF_HIP_TRY(hipEventRecord(swept[b], aux));
-    SAF_HIP_TRY(hipStreamWaitEvent(s, swept[b], 0));
-    if ((rc = launch_rows(kv, job, ws, half, i, stats, true, prof, s))) goto done;
-    SAF_HIP_TRY(hipEventRecord(fused[b], s));
+    unsigned char* buf = ws + kHdrBytes + (size_t)(i % kListBuffers) * job.w.half;
+    if (i >= kListBuffers) {
+      // buffer i & 3 was last read by fuse(i - 4); events exist after the odd-numbered fuse kernels:
+      // the first one at or after i - 4 is j = (i - 4) | 1  (<= i - 3, already recorded)
+      const int32_t j = (i - kListBuffers) | 1;
+      SAF_HIP_TRY(hipStreamWaitEvent(aux, fused[(j >> 1) % kEvRing], 0));
+    }
+    if ((rc = launch_classify(kv, job, ws, buf, i, prof, aux))) goto done;
+    if ((rc = launch_rows(kv, job, ws, buf, i, stats, true, prof, s))) goto done;
+    if (i & 1) SAF_HIP_TRY(hipEventRecord(fused[(i >> 1) % kEvRing], s));
   }
 done:
   // destroying a stream / event with work in flight is deferred by the runtime until it drains
   if (fork) (void)hipEventDestroy(fork);
-  for (int b = 0; b < 2; ++b) {
-    if (swept[b]) (void)hipEventDestroy(swept[b]);
+  for (int b = 0; b < kEvRing; ++b)
     if (fused[b]) (void)hipEventDestroy(fused[b]);
-  }
   if (aux) (void)hipStreamDestroy(aux);
   return rc;
 }
@@ -1088,6 +1148,7 @@ saf_profiler* saf_profiler_create(int32_t capacity_pairs) {
   p->pairs = new saf_profiler::Pair[capacity_pairs];
   p->capacity = 0;
   p->used = 0;
+  p->stride = 1;
   for (int i = 0; i < capacity_pairs; ++i) {
     if (hipEventCreate(&p->pairs[i].a) != hipSuccess || hipEventCreate(&p->pairs[i].b) != hipSuccess) break;
     p->capacity = i + 1;
@@ -1107,6 +1168,10 @@ void saf_profiler_destroy(saf_profiler* p) {
 
 void saf_profiler_reset(saf_profiler* p) {
   if (p) p->used = 0;
+}
+
+void saf_profiler_set_stride(saf_profiler* p, int32_t stride) {
+  if (p) p->stride = stride > 0 ? stride : 1;
 }
 
 int saf_profiler_read(saf_profiler* p, int32_t kernel_class, double* total_ms, int64_t* launches) {
