@@ -162,6 +162,12 @@ def main():
     st = fusion.stats()
     total_frames = world * a.frames * a.steps
     value = total_frames / dt
+    # integrity of the timed work (not timed): every frame of every step was fused, and the volume
+    # of the last step holds exactly one observation per valid (voxel, frame) pair
+    assert st["frames"] == a.frames * a.steps, f"fused {st['frames']} frames, expected {a.frames * a.steps}"
+    if world == 1:
+        w_sum = int(fusion.weight.sum(dtype=torch.int64))
+        assert w_sum * a.steps == st["valid"], f"weight sum {w_sum} x {a.steps} steps != valid count {st['valid']}"
 
     # ---- roofline of the dominant kernel (fuse_kernel), this rank ----
     roofline = None

@@ -77,15 +77,20 @@ __device__ __forceinline__ void voxel_coords(const KVol& v, uint32_t n, int& ix,
   ix = (int)x;
 }
 
-// Workspace: a header with four rotating sets of list counters (frame i uses set i & 3 and zeroes
-// set (i+1) & 3 for its successor) and the sweep-completion counter, then kListBuffers buffers
+// Workspace: a header with eight rotating sets of list counters (frame i uses set i & 7 and zeroes
+// set (i+1) & 7 for its successor) and the sweep-completion counter, then kListBuffers buffers
 // (the sweep/fuse pipeline of saf_fuse_frames lets the sweep run ahead), each holding the compact
 // lists of one frame and -- only for feature maps too large for LDS -- the map image.
-constexpr size_t kHdrBytes = 1024;
-constexpr int kCounterSets = 4;
 constexpr int kListBuffers = 4;      // the sweep may run up to 4 frames ahead of the fuse
-constexpr size_t kSweepDoneOff = 512;  // kDoneShards x u64: sweep blocks finished since the call started
-constexpr int kDoneShards = 8;
+// Counter set i & 7 is zeroed by sweep(i - 1) and read by fuse(i).  sweep(j) may start once
+// fuse(j - kListBuffers) is done, so the set of fuse(i) can be re-zeroed (by sweep(i + 7)) only
+// after fuse(i + 3) -- hence after fuse(i) -- has finished.  (With 4 sets, sweep(i + 3) could zero
+// the set fuse(i) is about to read.)
+constexpr int kCounterSets = 8;
+static_assert(kCounterSets > kListBuffers + 1, "a counter set must outlive the fuse kernel that reads it");
+constexpr size_t kSweepDoneOff = (size_t)kCounterSets * kNumLists * sizeof(unsigned long long);  // 1024
+constexpr int kDoneShards = 8;       // kDoneShards x u64: sweep blocks finished since the call started
+constexpr size_t kHdrBytes = 2048;
 struct WsLayout {
   size_t map_off, lists_off, half, total;
   uint32_t n_blocks, list_cap;

@@ -245,6 +245,24 @@ def test_weird_depth_and_large_weights(oracle):
         assert int(vol.stats[0]) > 0 and fusion.stats()["valid"] == int(vol.stats[0])
 
 
+def test_many_frames_in_one_call_pipeline(oracle):
+    """40 frames through ONE saf_fuse_frames call: the two-stream pipeline with device-side
+    sweep->fuse hand-off, 4-deep list buffers (each reused 10 times) and rotating counter sets.
+    A stale or prematurely recycled list / counter would touch the wrong voxels, so the index
+    sets are compared bit for bit, frame count and per-frame totals included."""
+    w, h, d = 160, 120, 64
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid((72, 64, 80))
+    frames = syn.make_frames(4242, 40, width=w, height=h, feat_dim=d, npy=npy, npx=npx, depth_kind="A")
+    vol, fusion = _oracle_vs_hip(oracle, grid, frames, d, seem=True, batch=40)
+    _assert_same(vol, fusion, seem=True)
+    st = fusion.stats()
+    assert st["frames"] == 40 and st["valid"] == int(vol.stats[0]) > 40 * 1000
+    # and again on the same volume (second call: header re-initialised, weights continue)
+    vol2, fusion2 = _oracle_vs_hip(oracle, grid, frames[:9], d, seem=False, batch=9)
+    _assert_same(vol2, fusion2)
+
+
 def test_sum_mode_and_finalize(oracle):
     """SAF_SUM accumulation + saf_merge_finalize == running mean, and mean_to_sum
     is its inverse."""
