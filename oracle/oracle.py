@@ -67,7 +67,8 @@ def _f32(t):
 class OracleVolume:
     """Volume state on the CPU with the reference's buffer names."""
 
-    def __init__(self, origin, voxel_size, nvox, trunc, feat_dim, n_classes=0, accum_mode=_abi.SAF_RUNNING_MEAN):
+    def __init__(self, origin, voxel_size, nvox, trunc, feat_dim, n_classes=0, accum_mode=_abi.SAF_RUNNING_MEAN,
+                 feat_dtype=torch.float32):
         nvox = torch.as_tensor(nvox)
         self.nvox = nvox
         self.nx, self.ny, self.nz = (int(v) for v in nvox)
@@ -85,7 +86,7 @@ class OracleVolume:
         ]
         self.tsdf = torch.zeros(n)
         self.rgb = torch.zeros(n, 3)
-        self.clip_feat = torch.zeros(n, feat_dim)
+        self.clip_feat = torch.zeros(n, feat_dim, dtype=feat_dtype)
         self.weight = torch.zeros(n, dtype=torch.int32)
         self.tsdf_weight = torch.zeros(n, dtype=torch.int32)
         self.labels_one_hot = torch.zeros(n, n_classes, dtype=torch.int32) if n_classes else None
@@ -94,7 +95,8 @@ class OracleVolume:
     def c_volume(self):
         p = _abi.ptr
         return _abi.SafVolume(
-            self.nx, self.ny, self.nz, self.feat_dim, self.n_classes, _abi.SAF_F32, self.accum_mode,
+            self.nx, self.ny, self.nz, self.feat_dim, self.n_classes,
+            _abi.SAF_BF16 if self.clip_feat.dtype == torch.bfloat16 else _abi.SAF_F32, self.accum_mode,
             self.trunc, p(self.axes[0]), p(self.axes[1]), p(self.axes[2]), p(self.tsdf),
             p(self.tsdf_weight), p(self.weight), p(self.rgb), p(self.clip_feat), p(self.labels_one_hot),
         )

@@ -65,6 +65,30 @@ static inline float dot3(float a0, float a1, float a2, float b0, float b1, float
 #endif
 }
 
+/* bf16 feature volumes (extension; the reference is fp32-only): widening is a shift, narrowing
+ * rounds to nearest even with NaN kept quiet -- the same integer arithmetic as the HIP kernels. */
+static inline float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float feat_get(const saf_volume* v, int64_t i) {
+  return v->feat_dtype == SAF_BF16 ? bf16_to_f32(((const uint16_t*)v->clip_feat)[i]) : ((const float*)v->clip_feat)[i];
+}
+static inline void feat_set(const saf_volume* v, int64_t i, float x) {
+  if (v->feat_dtype == SAF_BF16)
+    ((uint16_t*)v->clip_feat)[i] = f32_to_bf16(x);
+  else
+    ((float*)v->clip_feat)[i] = x;
+}
+
 static int g_threads = 1;
 void saf_oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 int saf_oracle_get_threads(void) { return g_threads; }
@@ -178,10 +202,9 @@ static inline float nearest_fetch(const float* img, int h, int w, int64_t sy, in
  * HOST pointers everywhere.  stats (host, may be NULL) as in saf.h.
  */
 int saf_oracle_fuse_frame(const saf_volume* v, const saf_frame* f, uint64_t* stats) {
-  if (!v || !f || v->feat_dtype != SAF_F32) return SAF_E_INVALID;
+  if (!v || !f || (v->feat_dtype != SAF_F32 && v->feat_dtype != SAF_BF16)) return SAF_E_INVALID;
   const int D = v->feat_dim;
   const int P = f->npy * f->npx;
-  float* feat = (float*)v->clip_feat;
   uint64_t nv = 0, nt = 0, dropped = 0;
   /* voxels are independent within a frame: x-slabs are spread over the host threads (only the
    * cpu_baseline leg of bench.py raises the thread count above 1) */
@@ -224,8 +247,8 @@ int saf_oracle_fuse_frame(const saf_volume* v, const saf_frame* f, uint64_t* sta
         bilin bf = bilinear_setup(c.gx, c.gy, f->npx, f->npy);
         for (int ch = 0; ch < D; ++ch) {
           float s = bilinear_fetch(f->feat_map + (int64_t)ch * P, f->npy, f->npx, f->npx, 1, &bf);
-          float* dst = &feat[n * D + ch];
-          *dst = (v->accum_mode == SAF_SUM) ? (*dst + s) : (s * a + *dst * b);
+          float old = feat_get(v, n * D + ch);
+          feat_set(v, n * D + ch, (v->accum_mode == SAF_SUM) ? (old + s) : (s * a + old * b));
         }
         v->weight[n] = w1;
         /* label histogram (clip_seem_fusion.py:786-791, :820-822) */

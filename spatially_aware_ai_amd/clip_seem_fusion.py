@@ -35,7 +35,7 @@ class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
     _rgb_bilinear = True  # clip_seem_fusion.py:793-798
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_patch_size, clip_patch_stride,
-                 clip_model, seg_model, keep_xyz_world=True):
+                 clip_model, seg_model, keep_xyz_world=True, feat_dtype=torch.float32):
         super().__init__()
         self.clip = clip_model
         self.clip_patch_size = clip_patch_size
@@ -43,7 +43,8 @@ class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
         self.scale_patches_by_depth = scale_patches_by_depth
         self.segmentation_model = seg_model
         self.n_classes = N_PANOPTIC_SLOTS
-        self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, self.n_classes, keep_xyz_world)
+        self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, self.n_classes, keep_xyz_world,
+                          feat_dtype)
         self.debug_counter = 0
 
     def integrate(self, depth_imgs, rgb_imgs, poses, K):

@@ -40,7 +40,8 @@ def _axis_tables(origin, voxel_size, nvox):
 class _FusionVolumeMixin:
     """Buffers, workspace and the C-ABI call shared by both fusion modules."""
 
-    def _init_volume(self, origin, voxel_size, nvox, trunc, feat_dim, n_classes=0, keep_xyz_world=True):
+    def _init_volume(self, origin, voxel_size, nvox, trunc, feat_dim, n_classes=0, keep_xyz_world=True,
+                     feat_dtype=torch.float32):
         nvox = torch.as_tensor(nvox)
         n = int(torch.prod(nvox.long()))
         self.origin = origin
@@ -51,7 +52,9 @@ class _FusionVolumeMixin:
         self.accum_mode = _abi.SAF_RUNNING_MEAN
         self.register_buffer("tsdf", torch.zeros(n, dtype=torch.float32))
         self.register_buffer("rgb", torch.zeros((n, 3), dtype=torch.float32))
-        self.register_buffer("clip_feat", torch.zeros((n, feat_dim), dtype=torch.float32))
+        if feat_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("feat_dtype must be torch.float32 (the reference layout) or torch.bfloat16")
+        self.register_buffer("clip_feat", torch.zeros((n, feat_dim), dtype=feat_dtype))
         self.register_buffer("weight", torch.zeros(n, dtype=torch.int32))
         self.register_buffer("tsdf_weight", torch.zeros(n, dtype=torch.int32))
         if n_classes:
@@ -86,7 +89,8 @@ class _FusionVolumeMixin:
         p = _abi.ptr
         return _abi.SafVolume(
             nx, ny, nz, int(self.n_clip_feats), 0 if labels is None else int(labels.shape[1]),
-            _abi.SAF_F32, int(self.accum_mode), float(self.trunc),
+            _abi.SAF_BF16 if self.clip_feat.dtype == torch.bfloat16 else _abi.SAF_F32, int(self.accum_mode),
+            float(self.trunc),
             p(self.axis_x), p(self.axis_y), p(self.axis_z),
             p(self.tsdf), p(self.tsdf_weight), p(self.weight), p(self.rgb), p(self.clip_feat), p(labels),
         )
@@ -181,7 +185,10 @@ def _query_scan(feats, text, epilogue, scale=1.0, normalize=False, last_only=Fal
         raise SafError("the query scan needs the MI355X device; there is no CPU fallback")
     out_dev = feats.device
     dev = feats.device if feats.is_cuda else torch.device("cuda", torch.cuda.current_device())
-    f = feats.detach().to(device=dev, dtype=torch.float32)
+    f = feats.detach().to(device=dev)
+    ft = {torch.float32: _abi.SAF_F32, torch.bfloat16: _abi.SAF_BF16, torch.float16: _abi.SAF_F16}.get(f.dtype)
+    if ft is None:
+        f, ft = f.float(), _abi.SAF_F32
     if f.dim() != 2:
         raise ValueError("features must be [N,D]")
     if f.stride(1) != 1:
@@ -199,7 +206,7 @@ def _query_scan(feats, text, epilogue, scale=1.0, normalize=False, last_only=Fal
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
     with torch.cuda.device(dev):
         rc = lib().saf_query_scan(
-            f.data_ptr(), _abi.SAF_F32, n, f.stride(0), d, t.data_ptr(), nl, t.stride(0), epilogue, float(scale),
+            f.data_ptr(), ft, n, f.stride(0), d, t.data_ptr(), nl, t.stride(0), epilogue, float(scale),
             int(bool(normalize)), _abi.ptr(out), _abi.ptr(last), _abi.ptr(ws), wsb, current_stream_ptr(),
         )
     check(rc, "saf_query_scan")
@@ -361,7 +368,7 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
     _rgb_bilinear = False  # nearest rgb sampling (clipfusion.py:701-706)
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_model, clip_pretraining,
-                 clip_patch_size, clip_patch_stride, keep_xyz_world=True):
+                 clip_patch_size, clip_patch_stride, keep_xyz_world=True, feat_dtype=torch.float32):
         super().__init__()
         if isinstance(clip_model, str):
             self.clip = Clip(clip_model, clip_pretraining)
@@ -372,7 +379,7 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
         self.clip_patch_size = clip_patch_size
         self.clip_patch_stride = clip_patch_stride
         self.scale_patches_by_depth = scale_patches_by_depth
-        self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, 0, keep_xyz_world)
+        self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, 0, keep_xyz_world, feat_dtype)
 
     def integrate(self, depth_imgs, rgb_imgs, poses, K):
         """Fuse a batch of frames (reference clipfusion.py:627-721).  Batch elements are folded in

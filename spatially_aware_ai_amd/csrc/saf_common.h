@@ -37,6 +37,19 @@ __device__ __forceinline__ void st_stream(float4* p, const float4 x) {
   __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(p));
 }
 
+// bf16 <-> f32 exactly as PyTorch does it: widening is a shift, narrowing rounds to nearest even
+// (NaN stays NaN).  The oracle uses the same integer arithmetic.
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // quiet NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
 // n / d for n < 2^31 by multiply-shift (exact; see saf_fuse.hip make_fastdiv).
 struct FastDiv {
   uint32_t mul, shift, d, pad;

@@ -38,7 +38,7 @@ namespace {
 // kernel-side descriptors (POD, passed by value)
 // ------------------------------------------------------------------------------------------
 struct KVol {
-  int nx, ny, nz, D, n_classes, accum;
+  int nx, ny, nz, D, n_classes, accum, bf16;
   uint32_t N;
   float trunc;
   const float *ax, *ay, *az;
@@ -726,7 +726,10 @@ __device__ __forceinline__ RowCtx fetch_row(int src, uint32_t n_l, float a_l, fl
 // counted waits: lanes whose chunk index would fall past the row re-do the last chunk (identical
 // value to the same address), and lane groups past the end of a batch re-do the batch's last
 // row inside the SAME wave instruction as its owner (same loads, same stores).
-template <int CPL, int R, bool G64, bool LDS_MAP, bool SUM>
+// BF16: the feature volume holds bfloat16 (a 16-byte lane access = 8 channels = two map chunks);
+// samples are blended in fp32 exactly as for the fp32 volume and rounded to nearest-even once per
+// update.
+template <int CPL, int R, bool G64, bool LDS_MAP, bool SUM, bool BF16>
 __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame f,
                                                                   const unsigned long long* __restrict__ counts,
                                                                   const uint32_t* __restrict__ lists,
@@ -758,11 +761,14 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
   const int lane = tid & 63, wave = tid >> 6;
   const int slot = G64 ? 0 : (lane >> g_log2), gl = lane & (G - 1);
   const int epw = G64 ? 1 : (64 >> g_log2);  // rows per wave step
-  int chs[CPL], mbs[CPL];
+  constexpr int KV = BF16 ? 2 : 1;  // map chunks (4 channels each) per 16-byte row unit
+  const int DU = DV / KV;           // 16-byte units per row
+  int chs[CPL], mbs[CPL][KV];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
-    chs[c] = min(gl + c * G, DV - 1);
-    mbs[c] = chs[c] * ppad;
+    chs[c] = min(gl + c * G, DU - 1);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) mbs[c][k] = (chs[c] * KV + k) * ppad;
   }
   const uint32_t list = blockIdx.x % kNumLists;
   const uint32_t count = (uint32_t)__hip_atomic_load(&counts[list], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -804,12 +810,28 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
     const int last = nb - 1;
 #define SAF_FETCH(i) fetch_row<G64>(min((i) * epw + slot, last), n_l, a_l, b_l, xy_l, wx_l, wy_l, f.npx, f.npy)
 #define SAF_LOAD(ctx_, old_)                                                           \
-  _Pragma("unroll") for (int c = 0; c < CPL; ++c) old_[c] = ld_stream(&feat[(int64_t)(ctx_).n * DV + chs[c]]);
-#define SAF_STORE(ctx_, old_)                                                                                      \
-  _Pragma("unroll") for (int c = 0; c < CPL; ++c) {                                                                \
-    const float4 sv = lerp_taps(map[mbs[c] + (ctx_).t.o_nw], map[mbs[c] + (ctx_).t.o_ne],                          \
-                                map[mbs[c] + (ctx_).t.o_sw], map[mbs[c] + (ctx_).t.o_se], (ctx_).w);               \
-    st_stream(&feat[(int64_t)(ctx_).n * DV + chs[c]], blend(sv, old_[c], (ctx_).a, (ctx_).b, sum));               \
+  _Pragma("unroll") for (int c = 0; c < CPL; ++c) old_[c] = ld_stream(&feat[(int64_t)(ctx_).n * DU + chs[c]]);
+#define SAF_TAPS(c_, k_, ctx_)                                                                         \
+  lerp_taps(map[mbs[c_][k_] + (ctx_).t.o_nw], map[mbs[c_][k_] + (ctx_).t.o_ne], map[mbs[c_][k_] + (ctx_).t.o_sw], \
+            map[mbs[c_][k_] + (ctx_).t.o_se], (ctx_).w)
+#define SAF_STORE(ctx_, old_)                                                                          \
+  _Pragma("unroll") for (int c = 0; c < CPL; ++c) {                                                    \
+    float4 out_;                                                                                       \
+    if (BF16) {                                                                                        \
+      const uint32_t w0_ = __builtin_bit_cast(uint32_t, old_[c].x), w1_ = __builtin_bit_cast(uint32_t, old_[c].y); \
+      const uint32_t w2_ = __builtin_bit_cast(uint32_t, old_[c].z), w3_ = __builtin_bit_cast(uint32_t, old_[c].w); \
+      const float4 n0_ = blend(SAF_TAPS(c, 0, ctx_), make_float4(bf16_lo(w0_), bf16_hi(w0_), bf16_lo(w1_), bf16_hi(w1_)), \
+                               (ctx_).a, (ctx_).b, sum);                                               \
+      const float4 n1_ = blend(SAF_TAPS(c, KV - 1, ctx_), make_float4(bf16_lo(w2_), bf16_hi(w2_), bf16_lo(w3_), bf16_hi(w3_)), \
+                               (ctx_).a, (ctx_).b, sum);                                               \
+      out_.x = __builtin_bit_cast(float, pack_bf16(n0_.x, n0_.y));                                     \
+      out_.y = __builtin_bit_cast(float, pack_bf16(n0_.z, n0_.w));                                     \
+      out_.z = __builtin_bit_cast(float, pack_bf16(n1_.x, n1_.y));                                     \
+      out_.w = __builtin_bit_cast(float, pack_bf16(n1_.z, n1_.w));                                     \
+    } else {                                                                                           \
+      out_ = blend(SAF_TAPS(c, 0, ctx_), old_[c], (ctx_).a, (ctx_).b, sum);                            \
+    }                                                                                                  \
+    st_stream(&feat[(int64_t)(ctx_).n * DU + chs[c]], out_);                                           \
   }
     int i0 = 0;
     if (steps >= R) {
@@ -844,6 +866,7 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
     }
 #undef SAF_FETCH
 #undef SAF_LOAD
+#undef SAF_TAPS
 #undef SAF_STORE
   }
 }
@@ -856,14 +879,16 @@ FuseFn pick_lds(bool lds) {
   return lds ? fuse_kernel<VEC, CPL, U, true> : fuse_kernel<VEC, CPL, U, false>;
 }
 
-template <int CPL, int R, bool SUM>
-FuseFn pick_rows2(bool g64, bool lds) {
-  if (g64) return lds ? fuse_rows_kernel<CPL, R, true, true, SUM> : fuse_rows_kernel<CPL, R, true, false, SUM>;
-  return lds ? fuse_rows_kernel<CPL, R, false, true, SUM> : fuse_rows_kernel<CPL, R, false, false, SUM>;
+template <int CPL, int R, bool SUM, bool BF16>
+FuseFn pick_rows3(bool g64, bool lds) {
+  if (g64)
+    return lds ? fuse_rows_kernel<CPL, R, true, true, SUM, BF16> : fuse_rows_kernel<CPL, R, true, false, SUM, BF16>;
+  return lds ? fuse_rows_kernel<CPL, R, false, true, SUM, BF16> : fuse_rows_kernel<CPL, R, false, false, SUM, BF16>;
 }
 template <int CPL, int R>
-FuseFn pick_rows(bool g64, bool lds, bool sum) {
-  return sum ? pick_rows2<CPL, R, true>(g64, lds) : pick_rows2<CPL, R, false>(g64, lds);
+FuseFn pick_rows(bool g64, bool lds, bool sum, bool bf16) {
+  if (bf16) return sum ? pick_rows3<CPL, R, true, true>(g64, lds) : pick_rows3<CPL, R, false, true>(g64, lds);
+  return sum ? pick_rows3<CPL, R, true, false>(g64, lds) : pick_rows3<CPL, R, false, false>(g64, lds);
 }
 
 int launch_fuse(const KVol& kv, const KFrame& kf, const WsLayout& w, const float* feat_map,
@@ -871,22 +896,33 @@ int launch_fuse(const KVol& kv, const KFrame& kf, const WsLayout& w, const float
                 const unsigned long long* sweep_done, unsigned long long sweep_target, bool shared_cus,
                 hipStream_t s) {
   const int D = kv.D, P = kf.npy * kf.npx;
+  const bool bf16 = kv.bf16 != 0;
   const int VEC = (D % 4 == 0) ? 4 : 1;
   const int DV = D / VEC;
+  const int units = bf16 ? D / 8 : DV;  // 16-byte row units (vector path)
   int g_log2 = 0;
-  while ((1 << g_log2) < DV && g_log2 < 6) ++g_log2;
+  while ((1 << g_log2) < units && g_log2 < 6) ++g_log2;
   const int G = 1 << g_log2;
-  const int cpl = (DV + G - 1) / G;
+  const int cpl = (units + G - 1) / G;
   const bool lds = w.lds_map;
   const bool sum = kv.accum == SAF_SUM;
   FuseFn fn;
-  if (VEC == 4 && cpl >= 1 && cpl <= 4) {
+  if (bf16) {
+    if (D % 8 != 0 || cpl > 4) return fail(SAF_E_UNSUPPORTED, "bf16 volume needs feat_dim %% 8 == 0 and <= 2048");
     const bool g64 = G == 64;
     switch (cpl) {
-      case 1: fn = pick_rows<1, 4>(g64, lds, sum); break;
-      case 2: fn = pick_rows<2, 4>(g64, lds, sum); break;
-      case 3: fn = pick_rows<3, 2>(g64, lds, sum); break;
-      default: fn = pick_rows<4, 2>(g64, lds, sum); break;
+      case 1: fn = pick_rows<1, 8>(g64, lds, sum, true); break;
+      case 2: fn = pick_rows<2, 4>(g64, lds, sum, true); break;
+      case 3: fn = pick_rows<3, 2>(g64, lds, sum, true); break;
+      default: fn = pick_rows<4, 2>(g64, lds, sum, true); break;
+    }
+  } else if (VEC == 4 && cpl >= 1 && cpl <= 4) {
+    const bool g64 = G == 64;
+    switch (cpl) {
+      case 1: fn = pick_rows<1, 4>(g64, lds, sum, false); break;
+      case 2: fn = pick_rows<2, 4>(g64, lds, sum, false); break;
+      case 3: fn = pick_rows<3, 2>(g64, lds, sum, false); break;
+      default: fn = pick_rows<4, 2>(g64, lds, sum, false); break;
     }
   } else if (VEC == 4) {
     fn = pick_lds<4, 0, 1>(lds);
@@ -922,7 +958,10 @@ int make_kvol(const saf_volume* vol, KVol* kv) {
     return fail(SAF_E_INVALID, "bad volume shape %dx%dx%d D=%d", vol->nx, vol->ny, vol->nz, vol->feat_dim);
   const int64_t N = n_voxels(vol);
   if (N >= (1ll << 31)) return fail(SAF_E_UNSUPPORTED, "volumes of 2^31 voxels or more are not supported");
-  if (vol->feat_dtype != SAF_F32) return fail(SAF_E_UNSUPPORTED, "feat_dtype %d: only SAF_F32 so far", vol->feat_dtype);
+  if (vol->feat_dtype != SAF_F32 && vol->feat_dtype != SAF_BF16)
+    return fail(SAF_E_UNSUPPORTED, "feat_dtype %d: SAF_F32 and SAF_BF16 are implemented", vol->feat_dtype);
+  if (vol->feat_dtype == SAF_BF16 && (vol->feat_dim % 8 != 0 || ((uintptr_t)vol->clip_feat & 15)))
+    return fail(SAF_E_UNSUPPORTED, "a bf16 volume needs feat_dim %% 8 == 0 and a 16-byte aligned buffer");
   if (vol->accum_mode != SAF_RUNNING_MEAN && vol->accum_mode != SAF_SUM)
     return fail(SAF_E_INVALID, "bad accum_mode %d", vol->accum_mode);
   if (!vol->axis_x || !vol->axis_y || !vol->axis_z || !vol->tsdf || !vol->tsdf_weight || !vol->weight || !vol->rgb ||
@@ -936,6 +975,7 @@ int make_kvol(const saf_volume* vol, KVol* kv) {
   kv->D = vol->feat_dim;
   kv->n_classes = vol->labels_one_hot ? vol->n_classes : 0;
   kv->accum = vol->accum_mode;
+  kv->bf16 = vol->feat_dtype == SAF_BF16;
   kv->N = (uint32_t)N;
   kv->trunc = vol->trunc;
   kv->ax = vol->axis_x; kv->ay = vol->axis_y; kv->az = vol->axis_z;

@@ -32,8 +32,16 @@ __device__ __forceinline__ float wave_max(float x) {
   return x;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(kQThreads) void query_kernel(const float* __restrict__ feats, int64_t n_rows,
+// feature element -> fp32 (FT: saf_dtype).  bf16 / fp16 volumes halve the scan's HBM bytes.
+template <int FT>
+__device__ __forceinline__ float load_feat(const void* __restrict__ base, int64_t i) {
+  if (FT == SAF_BF16) return __builtin_bit_cast(float, (uint32_t) static_cast<const uint16_t*>(base)[i] << 16);
+  if (FT == SAF_F16) return (float)static_cast<const _Float16*>(base)[i];
+  return static_cast<const float*>(base)[i];
+}
+
+template <int EPI, int FT>
+__global__ __launch_bounds__(kQThreads) void query_kernel(const void* __restrict__ feats, int64_t n_rows,
                                                            int64_t fstride, int D, const float* __restrict__ text,
                                                            int L, int64_t tstride, float scale, int normalize,
                                                            float* __restrict__ wts, float* __restrict__ out,
@@ -48,10 +56,9 @@ __global__ __launch_bounds__(kQThreads) void query_kernel(const float* __restric
     const int64_t r = r0 + wave;
     const bool active = r < n_rows;
     if (active) {
-      const float* f = feats + r * fstride;
       float ss = 0.f;
       for (int c = lane; c < D; c += 64) {
-        const float x = f[c];
+        const float x = load_feat<FT>(feats, r * fstride + c);
         row[c] = x;
         ss += x * x;
       }
@@ -122,12 +129,12 @@ __global__ __launch_bounds__(kQThreads) void query_kernel(const float* __restric
   }
 }
 
-template <int EPI>
-int launch(const float* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
+template <int EPI, int FT>
+int launch_t(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
            float scale, int normalize, float* wts, float* out, float* out_last, hipStream_t s) {
   const size_t shmem = (size_t)kQWaves * (((D + 3) & ~3) + ((L + 3) & ~3)) * sizeof(float);
   if (shmem > 150 * 1024) return fail(SAF_E_UNSUPPORTED, "feat_dim + n_text too large for the v1 scan (%zu B LDS)", shmem);
-  auto fn = query_kernel<EPI>;
+  auto fn = query_kernel<EPI, FT>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)shmem);
@@ -140,6 +147,19 @@ int launch(const float* feats, int64_t n_rows, int64_t fstride, int D, const flo
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kQThreads), shmem, s, feats, n_rows, fstride, D, text, L,
                      tstride, scale, normalize, wts, out, out_last);
   return check_launch("query_kernel");
+}
+
+template <int EPI>
+int launch(int ft, const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
+           float scale, int normalize, float* wts, float* out, float* out_last, hipStream_t s) {
+  switch (ft) {
+    case SAF_BF16:
+      return launch_t<EPI, SAF_BF16>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+    case SAF_F16:
+      return launch_t<EPI, SAF_F16>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+    default:
+      return launch_t<EPI, SAF_F32>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+  }
 }
 
 }  // namespace
@@ -157,29 +177,31 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
                    const float* text, int32_t n_text, int64_t text_stride, int32_t epilogue, float scale,
                    int32_t normalize, float* out, float* out_last, void* workspace, size_t workspace_bytes,
                    void* stream) {
-  if (feat_dtype != SAF_F32) return fail(SAF_E_UNSUPPORTED, "query scan: only SAF_F32 features so far");
+  if (feat_dtype != SAF_F32 && feat_dtype != SAF_BF16 && feat_dtype != SAF_F16)
+    return fail(SAF_E_UNSUPPORTED, "query scan: unknown feature dtype %d", feat_dtype);
   if (!feats || !text || n_rows < 0 || feat_dim <= 0 || n_text <= 0 || feat_stride < feat_dim || text_stride < feat_dim)
     return fail(SAF_E_INVALID, "query scan: bad arguments");
   if (!out && !out_last) return fail(SAF_E_INVALID, "query scan: no output buffer");
   if (n_rows == 0) return SAF_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const float* f = static_cast<const float*>(feats);
+  const void* f = feats;
+  const int ft = feat_dtype;
   switch (epilogue) {
     case SAF_Q_SCORES:
-      return launch<SAF_Q_SCORES>(f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
+      return launch<SAF_Q_SCORES>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
                                   nullptr, out, out_last, s);
     case SAF_Q_SOFTMAX:
-      return launch<SAF_Q_SOFTMAX>(f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
+      return launch<SAF_Q_SOFTMAX>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
                                    nullptr, out, out_last, s);
     case SAF_Q_SURGERY: {
       if (!workspace || workspace_bytes < saf_query_workspace_bytes(n_text, epilogue))
         return fail(SAF_E_WORKSPACE, "query scan: surgery needs %zu bytes of workspace",
                     saf_query_workspace_bytes(n_text, epilogue));
       float* wts = static_cast<float*>(workspace);
-      int rc = launch<EPI_WEIGHTS>(f, 1, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize, wts,
+      int rc = launch<EPI_WEIGHTS>(ft, f, 1, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize, wts,
                                    nullptr, nullptr, s);
       if (rc) return rc;
-      return launch<SAF_Q_SURGERY>(f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize, wts,
+      return launch<SAF_Q_SURGERY>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize, wts,
                                    out, out_last, s);
     }
     default:

@@ -119,17 +119,19 @@ def test_clipseem_golden(small, golden_dir):
     assert fusion.stats()["labels_dropped"] == 0
 
 
-def _oracle_vs_hip(oracle, grid, frames, dim, seem=False, accum=_abi.SAF_RUNNING_MEAN, batch=1):
+def _oracle_vs_hip(oracle, grid, frames, dim, seem=False, accum=_abi.SAF_RUNNING_MEAN, batch=1,
+                   feat_dtype=torch.float32):
     from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
 
-    vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, dim, 143 if seem else 0, accum)
+    vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, dim, 143 if seem else 0, accum,
+                              feat_dtype=feat_dtype)
     clip, seg = FakeClip(dim), FakeSeg()
     if seem:
         fusion = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, 10, 10, clip, seg,
-                                keep_xyz_world=False).cuda()
+                                keep_xyz_world=False, feat_dtype=feat_dtype).cuda()
     else:
         fusion = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, 10, 10,
-                            keep_xyz_world=False).cuda()
+                            keep_xyz_world=False, feat_dtype=feat_dtype).cuda()
     fusion.accum_mode = accum
     for s in range(0, len(frames), batch):
         fs = frames[s : s + batch]
@@ -261,6 +263,37 @@ def test_many_frames_in_one_call_pipeline(oracle):
     # and again on the same volume (second call: header re-initialised, weights continue)
     vol2, fusion2 = _oracle_vs_hip(oracle, grid, frames[:9], d, seem=False, batch=9)
     _assert_same(vol2, fusion2)
+
+
+@pytest.mark.parametrize("dim,seem", [(512, True), (64, False), (1024, False), (24, True)])
+def test_bf16_volume_bit_exact_against_oracle(oracle, dim, seem):
+    """bfloat16 feature volume (BASELINE config 3): fp32 blend, one round-to-nearest-even per update.
+    The oracle does the same arithmetic, so the stored bf16 bits must be identical; against an fp32
+    volume the features agree to bf16 resolution."""
+    w, h = 64, 48
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid((28, 24, 36))
+    frames = syn.make_frames(31, 10, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="A")
+    vol, fusion = _oracle_vs_hip(oracle, grid, frames, dim, seem=seem, batch=5, feat_dtype=torch.bfloat16)
+    assert fusion.clip_feat.dtype == torch.bfloat16
+    assert torch.equal(fusion.weight.cpu(), vol.weight) and torch.equal(fusion.tsdf_weight.cpu(), vol.tsdf_weight)
+    assert torch.equal(fusion.clip_feat.cpu().view(torch.int16), vol.clip_feat.view(torch.int16)), "bf16 bits differ"
+    _close(fusion.rgb, vol.rgb, "rgb")
+    vol32, _ = _oracle_vs_hip(oracle, grid, frames, dim, seem=seem, batch=5)
+    err = (vol.clip_feat.float() - vol32.clip_feat).abs()
+    assert float(err.max()) <= 0.02 * float(vol32.clip_feat.abs().max()) + 1e-3
+    # the query scan reads the bf16 rows directly
+    from spatially_aware_ai_amd.clipfusion import _query_scan
+
+    text = torch.randn(5, dim, generator=torch.Generator().manual_seed(3))
+    text = text / text.norm(dim=-1, keepdim=True)
+    rows = torch.nonzero(vol.weight > 0)[:200, 0]
+    got = _query_scan(fusion.clip_feat[rows.cuda()], text.cuda(), _abi.SAF_Q_SOFTMAX, scale=100.0, normalize=True)
+    want = oracle.query_scan(vol.clip_feat[rows].float(), text, _abi.SAF_Q_SOFTMAX, scale=100.0, normalize=True)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-6)
+    half = _query_scan(vol32.clip_feat[rows].half().cuda(), text.cuda(), _abi.SAF_Q_SCORES, scale=1.0)
+    want_h = oracle.query_scan(vol32.clip_feat[rows].half().float(), text, _abi.SAF_Q_SCORES, scale=1.0)
+    np.testing.assert_allclose(half.cpu().numpy(), want_h.numpy(), rtol=2e-4, atol=2e-5)
 
 
 def test_sum_mode_and_finalize(oracle):
