@@ -149,6 +149,231 @@ int launch_t(const void* feats, int64_t n_rows, int64_t fstride, int D, const fl
   return check_launch("query_kernel");
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA scan (feat_dim % 8 == 0, n_text <= 64): exact-fp32 matrix cores.
+//
+// A wave owns 32 feature rows at a time.  v_mfma_f32_32x32x2_f32 takes A[row = lane & 31][k = lane >> 5]
+// and B[k = lane >> 5][col = lane & 31], one value per lane; the k order inside a dot product is
+// free, so lane half h takes k = 8c + 4h + j (j = 0..3) of every 8-wide K chunk c: each lane then
+// reads 16 contiguous bytes of ITS row straight from HBM (no LDS staging of the features, every
+// byte read once), and 16 contiguous bytes of ITS text row from LDS.  Text rows are padded to
+// D + 4 floats: (D/4 + 1) is odd, so the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank
+// slots.  Row norms come from the same registers (sum of squares of what the lane loaded, the two
+// halves added), and the epilogue works on the accumulator layout (col = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): row-wise max / sum are 5-step xor shuffles inside
+// each 32-lane half.  The result of an MFMA chain is bit-for-bit an fmaf chain in k order.
+// Bytes: N*D*s in, N*L*4 out -- HBM-bound for L <= 32, about balanced at L = 64.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int FT>
+__device__ __forceinline__ float4 load_feat4(const void* __restrict__ base, int64_t i) {
+  if (FT == SAF_F32) return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + i);
+  const uint2 w = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + i);
+  if (FT == SAF_BF16)
+    return make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 a = __builtin_bit_cast(h2, w.x), b = __builtin_bit_cast(h2, w.y);
+  return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+}
+
+__device__ __forceinline__ float half_max(float x) {  // over the 32 lanes of this half
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+  return x;
+}
+__device__ __forceinline__ float half_sum(float x) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+constexpr int kQGroup = 8;  // K chunks (of 8 floats) per prefetch group: 64 floats of every row
+
+template <int EPI, int FT, int TILES>
+__global__ __launch_bounds__(kQThreads) void query_mfma_kernel(const void* __restrict__ feats, int64_t n_rows,
+                                                                int64_t fstride, int D, const float* __restrict__ text,
+                                                                int L, int64_t tstride, float scale, int normalize,
+                                                                const float* __restrict__ wts, float* __restrict__ out,
+                                                                float* __restrict__ out_last) {
+  extern __shared__ __attribute__((aligned(16))) float s_text[];  // [TILES*32][D + 4], rows >= L are zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tstr = D + 4;
+  for (int i = tid; i < TILES * 32 * D; i += kQThreads) {
+    const int n = i / D, k = i - n * D;
+    s_text[n * tstr + k] = n < L ? text[(int64_t)n * tstride + k] : 0.0f;
+  }
+  __syncthreads();
+  const int m = lane & 31, h = lane >> 5;
+  const int n_groups = D / (8 * kQGroup);  // full prefetch groups; the remainder is handled chunk by chunk
+  const int64_t n_tiles = (n_rows + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * kQWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kQWaves) {
+    int64_t row = tile * 32 + m;
+    if (row >= n_rows) row = n_rows - 1;  // padded lanes recompute the last row, never stored
+    const int64_t base = row * fstride + 4 * h;
+    const float* tb = s_text + m * tstr + 4 * h;
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    float ss = 0.0f;
+    float4 cur[kQGroup], nxt[kQGroup];
+    if (n_groups > 0) {
+#pragma unroll
+      for (int q = 0; q < kQGroup; ++q) nxt[q] = load_feat4<FT>(feats, base + 8 * q);
+    }
+    for (int g = 0; g < n_groups; ++g) {
+#pragma unroll
+      for (int q = 0; q < kQGroup; ++q) cur[q] = nxt[q];
+      if (g + 1 < n_groups) {
+#pragma unroll
+        for (int q = 0; q < kQGroup; ++q) nxt[q] = load_feat4<FT>(feats, base + 8 * ((g + 1) * kQGroup + q));
+      }
+#pragma unroll
+      for (int q = 0; q < kQGroup; ++q) {
+        const int k0 = 8 * (g * kQGroup + q);
+        const float4 a = cur[q];
+        ss = __builtin_fmaf(a.x, a.x, ss);
+        ss = __builtin_fmaf(a.y, a.y, ss);
+        ss = __builtin_fmaf(a.z, a.z, ss);
+        ss = __builtin_fmaf(a.w, a.w, ss);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          const float4 b = *reinterpret_cast<const float4*>(tb + t * 32 * tstr + k0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    for (int k0 = 8 * kQGroup * n_groups; k0 < D; k0 += 8) {  // D not a multiple of 64
+      const float4 a = load_feat4<FT>(feats, base + k0);
+      ss = __builtin_fmaf(a.x, a.x, ss);
+      ss = __builtin_fmaf(a.y, a.y, ss);
+      ss = __builtin_fmaf(a.z, a.z, ss);
+      ss = __builtin_fmaf(a.w, a.w, ss);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(tb + t * 32 * tstr + k0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+    // ---- epilogue on the accumulator layout: this lane holds column n = m (+32 t) of 16 rows
+    ss += __shfl_xor(ss, 32);  // both halves of row m
+    // clip_feat /= norm ; nan_to_num: an all-zero row gives zeros       clip_seem_fusion.py:508-511
+    const float inv = normalize ? (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int mi = (i & 3) + 8 * (i >> 2) + 4 * h;  // row of accumulator register i in this half
+      const float inv_i = __shfl(inv, mi);
+      const int64_t r = tile * 32 + mi;
+      float val[TILES];
+      bool ok[TILES];
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        ok[t] = (m + 32 * t) < L;
+        val[t] = acc[t][i] * inv_i;  // cosine score S[r][n]
+      }
+      if (EPI == SAF_Q_SOFTMAX) {
+        // relevance = (100 * img_feats @ text.T).softmax(-1)            clipfusion.py:902-903
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) mx = fmaxf(mx, ok[t] ? scale * val[t] : -INFINITY);
+        mx = half_max(mx);
+        float e[TILES], sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          e[t] = ok[t] ? expf(scale * val[t] - mx) : 0.0f;
+          sum += e[t];
+        }
+        sum = half_sum(sum);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) val[t] = e[t] / sum;
+      } else if (EPI == SAF_Q_SURGERY) {
+        // similarity = S*w - mean_t(S*w)                                 clipfusion.py:924-932
+        float part = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          val[t] = ok[t] ? val[t] * wts[m + 32 * t] : 0.0f;
+          part += val[t];
+        }
+        const float mean = half_sum(part) / (float)L;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) val[t] -= mean;
+      } else {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) val[t] *= scale;
+      }
+      if (r < n_rows) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          if (ok[t]) {
+            if (out) out[r * L + m + 32 * t] = val[t];
+            if (out_last && m + 32 * t == L - 1) out_last[r] = val[t];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int FT, int TILES>
+int launch_mfma_t(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
+                  float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s) {
+  const size_t shmem = (size_t)TILES * 32 * (D + 4) * sizeof(float);
+  auto fn = query_mfma_kernel<EPI, FT, TILES>;
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)shmem);
+    if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const int per_cu = (int)((160 * 1024) / (shmem + 256)) > 2 ? 2 : (int)((160 * 1024) / (shmem + 256));
+  int64_t blocks = ((n_rows + 31) / 32 + kQWaves - 1) / kQWaves;
+  const int64_t cap = (int64_t)device_cus() * (per_cu < 1 ? 1 : per_cu);
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kQThreads), shmem, s, feats, n_rows, fstride, D, text, L,
+                     tstride, scale, normalize, wts, out, out_last);
+  return check_launch("query_mfma_kernel");
+}
+
+// true if the MFMA scan can take this shape
+inline bool mfma_ok(int ft, int64_t fstride, int D, int L, const void* feats) {
+  const int esz = ft == SAF_F32 ? 4 : 2;
+  if (D % 8 != 0 || L > 64) return false;
+  if (((uintptr_t)feats & 15) || (fstride * esz) % (4 * esz) != 0 || (fstride % 4) != 0) return false;
+  const size_t shmem = (size_t)(L > 32 ? 2 : 1) * 32 * (D + 4) * sizeof(float);
+  return shmem <= 150 * 1024;
+}
+
+template <int EPI, int FT>
+int launch_mfma_f(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
+                  float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s) {
+  return L > 32 ? launch_mfma_t<EPI, FT, 2>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out,
+                                            out_last, s)
+                : launch_mfma_t<EPI, FT, 1>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out,
+                                            out_last, s);
+}
+
+template <int EPI>
+int launch_mfma(int ft, const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L,
+                int64_t tstride, float scale, int normalize, const float* wts, float* out, float* out_last,
+                hipStream_t s) {
+  switch (ft) {
+    case SAF_BF16:
+      return launch_mfma_f<EPI, SAF_BF16>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+    case SAF_F16:
+      return launch_mfma_f<EPI, SAF_F16>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+    default:
+      return launch_mfma_f<EPI, SAF_F32>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+  }
+}
+
 template <int EPI>
 int launch(int ft, const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
            float scale, int normalize, float* wts, float* out, float* out_last, hipStream_t s) {
@@ -186,11 +411,18 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
   hipStream_t s = static_cast<hipStream_t>(stream);
   const void* f = feats;
   const int ft = feat_dtype;
+  const bool mfma = mfma_ok(ft, feat_stride, feat_dim, n_text, feats);
   switch (epilogue) {
     case SAF_Q_SCORES:
+      if (mfma)
+        return launch_mfma<SAF_Q_SCORES>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale,
+                                         normalize, nullptr, out, out_last, s);
       return launch<SAF_Q_SCORES>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
                                   nullptr, out, out_last, s);
     case SAF_Q_SOFTMAX:
+      if (mfma)
+        return launch_mfma<SAF_Q_SOFTMAX>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale,
+                                          normalize, nullptr, out, out_last, s);
       return launch<SAF_Q_SOFTMAX>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
                                    nullptr, out, out_last, s);
     case SAF_Q_SURGERY: {
@@ -201,6 +433,9 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
       int rc = launch<EPI_WEIGHTS>(ft, f, 1, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize, wts,
                                    nullptr, nullptr, s);
       if (rc) return rc;
+      if (mfma)
+        return launch_mfma<SAF_Q_SURGERY>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, 1.0f,
+                                          normalize, wts, out, out_last, s);
       return launch<SAF_Q_SURGERY>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize, wts,
                                    out, out_last, s);
     }
