@@ -252,8 +252,8 @@ def main():
             "avg_launch_us": round(iso_s * 1e6, 2), "achieved": round(fuse_bytes / iso_s / 1e9, 1),
             "frac": round(fuse_bytes / iso_s / 1e9 / HBM_PEAK_GBS, 4), "launches": int(n.value),
             "sweep_us": round(tot_s.value / max(1, n_s.value) * 1e3, 2),
-            "note": "fuse kernel alone on the chip (2 workgroups/CU); the timed region overlaps it with the next "
-                    "frame's sweep",
+            "note": "fuse kernel alone on the chip (one frame per call); in the timed region it shares the chip "
+                    "with the sweeps of the following frames",
         }
 
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1 only) ----

@@ -15,7 +15,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 dst = f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+def newest(pattern):
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
+ks = newest(f"{src}/trace/*/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks[0], f"{dst}/kernel_stats.csv")
     for r in csv.DictReader(open(ks[0])):
@@ -35,7 +40,7 @@ def name_of(k):
 
 out = {}
 for d, cn in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+    fs = newest(f"{src}/{d}/*/*_counter_collection.csv")
     if not fs:
         continue
     agg = collections.defaultdict(list)
