@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--unique-frames", type=int, default=512,
                     help="distinct synthetic frames resident per rank (cycled to --frames)")
     ap.add_argument("--merge", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
+    ap.add_argument("--no-overlap-merge", action="store_true",
+                    help="N > 1: run each step's merge on the compute stream instead of overlapping it with the "
+                         "next step's fusion (second volume + side stream)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the control flow)")
     ap.add_argument("--feat-dtype", default="f32", choices=["f32", "bf16"],
                     help="feature-volume dtype: f32 = the reference layout (headline); bf16 = BASELINE config 3")
     ap.add_argument("--labels", action="store_true",
@@ -92,13 +97,18 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    if os.environ.get("SAF_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0  # rehearsal: every rank on the one GPU of the box
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(a.backend)
 
     from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
     from spatially_aware_ai_amd import distributed as sdist
@@ -112,13 +122,21 @@ def main():
 
     fdt = torch.bfloat16 if a.feat_dtype == "bf16" else torch.float32
     esz = 2 if a.feat_dtype == "bf16" else 4
-    if a.labels:
-        fusion = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, a.height // 3,
-                                a.height // 6, ResidentFeatures(), None, keep_xyz_world=False, feat_dtype=fdt).to(device)
-    else:
-        fusion = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, ResidentFeatures(), None,
-                            a.height // 3, a.height // 6, keep_xyz_world=False, feat_dtype=fdt).to(device)
-    fusion.accum_mode = _abi.SAF_SUM if world > 1 else _abi.SAF_RUNNING_MEAN
+    # N > 1: consecutive steps are independent jobs, so job k's merge (RCCL, side stream) overlaps
+    # job k+1's fusion into a second volume; all of it is inside the timed region.
+    overlap = world > 1 and not a.no_overlap_merge
+    fusions = []
+    for _ in range(2 if overlap else 1):
+        if a.labels:
+            fz = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, a.height // 3,
+                                a.height // 6, ResidentFeatures(), None, keep_xyz_world=False, feat_dtype=fdt)
+        else:
+            fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, ResidentFeatures(), None,
+                            a.height // 3, a.height // 6, keep_xyz_world=False, feat_dtype=fdt)
+        fz = fz.to(device)
+        fz.accum_mode = _abi.SAF_SUM if world > 1 else _abi.SAF_RUNNING_MEAN
+        fusions.append(fz)
+    fusion = fusions[0]
 
     uniq = min(a.unique_frames, a.frames)
     depth, rgb, poses, ks, feat = gen_frames_gpu(uniq, a.width, a.height, a.dim, npy, npx, a.depth_kind,
@@ -132,27 +150,60 @@ def main():
     for i in range(a.frames):
         frames[i] = arr_u[i % uniq]
     ws = fusion._get_workspace(npy, npx)
-    vol = fusion._c_volume()
-    stream = torch.cuda.current_stream().cuda_stream
+    vols = [fz._c_volume() for fz in fusions]
+    vol = vols[0]
+    main_stream = torch.cuda.current_stream()
+    stream = main_stream.cuda_stream
+    comm_stream = torch.cuda.Stream() if overlap else main_stream
+    merge_done = [None] * len(fusions)
+    merge_state = {"mode": a.merge, "fallback": None}
     L = lib()
     prof = None
     if not a.no_profile_events:
         prof = L.saf_profiler_create(3 * a.frames * max(1, a.steps))
         L.saf_profiler_set_stride(prof, a.profile_stride)
 
-    vol_tensors = [fusion.clip_feat, fusion.rgb, fusion.tsdf, fusion.weight, fusion.tsdf_weight]
-    if a.labels:
-        vol_tensors.append(fusion.labels_one_hot)
+    def volume_tensors(fz):
+        ts = [fz.clip_feat, fz.rgb, fz.tsdf, fz.weight, fz.tsdf_weight]
+        if a.labels:
+            ts.append(fz.labels_one_hot)
+        return ts
+
+    vol_tensors = [volume_tensors(fz) for fz in fusions]
+    step_no = [0]
+
+    def merge(fz):
+        fz.accum_mode = _abi.SAF_SUM
+        try:
+            sdist.merge_volumes(fz, mode=merge_state["mode"])
+        except Exception as e:  # e.g. a backend without (in-place) reduce-scatter: fall back, keep measuring
+            if merge_state["mode"] == "all_reduce":
+                raise
+            merge_state["fallback"] = f"{type(e).__name__}: {e}"[:200]
+            merge_state["mode"] = "all_reduce"
+            fz.accum_mode = _abi.SAF_SUM
+            sdist.merge_volumes(fz, mode="all_reduce")
 
     def step(profiler):
-        for t in vol_tensors:
+        slot = step_no[0] % len(fusions)
+        step_no[0] += 1
+        fz = fusions[slot]
+        if merge_done[slot] is not None:  # this volume's previous merge must have drained
+            main_stream.wait_event(merge_done[slot])
+        for t in vol_tensors[slot]:
             t.zero_()
-        rc = L.saf_fuse_frames_profiled(C.byref(vol), frames, a.frames, ws.data_ptr(), ws.numel(),
+        rc = L.saf_fuse_frames_profiled(C.byref(vols[slot]), frames, a.frames, ws.data_ptr(), ws.numel(),
                                         fusion.fuse_stats.data_ptr(), profiler, stream)
         check(rc, "saf_fuse_frames_profiled")
         if world > 1:
-            fusion.accum_mode = _abi.SAF_SUM
-            sdist.merge_volumes(fusion, mode=a.merge)
+            if overlap:
+                fused = main_stream.record_event()
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(fused)
+                    merge(fz)
+                    merge_done[slot] = comm_stream.record_event()
+            else:
+                merge(fz)
 
     def barrier():
         if world > 1:
@@ -182,7 +233,7 @@ def main():
     # of the last step holds exactly one observation per valid (voxel, frame) pair
     assert st["frames"] == a.frames * a.steps, f"fused {st['frames']} frames, expected {a.frames * a.steps}"
     if world == 1:
-        w_sum = int(fusion.weight.sum(dtype=torch.int64))
+        w_sum = int(fusions[(step_no[0] - 1) % len(fusions)].weight.sum(dtype=torch.int64))
         assert w_sum * a.steps == st["valid"], f"weight sum {w_sum} x {a.steps} steps != valid count {st['valid']}"
 
     # ---- roofline of the dominant kernel (fuse_kernel), this rank ----
@@ -278,10 +329,12 @@ def main():
             "config": {
                 "workload": f"{a.frames} frames/rank {a.width}x{a.height} depth-{a.depth_kind}, per-rank "
                             f"{a.grid}^3x{a.dim} {a.feat_dtype} grid{' + panoptic label histogram' if a.labels else ''}, frames sharded, "
-                            + ("one RCCL " + a.merge + " merge per step" if world > 1 else "single GPU (no merge)"),
+                            + (f"one {a.backend} {merge_state['mode']} merge per step"
+                               + (", overlapped with the next step's fusion" if overlap else "")
+                               if world > 1 else "single GPU (no merge)"),
                 "frames_per_rank": a.frames, "grid": a.grid, "feat_dim": a.dim, "image": [a.width, a.height],
                 "feature_map": [npy, npx], "unique_frames_resident": uniq, "n_voxels": n_vox,
-                "parallelism": f"frames-dp{world}",
+                "parallelism": f"frames-dp{world}", "merge_fallback": merge_state["fallback"],
             },
             "roofline": roofline,
             "kernel_breakdown": breakdown,
