@@ -180,6 +180,20 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
 size_t saf_query_workspace_bytes(int32_t n_text, int32_t epilogue);
 
 /*
+ * Wide scan (BASELINE config 5: hundreds to thousands of text queries over a 16-bit feature
+ * volume): scores out[n,q] = scale * <f_n, t_q> (rows optionally L2-normalised first) on the 16-bit
+ * matrix cores with fp32 accumulation.  The text embeddings are rounded to the feature dtype.
+ *   feats      [n_rows, feat_stride] SAF_F16 or SAF_BF16, feat_dim in {128, 256, 512}
+ *   out        [n_rows, out_stride] of out_dtype (SAF_F32, SAF_F16 or SAF_BF16), out_stride >= n_text
+ *   workspace  saf_query_wide_workspace_bytes(n_text, feat_dim) bytes of device scratch
+ */
+size_t saf_query_wide_workspace_bytes(int32_t n_text, int32_t feat_dim);
+int saf_query_scan_wide(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_t feat_stride,
+                        int32_t feat_dim, const float* text, int32_t n_text, int64_t text_stride,
+                        float scale, int32_t normalize, void* out, int32_t out_dtype, int64_t out_stride,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * After the cross-rank SUM of SAF_SUM-mode volumes: clip_feat <- F/w,
  * rgb <- C/w, tsdf <- T/wt over voxels [first, first+count); rows with zero weight stay zero.
  */

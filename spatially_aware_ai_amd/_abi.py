@@ -95,6 +95,15 @@ PROTOTYPES = {
         ],
     ),
     "saf_query_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "saf_query_wide_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "saf_query_scan_wide": (
+        C.c_int,
+        [
+            _fp, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+            _fp, C.c_int32, C.c_int64,
+            C.c_float, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_size_t, _fp,
+        ],
+    ),
     "saf_merge_finalize": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_mean_to_sum": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_label_argmax": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, _fp]),

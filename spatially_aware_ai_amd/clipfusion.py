@@ -214,6 +214,38 @@ def _query_scan(feats, text, epilogue, scale=1.0, normalize=False, last_only=Fal
     return res.to(out_dev)
 
 
+_DT = {torch.float32: _abi.SAF_F32, torch.bfloat16: _abi.SAF_BF16, torch.float16: _abi.SAF_F16}
+
+
+def query_scores_wide(feats, text, scale=1.0, normalize=True, out_dtype=None):
+    """Cosine scores of many text queries over a 16-bit feature volume (BASELINE config 5: the
+    query_mesh.py scan with ~1000 queries): ``out[n, q] = scale * <f_n / |f_n|, t_q>`` on the 16-bit matrix
+    cores (saf_query_scan_wide).  ``feats`` [N, D] float16 / bfloat16 on the HIP device, D in {128, 256, 512};
+    ``text`` [Q, >=D] fp32 (rounded to the feature dtype); returns [N, Q] of ``out_dtype`` (default: feats.dtype).
+    """
+    require_cuda(feats, "features")
+    if feats.dtype not in (torch.float16, torch.bfloat16) or feats.dim() != 2:
+        raise ValueError("query_scores_wide needs a [N, D] float16 / bfloat16 feature tensor")
+    if feats.stride(1) != 1:
+        feats = feats.contiguous()
+    out_dtype = out_dtype or feats.dtype
+    t = text.detach().to(device=feats.device, dtype=torch.float32)
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    n, d = feats.shape
+    q = t.shape[0]
+    out = torch.empty((n, q), dtype=out_dtype, device=feats.device)
+    wsb = lib().saf_query_wide_workspace_bytes(q, d)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=feats.device)
+    with torch.cuda.device(feats.device):
+        rc = lib().saf_query_scan_wide(
+            feats.data_ptr(), _DT[feats.dtype], n, feats.stride(0), d, t.data_ptr(), q, t.stride(0), float(scale),
+            int(bool(normalize)), out.data_ptr(), _DT[out_dtype], out.stride(0), ws.data_ptr(), wsb, current_stream_ptr(),
+        )
+    check(rc, "saf_query_scan_wide")
+    return out
+
+
 class Clip(torch.nn.Module):
     """Mirror of the reference ``Clip`` (clipfusion.py:766-1039).
 

@@ -1,0 +1,306 @@
+// saf_query_wide.hip -- many-query cosine scan on the 16-bit matrix cores (BASELINE config 5:
+// a 1000-query CLIP-text scan over a 256^3 x 512 fp16 volume, the query_mesh.py path at scale).
+//
+// This is a dense contraction (2*N*D*Q flop, 17 TFLOP at config 5), MFMA-bound, so the layout is a
+// GEMM's -- but one operand is the whole HBM-resident volume, read exactly once:
+//   * a wave owns 32 feature rows and keeps them in registers for ALL queries: lane (r = lane & 31,
+//     h = lane >> 5) holds A[r][16 s + 8 h + j] (j = 0..7) for every K step s -- the operand layout of
+//     v_mfma_f32_32x32x{16}_{f16,bf16}; each 16-byte fragment is loaded straight from the lane's own
+//     row (D = 512: 128 VGPRs per lane);
+//   * the text embeddings (rounded once to the volume's dtype by a small pre-kernel) stream through a
+//     double-buffered LDS tile of 32 queries; rows padded by 16 bytes so that the 16 lanes of a
+//     ds_read_b128 group hit distinct bank quads; the 8 waves of a workgroup (256 feature rows) share it;
+//   * per tile 32 MFMAs per wave accumulate a 32x32 fp32 block, scaled by the row's 1/norm (computed from
+//     the same registers) and written out as scores in the requested dtype.
+#include "saf_common.h"
+#include "saf_host.h"
+
+namespace saf {
+namespace {
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr int kWThreads = 512;
+constexpr int kWWaves = kWThreads / 64;
+constexpr int kWTile = 32;  // queries per LDS tile
+
+// fp32 text [Q][tstride] -> 16-bit [Qpad][D] (rows >= Q zero)
+template <int FT>
+__global__ void text_to_16_kernel(const float* __restrict__ text, int Q, int64_t tstride, int D, int Qpad,
+                                  uint16_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Qpad * D) return;
+  const int q = i / D, k = i - q * D;
+  const float v = q < Q ? text[(int64_t)q * tstride + k] : 0.0f;
+  if (FT == SAF_BF16) {
+    out[i] = (uint16_t)f32_to_bf16_bits(v);
+  } else {
+    const _Float16 hv = (_Float16)v;
+    out[i] = __builtin_bit_cast(uint16_t, hv);
+  }
+}
+
+template <int FT>
+__device__ __forceinline__ float elem16_to_f32(uint16_t b) {
+  if (FT == SAF_BF16) return __builtin_bit_cast(float, (uint32_t)b << 16);
+  return (float)__builtin_bit_cast(_Float16, b);
+}
+
+template <int OT>
+__device__ __forceinline__ void store_score(void* __restrict__ out, int64_t idx, float v) {
+  if (OT == SAF_F32) {
+    static_cast<float*>(out)[idx] = v;
+  } else if (OT == SAF_BF16) {
+    static_cast<uint16_t*>(out)[idx] = (uint16_t)f32_to_bf16_bits(v);
+  } else {
+    const _Float16 hv = (_Float16)v;
+    static_cast<uint16_t*>(out)[idx] = __builtin_bit_cast(uint16_t, hv);
+  }
+}
+
+template <int FT>
+__device__ __forceinline__ f32x16_t mfma16(const uint4& a, const uint4& b, const f32x16_t& c) {
+  if (FT == SAF_BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+}
+
+// Four consecutive scores of one feature row -> one 8-byte (16-bit out) or 16-byte (fp32 out) store.
+template <int OT>
+__device__ __forceinline__ void store_scores4(void* __restrict__ out, int64_t idx, float v0, float v1, float v2,
+                                              float v3) {
+  if (OT == SAF_F32) {
+    *reinterpret_cast<float4*>(static_cast<float*>(out) + idx) = make_float4(v0, v1, v2, v3);
+  } else if (OT == SAF_BF16) {
+    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(out) + idx) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+  } else {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 a, b;
+    a.x = (_Float16)v0; a.y = (_Float16)v1; b.x = (_Float16)v2; b.y = (_Float16)v3;
+    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(out) + idx) =
+        make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+  }
+}
+
+// KS = D / 16 K steps (register-resident feature fragments: 4 VGPRs each).
+//
+// Operand roles: the TEXT tile is the MFMA's A operand and the FEATURE rows its B operand (both
+// fragments have the same lane layout: row/col = lane & 31, k = 16 s + 8 h + j), so the accumulator
+// holds C[query][feature row]: lane (r, h) owns feature row r and, in register group g = i >> 2, the four
+// CONSECUTIVE queries 8 g + 4 h + (i & 3).  The epilogue is then per lane: its own row's 1/norm (no
+// shuffles) and one vector store of 4 scores per group.
+template <int FT, int OT, int KS>
+__global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void query_wide_kernel(const uint16_t* __restrict__ feats, int64_t n_rows,
+                                                                int64_t fstride, const uint16_t* __restrict__ text16,
+                                                                int Q, int Qpad, float scale, int normalize,
+                                                                void* __restrict__ out, int64_t ostride) {
+  constexpr int D = KS * 16;
+  constexpr int ROWB = D * 2 + 16;  // padded LDS row in bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_tiles[];  // 2 x [32][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n_qt = Qpad / kWTile;
+  const int64_t n_blocks = (n_rows + 32 * kWWaves - 1) / (32 * kWWaves);
+  // cooperative tile copy: 32 rows x D*2 bytes = 32 * (D/8) 16-byte pieces over 512 threads
+  constexpr int PIECES = kWTile * (D / 8);
+  constexpr int PPT = (PIECES + kWThreads - 1) / kWThreads;  // pieces per thread (4 at D = 512)
+  const bool vec_ok = (OT == SAF_F32 ? (ostride % 4 == 0) : (ostride % 4 == 0)) &&
+                      (((uintptr_t)out & 15) == 0);
+  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int64_t row0 = (blk * kWWaves + wave) * 32;
+    const int64_t row_true = row0 + r;
+    const int64_t row = row_true < n_rows ? row_true : n_rows - 1;  // padded lanes recompute the last row
+    const uint16_t* arow = feats + row * fstride + 8 * h;
+    // the wave's 32 rows, register resident for every query tile
+    uint4 a[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const uint4*>(arow + 16 * s);
+    float inv = scale;
+    if (normalize) {
+      float ss = 0.0f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint32_t w[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = elem16_to_f32<FT>((uint16_t)(w[j] & 0xffffu)), hi = elem16_to_f32<FT>((uint16_t)(w[j] >> 16));
+          ss = __builtin_fmaf(lo, lo, ss);
+          ss = __builtin_fmaf(hi, hi, ss);
+        }
+      }
+      ss += __shfl_xor(ss, 32);                              // both halves of row r
+      inv = ss > 0.0f ? scale / sqrtf(ss) : 0.0f;            // nan_to_num: an all-zero row scores 0
+    }
+
+    __syncthreads();  // the previous row block is done with both LDS buffers
+    for (int p = tid; p < PIECES; p += kWThreads) {
+      const int q = p / (D / 8), c = p - q * (D / 8);
+      *reinterpret_cast<uint4*>(s_tiles + q * ROWB + c * 16) =
+          *reinterpret_cast<const uint4*>(text16 + (int64_t)q * D + c * 8);
+    }
+    __syncthreads();
+    for (int qt = 0; qt < n_qt; ++qt) {
+      const unsigned char* cur = s_tiles + (size_t)(qt & 1) * kWTile * ROWB;
+      unsigned char* nxt = s_tiles + (size_t)((qt + 1) & 1) * kWTile * ROWB;
+      // Next tile: at D = 512 a text row is exactly one 1 KiB LDS-DMA piece (global_load_lds_dwordx4:
+      // 64 lanes x 16 B, written linearly from a wave-uniform LDS base), so each wave copies 4 rows
+      // straight into the other buffer with no registers; it lands while this tile's MFMAs run and
+      // is covered by the barrier's vmcnt(0).  Narrower rows are staged through registers.
+      constexpr bool kDma = (D == 512);
+      uint4 stage[kDma ? 1 : PPT];
+      const bool more = qt + 1 < n_qt;
+      if (more) {
+        if (kDma) {
+#pragma unroll
+          for (int k = 0; k < kWTile / kWWaves; ++k) {
+            const int q = wave * (kWTile / kWWaves) + k;
+            const uint16_t* src = text16 + (int64_t)((qt + 1) * kWTile + q) * D + lane * 8;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(nxt + q * ROWB), 16, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < PPT; ++k) {
+            const int p = tid + k * kWThreads;
+            if (p < PIECES) {
+              const int q = p / (D / 8), c = p - q * (D / 8);
+              stage[k] = *reinterpret_cast<const uint4*>(text16 + (int64_t)((qt + 1) * kWTile + q) * D + c * 8);
+            }
+          }
+        }
+      }
+      f32x16_t acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+      const unsigned char* trow = cur + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4 t = *reinterpret_cast<const uint4*>(trow + 32 * s);
+        acc = mfma16<FT>(t, a[s], acc);  // C[query][feature row]
+      }
+      if (more && !kDma) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const int p = tid + k * kWThreads;
+          if (p < PIECES) {
+            const int q = p / (D / 8), c = p - q * (D / 8);
+            *reinterpret_cast<uint4*>(nxt + q * ROWB + c * 16) = stage[k];
+          }
+        }
+      }
+      // The barrier comes BEFORE this tile's output stores: what it waits for (vmcnt counts loads and
+      // stores in issue order) is then the LDS-DMA of the next tile plus the PREVIOUS tile's stores, which
+      // have had a whole MFMA phase to drain; this tile's stores overlap the next tile's MFMAs.
+      if (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile qt consumed by every wave; tile qt+1 fully written
+      if (row_true < n_rows) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int q0 = qt * kWTile + 8 * g + 4 * h;
+          const int64_t idx = row_true * ostride + q0;
+          const float v0 = acc[4 * g] * inv, v1 = acc[4 * g + 1] * inv, v2 = acc[4 * g + 2] * inv,
+                      v3 = acc[4 * g + 3] * inv;
+          if (vec_ok && q0 + 3 < Q) {
+            store_scores4<OT>(out, idx, v0, v1, v2, v3);
+          } else {
+            if (q0 < Q) store_score<OT>(out, idx, v0);
+            if (q0 + 1 < Q) store_score<OT>(out, idx + 1, v1);
+            if (q0 + 2 < Q) store_score<OT>(out, idx + 2, v2);
+            if (q0 + 3 < Q) store_score<OT>(out, idx + 3, v3);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int FT, int OT, int KS>
+int launch_wide(const uint16_t* feats, int64_t n_rows, int64_t fstride, const uint16_t* text16, int Q, int Qpad,
+                float scale, int normalize, void* out, int64_t ostride, hipStream_t s) {
+  constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16);
+  auto fn = query_wide_kernel<FT, OT, KS>;
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)shmem);
+    if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  int64_t blocks = (n_rows + 32 * kWWaves - 1) / (32 * kWWaves);
+  const int64_t cap = device_cus();
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kWThreads), shmem, s, feats, n_rows, fstride, text16, Q, Qpad,
+                     scale, normalize, out, ostride);
+  return check_launch("query_wide_kernel");
+}
+
+template <int FT, int OT>
+int launch_wide_ks(int D, const uint16_t* feats, int64_t n_rows, int64_t fstride, const uint16_t* text16, int Q,
+                   int Qpad, float scale, int normalize, void* out, int64_t ostride, hipStream_t s) {
+  switch (D) {
+    case 128: return launch_wide<FT, OT, 8>(feats, n_rows, fstride, text16, Q, Qpad, scale, normalize, out, ostride, s);
+    case 256: return launch_wide<FT, OT, 16>(feats, n_rows, fstride, text16, Q, Qpad, scale, normalize, out, ostride, s);
+    case 512: return launch_wide<FT, OT, 32>(feats, n_rows, fstride, text16, Q, Qpad, scale, normalize, out, ostride, s);
+    default: return fail(SAF_E_UNSUPPORTED, "wide scan: feat_dim must be 128, 256 or 512 (got %d)", D);
+  }
+}
+
+template <int FT>
+int launch_wide_ot(int ot, int D, const uint16_t* feats, int64_t n_rows, int64_t fstride, const uint16_t* text16, int Q,
+                   int Qpad, float scale, int normalize, void* out, int64_t ostride, hipStream_t s) {
+  switch (ot) {
+    case SAF_F32: return launch_wide_ks<FT, SAF_F32>(D, feats, n_rows, fstride, text16, Q, Qpad, scale, normalize, out, ostride, s);
+    case SAF_F16: return launch_wide_ks<FT, SAF_F16>(D, feats, n_rows, fstride, text16, Q, Qpad, scale, normalize, out, ostride, s);
+    case SAF_BF16: return launch_wide_ks<FT, SAF_BF16>(D, feats, n_rows, fstride, text16, Q, Qpad, scale, normalize, out, ostride, s);
+    default: return fail(SAF_E_INVALID, "wide scan: bad out_dtype %d", ot);
+  }
+}
+
+}  // namespace
+}  // namespace saf
+
+using namespace saf;
+
+extern "C" {
+
+size_t saf_query_wide_workspace_bytes(int32_t n_text, int32_t feat_dim) {
+  if (n_text <= 0 || feat_dim <= 0) return 0;
+  const size_t qpad = ((size_t)n_text + kWTile - 1) / kWTile * kWTile;
+  return (qpad * feat_dim * 2 + 255) & ~(size_t)255;
+}
+
+int saf_query_scan_wide(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_t feat_stride, int32_t feat_dim,
+                        const float* text, int32_t n_text, int64_t text_stride, float scale, int32_t normalize,
+                        void* out, int32_t out_dtype, int64_t out_stride, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (feat_dtype != SAF_F16 && feat_dtype != SAF_BF16)
+    return fail(SAF_E_UNSUPPORTED, "wide scan: features must be SAF_F16 or SAF_BF16");
+  if (!feats || !text || !out || n_rows < 0 || n_text <= 0 || feat_stride < feat_dim || text_stride < feat_dim ||
+      out_stride < n_text)
+    return fail(SAF_E_INVALID, "wide scan: bad arguments");
+  if (((uintptr_t)feats & 15) || (feat_stride % 8) != 0) return fail(SAF_E_INVALID, "wide scan: feature rows must be 16-byte aligned");
+  if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < saf_query_wide_workspace_bytes(n_text, feat_dim))
+    return fail(SAF_E_WORKSPACE, "wide scan: workspace needs %zu bytes", saf_query_wide_workspace_bytes(n_text, feat_dim));
+  if (n_rows == 0) return SAF_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int Qpad = (n_text + kWTile - 1) / kWTile * kWTile;
+  uint16_t* text16 = static_cast<uint16_t*>(workspace);
+  const int items = Qpad * feat_dim;
+  if (feat_dtype == SAF_BF16)
+    hipLaunchKernelGGL(text_to_16_kernel<SAF_BF16>, dim3((items + 255) / 256), dim3(256), 0, s, text, n_text, text_stride,
+                       feat_dim, Qpad, text16);
+  else
+    hipLaunchKernelGGL(text_to_16_kernel<SAF_F16>, dim3((items + 255) / 256), dim3(256), 0, s, text, n_text, text_stride,
+                       feat_dim, Qpad, text16);
+  int rc = check_launch("text_to_16_kernel");
+  if (rc) return rc;
+  const uint16_t* f = static_cast<const uint16_t*>(feats);
+  return feat_dtype == SAF_BF16
+             ? launch_wide_ot<SAF_BF16>(out_dtype, feat_dim, f, n_rows, feat_stride, text16, n_text, Qpad, scale, normalize,
+                                        out, out_stride, s)
+             : launch_wide_ot<SAF_F16>(out_dtype, feat_dim, f, n_rows, feat_stride, text16, n_text, Qpad, scale, normalize,
+                                       out, out_stride, s);
+}
+
+}  // extern "C"

@@ -296,6 +296,35 @@ def test_bf16_volume_bit_exact_against_oracle(oracle, dim, seem):
     np.testing.assert_allclose(half.cpu().numpy(), want_h.numpy(), rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("dt,dim,out_dt", [(torch.float16, 512, torch.float32), (torch.bfloat16, 512, torch.bfloat16),
+                                           (torch.float16, 128, torch.float16), (torch.bfloat16, 256, torch.float32)])
+def test_wide_query_scan_16bit_mfma(oracle, dt, dim, out_dt):
+    """Config-5 path: many queries over a 16-bit volume on the 16-bit matrix cores, against the oracle's
+    double-precision scores of the SAME rounded operands.  Ragged sizes (rows % 256, queries % 32), one
+    all-zero row (nan_to_num -> 0)."""
+    from spatially_aware_ai_amd.clipfusion import query_scores_wide
+
+    g = torch.Generator().manual_seed(11)
+    n, q = 1000, 203
+    feats = torch.randn(n, dim, generator=g).to(dt)
+    feats[77] = 0
+    text = torch.randn(q, dim, generator=g)
+    text = text / text.norm(dim=-1, keepdim=True)
+    got = query_scores_wide(feats.cuda(), text.cuda(), scale=1.0, normalize=True, out_dtype=out_dt)
+    assert got.shape == (n, q) and got.dtype == out_dt
+    want = oracle.query_scan(feats.float(), text.to(dt).float(), _abi.SAF_Q_SCORES, scale=1.0, normalize=True)
+    tol = {torch.float32: 2e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}[out_dt]
+    err = (got.float().cpu() - want).abs().max().item()
+    assert err <= tol, f"max abs err {err}"
+    assert float(got[77].abs().max()) == 0.0
+    # asymmetric structure check (A = one-hot rows): score[n, q] must be text[q, k_n]
+    eye = torch.zeros(64, dim)
+    ks = torch.randperm(dim, generator=g)[:64]
+    eye[torch.arange(64), ks] = 1.0
+    sc = query_scores_wide(eye.to(dt).cuda(), text.cuda(), normalize=False, out_dtype=torch.float32).cpu()
+    np.testing.assert_allclose(sc.numpy(), text.to(dt).float()[:, ks].T.numpy(), rtol=0, atol=1e-6)
+
+
 def test_sum_mode_and_finalize(oracle):
     """SAF_SUM accumulation + saf_merge_finalize == running mean, and mean_to_sum
     is its inverse."""
