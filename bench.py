@@ -63,6 +63,11 @@ def parse():
                     help="ClipSeemFusion path: panoptic label histogram + bilinear rgb (BASELINE config 3)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--end-to-end", type=int, default=0, metavar="FRAMES",
+                    help="after the timed region, also time FRAMES frames through the reference-shaped API with a "
+                         "ViT-B/32-shaped random-weight CLIP image tower in front of the fuse (reported separately)")
+    ap.add_argument("--e2e-batch", type=int, default=8, help="frames per integrate() call in the end-to-end pass")
+    ap.add_argument("--e2e-dtype", default="f32", choices=["f32", "bf16"], help="backbone compute dtype")
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="record HIP events around the kernels of every n-th frame of the timed region")
     return ap.parse_args()
@@ -307,6 +312,46 @@ def main():
                     "with the sweeps of the following frames",
         }
 
+    # ---- end-to-end: backbone + fuse through the reference-shaped Python API (reported separately) ----
+    e2e = None
+    if a.end_to_end > 0 and rank == 0 and world == 1 and a.dim == 512 and not a.labels:
+        from spatially_aware_ai_amd.backbones import RandomViTB32
+        from spatially_aware_ai_amd.clipfusion import Clip
+
+        clip = Clip("ViT-B-32 (random weights)", None, backbone=RandomViTB32(), tokenizer=None).to(device).eval()
+        clip.requires_grad_(False)
+        fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, a.height // 3,
+                        a.height // 6, keep_xyz_world=False, feat_dtype=fdt).to(device)
+        nfr = min(a.end_to_end, uniq)
+        bs = max(1, a.e2e_batch)
+
+        def run_e2e():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.e2e_dtype == "bf16"):
+                for s0 in range(0, nfr, bs):
+                    sl = slice(s0, min(nfr, s0 + bs))
+                    fz.integrate(depth[sl], rgb[sl], poses[sl], ks[sl])
+
+        run_e2e()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_e2e()
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.e2e_dtype == "bf16"):
+            t2 = time.perf_counter()
+            for s0 in range(0, nfr, bs):
+                clip.img_inference_tiled(rgb[s0 : s0 + bs].permute(0, 3, 1, 2), a.height // 3, a.height // 6)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t2
+        e2e = {
+            "value": round(nfr / d1, 1), "unit": "frames/s", "frames": nfr, "batch": bs,
+            "backbone": "ViT-B/32 image tower, seeded random weights (no CLIP weights offline), 35 tiles/frame, "
+                        + a.e2e_dtype,
+            "backbone_only_frames_per_s": round(nfr / d2, 1),
+            "note": "Clip.img_inference_tiled (PyTorch-ROCm) + saf_fuse_frames through ClipFusion.integrate; "
+                    "kMaX is not part of this pass",
+        }
+
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1 only) ----
     cpu = None
     if rank == 0 and world == 1 and a.cpu_frames != 0:
@@ -339,6 +384,7 @@ def main():
             "roofline": roofline,
             "kernel_breakdown": breakdown,
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
