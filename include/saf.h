@@ -203,6 +203,19 @@ int saf_merge_finalize(const saf_volume* vol, int64_t first_voxel, int64_t n_vox
  * (x*w), so that it can enter the reduction. */
 int saf_mean_to_sum(const saf_volume* vol, int64_t first_voxel, int64_t n_voxels, void* stream);
 
+/*
+ * Vertex sampling half of extract_mesh (clipfusion.py:741-760; clip_seem_fusion.py:843-878): for
+ * marching-cubes vertices given in voxel-index coordinates, grid = (v + 0.5) * (1/nvox) * 2 - 1 and
+ * 3-D grid_sample(align_corners=False, zeros padding) of the volume:
+ *   out_feat [V,D] f32   trilinear sample of clip_feat (volume dtype f32 or bf16)
+ *   out_rgb  [V,3] f32   trilinear sample of rgb, clamped to [0,1]
+ *   out_obj  [V]   f32   nearest sample of obj_idx [N] i32            (optional pair, may be NULL)
+ *   out_seg  [V,3] f32   nearest sample of seg_color [N,3] f32, clamped (optional pair, may be NULL)
+ */
+int saf_sample_vertices(const saf_volume* vol, const float* verts_index, int64_t n_verts, float* out_feat,
+                        float* out_rgb, const int32_t* obj_idx, float* out_obj, const float* seg_color,
+                        float* out_seg, void* stream);
+
 /* Per-voxel argmax of the label histogram with the all-zero row -> -1 rule
  * (clip_seem_fusion.py:315-325).  out[N] i32. */
 int saf_label_argmax(const int32_t* labels_one_hot, int64_t n_voxels, int32_t n_classes,

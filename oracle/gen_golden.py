@@ -376,6 +376,52 @@ def gen_query(ref_cf, out_dir):
     print("query: run_query", tuple(rel.shape), "surgery", tuple(surgery.shape))
 
 
+def gen_extract_mesh(ref_cf, ref_csf, out_dir):
+    """The vertex-sampling half of extract_mesh (clipfusion.py:741-760, clip_seem_fusion.py:843-878): the
+    reference's own code runs, with skimage's marching cubes replaced by a stub that returns chosen
+    vertices (index-space coordinates, including points at and beyond the volume border) and faces."""
+    import skimage.measure as skm
+
+    g = torch.Generator().manual_seed(2468)
+    nvox = torch.tensor([12, 10, 14], dtype=torch.int32)
+    n, d = int(torch.prod(nvox)), 8
+    nv = 400
+    verts = (torch.rand(nv, 3, generator=g) * (nvox.float() + 1.0) - 1.0).numpy().astype(np.float32)
+    verts[:8] = np.array([[0, 0, 0], [11, 9, 13], [-0.5, 4, 4], [11.5, 9.5, 13.5], [5, -0.5, 7], [5.5, 4.5, 6.5],
+                          [0.25, 0.25, 0.25], [10.75, 8.75, 12.75]], dtype=np.float32)
+    faces = np.stack([np.arange(0, nv - 2), np.arange(1, nv - 1), np.arange(2, nv)], axis=1)
+    skm.marching_cubes = lambda vol, level=0: (verts.copy(), faces.copy(), None, None)
+    origin = torch.tensor([-0.7, -0.5, -0.9])
+    ref_cf.Clip.feature_dim = d
+    fusion = ref_cf.ClipFusion(origin, 0.1, nvox, 0.3, False, "stub", "stub", 10, 10)
+    fusion.n_clip_feats = d
+    fusion.clip_feat = torch.randn(n, d, generator=g)
+    fusion.rgb = torch.rand(n, 3, generator=g) * 1.2 - 0.1  # exercises the clamp(0, 1)
+    fusion.weight = (torch.rand(n, generator=g) > 0.2).int()
+    fusion.tsdf = torch.randn(n, generator=g)
+    verts_world, faces_out, vcol, vfeat = fusion.extract_mesh()
+
+    class FakeClip:
+        feature_dim = d
+
+    seem = ref_csf.ClipSeemFusion(origin, 0.1, nvox, 0.3, False, 10, 10, FakeClip(), None)
+    seem.clip_feat, seem.rgb, seem.weight, seem.tsdf = fusion.clip_feat, fusion.rgb, fusion.weight, fusion.tsdf
+    seem.voxel_obj_idx = torch.randint(0, 9, tuple(int(v) for v in nvox), generator=g)
+    seem.objects_segmentation_color = torch.rand(n, 3, generator=g)
+    out6 = seem.extract_mesh()
+    np.savez_compressed(
+        os.path.join(out_dir, "extract_mesh_sampling.npz"),
+        nvox=nvox.numpy(), origin=origin.numpy(), voxel_size=np.float64(0.1), verts_index=verts, faces=faces,
+        clip_feat=fusion.clip_feat.numpy(), rgb=fusion.rgb.numpy(),
+        voxel_obj_idx=seem.voxel_obj_idx.numpy().astype(np.int32),
+        objects_segmentation_color=seem.objects_segmentation_color.numpy(),
+        verts_world=verts_world, vertex_colors=vcol.numpy(), vertex_clip_feats=vfeat.numpy(),
+        seem_vertex_colors=out6[2].numpy(), seem_vertex_clip_feats=out6[3].numpy(),
+        seem_vertex_obj_idx=out6[4].numpy(), seem_vertex_segment_color=out6[5].numpy(),
+    )
+    print("extract_mesh sampling:", tuple(vfeat.shape), "good faces", len(faces_out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -390,6 +436,7 @@ def main():
     gen_backproject(ref_cf, args.out)
     gen_query(ref_cf, args.out)
     gen_fusion_c1(ref_cf, args.out)
+    gen_extract_mesh(ref_cf, ref_csf, args.out)
     with open(os.path.join(args.out, "README.md"), "w") as f:
         f.write(
             "Golden vectors produced by `oracle/gen_golden.py` from the reference's own Python\n"

@@ -47,6 +47,8 @@ def lib():
             fn = getattr(l, name)
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(_abi.SafVolume), C.c_int64, C.c_int64]
+        l.saf_oracle_sample_vertices.restype = C.c_int
+        l.saf_oracle_sample_vertices.argtypes = [C.POINTER(_abi.SafVolume), vp, C.c_int64, vp, vp, vp, vp, vp, vp]
         l.saf_oracle_set_threads.argtypes = [C.c_int]
         l.saf_oracle_get_threads.restype = C.c_int
         l.saf_oracle_label_argmax.restype = C.c_int
@@ -138,6 +140,23 @@ class OracleVolume:
     def mean_to_sum(self):
         vol = self.c_volume()
         assert lib().saf_oracle_mean_to_sum(C.byref(vol), 0, self.n) == 0
+
+
+def sample_vertices(vol, verts_index, obj_idx=None, seg_color=None):
+    """extract_mesh's vertex sampling on an OracleVolume; returns (feat[V,D], rgb[V,3], obj[V] | None, seg[V,3] | None)."""
+    verts = _f32(verts_index)
+    nv = verts.shape[0]
+    feat = torch.zeros(nv, vol.feat_dim)
+    rgb = torch.zeros(nv, 3)
+    oi = torch.as_tensor(obj_idx, dtype=torch.int32).contiguous() if obj_idx is not None else None
+    sc = _f32(seg_color) if seg_color is not None else None
+    oo = torch.zeros(nv) if oi is not None else None
+    so = torch.zeros(nv, 3) if sc is not None else None
+    c = vol.c_volume()
+    p = _abi.ptr
+    rc = lib().saf_oracle_sample_vertices(C.byref(c), p(verts), nv, p(feat), p(rgb), p(oi), p(oo), p(sc), p(so))
+    assert rc == 0
+    return feat, rgb, oo, so
 
 
 def backproject_lattice(depth, pose, kinv, u_idx, v_idx, max_depth):

@@ -443,3 +443,71 @@ int saf_oracle_label_argmax(const int32_t* labels, int64_t n_voxels, int32_t n_c
   }
   return SAF_OK;
 }
+
+/*
+ * Vertex sampling of extract_mesh (clipfusion.py:741-760; clip_seem_fusion.py:843-878):
+ * grid = (verts + 0.5) / nvox * 2 - 1 evaluated as (v + 0.5) * fl(1/n) (numpy array / int32 tensor goes
+ * through Tensor.__rtruediv__ = reciprocal * x), axes swapped to (z, y, x), then ATen's scalar 3-D
+ * grid sampler, align_corners=False, zeros padding: trilinear for clip_feat / rgb (clamped), nearest for
+ * the object index and the segmentation colour (clamped).
+ */
+typedef struct {
+  float f, w0, w1;
+  int i0;
+} axis3;
+static inline axis3 axis_setup(float v, int size) {
+  axis3 a;
+  float r = 1.0f / (float)size;
+  float g = (v + 0.5f) * r;
+  g = g * 2.0f;
+  g = g - 1.0f;
+  a.f = ((g + 1.0f) * (float)size - 1.0f) / 2.0f;
+  float fl = floorf(a.f);
+  a.i0 = (int)fl;
+  a.w0 = (fl + 1.0f) - a.f;
+  a.w1 = a.f - fl;
+  return a;
+}
+
+int saf_oracle_sample_vertices(const saf_volume* v, const float* verts, int64_t n_verts, float* out_feat,
+                               float* out_rgb, const int32_t* obj_idx, float* out_obj, const float* seg_color,
+                               float* out_seg) {
+  const int D = v->feat_dim;
+  for (int64_t t = 0; t < n_verts; ++t) {
+    axis3 ax = axis_setup(verts[t * 3 + 2], v->nz), ay = axis_setup(verts[t * 3 + 1], v->ny),
+          az = axis_setup(verts[t * 3 + 0], v->nx);
+    int64_t row[8];
+    float w[8];
+    for (int c = 0; c < 8; ++c) {
+      int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+      int x = ax.i0 + dx, y = ay.i0 + dy, z = az.i0 + dz;
+      int in = x >= 0 && x < v->nz && y >= 0 && y < v->ny && z >= 0 && z < v->nx;
+      row[c] = in ? ((int64_t)z * v->ny + y) * v->nz + x : -1;
+      w[c] = (dx ? ax.w1 : ax.w0) * (dy ? ay.w1 : ay.w0) * (dz ? az.w1 : az.w0);
+    }
+    for (int ch = 0; ch < D; ++ch) {
+      float acc = 0.0f;
+      for (int c = 0; c < 8; ++c)
+        if (row[c] >= 0) acc += feat_get(v, row[c] * D + ch) * w[c];
+      out_feat[t * D + ch] = acc;
+    }
+    for (int ch = 0; ch < 3; ++ch) {
+      float acc = 0.0f;
+      for (int c = 0; c < 8; ++c)
+        if (row[c] >= 0) acc += v->rgb[row[c] * 3 + ch] * w[c];
+      out_rgb[t * 3 + ch] = acc < 0.0f ? 0.0f : (acc > 1.0f ? 1.0f : acc);
+    }
+    if (obj_idx || seg_color) {
+      float xn = nearbyintf(ax.f), yn = nearbyintf(ay.f), zn = nearbyintf(az.f);
+      int in = xn >= 0.0f && xn < (float)v->nz && yn >= 0.0f && yn < (float)v->ny && zn >= 0.0f && zn < (float)v->nx;
+      int64_t n = in ? ((int64_t)zn * v->ny + (int64_t)yn) * v->nz + (int64_t)xn : -1;
+      if (obj_idx) out_obj[t] = n >= 0 ? (float)obj_idx[n] : 0.0f;
+      if (seg_color)
+        for (int ch = 0; ch < 3; ++ch) {
+          float s = n >= 0 ? seg_color[n * 3 + ch] : 0.0f;
+          out_seg[t * 3 + ch] = s < 0.0f ? 0.0f : (s > 1.0f ? 1.0f : s);
+        }
+    }
+  }
+  return SAF_OK;
+}

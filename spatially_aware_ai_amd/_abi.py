@@ -107,6 +107,7 @@ PROTOTYPES = {
     "saf_merge_finalize": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_mean_to_sum": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_label_argmax": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, _fp]),
+    "saf_sample_vertices": (C.c_int, [C.POINTER(SafVolume), _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
 }
 
 

@@ -62,6 +62,14 @@ class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
         label_maps = [self.segmentation_model.run_on_image(rgb_chw[i]).float() for i in range(len(rgb_imgs))]
         self._fuse(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, True)
 
+    def extract_mesh(self, marching_cubes=None):
+        """Reference clip_seem_fusion.py:824-888: the 6-tuple (verts_world, faces, vertex_colors,
+        vertex_clip_feats, vertex_obj_idx, vertex_segment_color); needs ``voxel_obj_idx`` and
+        ``objects_segmentation_color`` set by the caller as the manager does (:352-372)."""
+        verts, faces = self._marching_cubes_vertices(marching_cubes)
+        colors, feats, obj, seg = self.sample_mesh_vertices(verts, self.voxel_obj_idx, self.objects_segmentation_color)
+        return self._verts_world(verts), faces, colors, feats, obj, seg
+
     def label_index(self):
         """Per-voxel class id, -1 where nothing was fused: the manager's
         ``argmax_with_check_2d_efficient(labels_one_hot)`` (clip_seem_fusion.py:315-325)."""

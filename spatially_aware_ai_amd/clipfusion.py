@@ -166,11 +166,65 @@ class _FusionVolumeMixin:
             raise SafError(f"{s[4]} fuse workgroups timed out waiting for their frame's sweep; the volume is incomplete")
         return {"valid": s[0], "tsdf_valid": s[1], "frames": s[2], "labels_dropped": s[3]}
 
-    def extract_mesh(self):
-        raise NotImplementedError(
-            "extract_mesh (marching cubes + vertex sampling, reference clipfusion.py:723-763) is outside the "
-            "fused hot path built so far; see DESIGN.md 'next rows'"
-        )
+    def sample_mesh_vertices(self, verts_index, voxel_obj_idx=None, objects_segmentation_color=None):
+        """The sampling half of ``extract_mesh`` (reference clipfusion.py:741-760, clip_seem_fusion.py:843-878)
+        on the HIP device: marching-cubes vertices in voxel-index coordinates -> (vertex_colors[V,3] clamped,
+        vertex_clip_feats[V,D] f32[, vertex_obj_idx[V,1], vertex_segment_color[V,3]])."""
+        verts = torch.as_tensor(np.asarray(verts_index, dtype=np.float32)).to(self.tsdf.device).contiguous()
+        nv = verts.shape[0]
+        dev = self.tsdf.device
+        feat = torch.empty((nv, int(self.n_clip_feats)), dtype=torch.float32, device=dev)
+        rgb = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        oi = so = oo = sc = None
+        if voxel_obj_idx is not None:
+            oi = torch.as_tensor(voxel_obj_idx).to(device=dev, dtype=torch.int32).contiguous().reshape(-1)
+            oo = torch.empty(nv, dtype=torch.float32, device=dev)
+        if objects_segmentation_color is not None:
+            sc = self._f32c(torch.as_tensor(objects_segmentation_color).to(dev), "objects_segmentation_color")
+            so = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        vol = self._c_volume()
+        p = _abi.ptr
+        with torch.cuda.device(dev):
+            rc = lib().saf_sample_vertices(C.byref(vol), p(verts), nv, p(feat), p(rgb), p(oi), p(oo), p(sc), p(so),
+                                           current_stream_ptr())
+        check(rc, "saf_sample_vertices")
+        out = [rgb, feat]
+        if oo is not None:
+            out.append(oo[:, None])
+        if so is not None:
+            out.append(so)
+        return tuple(out)
+
+    def _marching_cubes_vertices(self, marching_cubes=None):
+        """TSDF -> (verts in index space, faces) as the reference does on the CPU (clipfusion.py:724-739):
+        un-fused voxels become NaN, faces touching NaN vertices are dropped, vertices re-indexed."""
+        if marching_cubes is None:
+            try:
+                import skimage.measure
+
+                marching_cubes = skimage.measure.marching_cubes
+            except ImportError as e:
+                raise ImportError(
+                    "extract_mesh needs scikit-image's marching_cubes (the reference's dependency) or a "
+                    "marching_cubes= callable with the same signature"
+                ) from e
+        tsdf = self.tsdf.masked_fill(self.weight == 0, torch.nan).cpu()
+        verts, faces = marching_cubes(tsdf.view(*[int(v) for v in self.nvox]).numpy(), level=0)[:2]
+        faces = faces[~np.isnan(verts[faces]).any(axis=(1, 2))]
+        used = np.zeros(len(verts), dtype=bool)
+        used[np.unique(faces)] = True
+        faces = (np.cumsum(used) - 1)[faces]
+        return verts[used], faces
+
+    def _verts_world(self, verts):
+        return verts * self.voxel_size + torch.as_tensor(self.origin).cpu().numpy()
+
+    def extract_mesh(self, marching_cubes=None):
+        """Reference clipfusion.py:723-763: (verts_world, faces, vertex_colors, vertex_clip_feats).  Marching
+        cubes stays on the CPU as in the reference; the vertex sampling of the D-channel volume runs in HIP."""
+        verts, faces = self._marching_cubes_vertices(marching_cubes)
+        colors, feats = self.sample_mesh_vertices(verts)[:2]
+        return self._verts_world(verts), faces, colors, feats
 
 
 # --------------------------------------------------------------------------------------------

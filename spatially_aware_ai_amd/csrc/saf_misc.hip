@@ -137,6 +137,90 @@ __global__ __launch_bounds__(256) void label_argmax_kernel(const int* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// extract_mesh's vertex sampling: 3-D grid_sample at marching-cubes vertices.
+// One wave per vertex: the 8 corner rows (D contiguous values each) are gathered with all lanes.
+// Arithmetic follows ATen's scalar 3-D grid sampler (grid_sampler_3d_cpu_impl): un-normalise
+// ((g + 1) * size - 1) / 2, corner weights as products of distances to the opposite corner,
+// corners summed in the order tnw, tne, tsw, tse, bnw, bne, bsw, bse, out-of-volume corners skipped.
+// ------------------------------------------------------------------------------------------
+struct Axis3 {
+  float g;   // normalised grid coordinate
+  float f;   // un-normalised source index
+  int i0;    // floor
+  float w0, w1;  // weights of corner i0 and i0 + 1
+};
+__device__ __forceinline__ Axis3 axis_setup(float v_index, int size) {
+  Axis3 a;
+  // grid = (verts + 0.5) / nvox * 2 - 1 : numpy f32 + 0.5, then Tensor.__rtruediv__ = reciprocal(nvox) * x
+  const float r = 1.0f / (float)size;
+  float g = (v_index + 0.5f) * r;
+  g = g * 2.0f;
+  g = g - 1.0f;
+  a.g = g;
+  a.f = ((g + 1.0f) * (float)size - 1.0f) / 2.0f;
+  const float fl = __builtin_floorf(a.f);
+  a.i0 = (int)fl;
+  a.w0 = (fl + 1.0f) - a.f;  // distance to the far corner  (ix_bse - ix)
+  a.w1 = a.f - fl;           // distance to the near corner (ix - ix_tnw)
+  return a;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void sample_vertices_kernel(
+    int nx, int ny, int nz, int D, const void* __restrict__ feat, const float* __restrict__ rgb,
+    const float* __restrict__ verts, int64_t n_verts, float* __restrict__ out_feat, float* __restrict__ out_rgb,
+    const int* __restrict__ obj_idx, float* __restrict__ out_obj, const float* __restrict__ seg_color,
+    float* __restrict__ out_seg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t vtx = wave; vtx < n_verts; vtx += n_waves) {
+    // the reference swaps the grid to (z, y, x) order because grid_sample's x runs along the LAST
+    // volume axis (clipfusion.py:742): axis X of the sampler = nz, Y = ny, Z = nx.
+    const Axis3 ax = axis_setup(verts[vtx * 3 + 2], nz);
+    const Axis3 ay = axis_setup(verts[vtx * 3 + 1], ny);
+    const Axis3 az = axis_setup(verts[vtx * 3 + 0], nx);
+    int64_t row[8];
+    float w[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {  // c = (dz << 2) | (dy << 1) | dx : tnw, tne, tsw, tse, bnw, ...
+      const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+      const int x = ax.i0 + dx, y = ay.i0 + dy, z = az.i0 + dz;  // x along nz, y along ny, z along nx
+      const bool in = x >= 0 && x < nz && y >= 0 && y < ny && z >= 0 && z < nx;
+      row[c] = in ? ((int64_t)z * ny + y) * nz + x : -1;
+      w[c] = (dx ? ax.w1 : ax.w0) * (dy ? ay.w1 : ay.w0) * (dz ? az.w1 : az.w0);
+    }
+    for (int ch = lane; ch < D; ch += 64) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (row[c] >= 0) {
+          const float val = BF16 ? __builtin_bit_cast(float, (uint32_t) static_cast<const uint16_t*>(feat)[row[c] * D + ch] << 16)
+                                 : static_cast<const float*>(feat)[row[c] * D + ch];
+          acc += val * w[c];
+        }
+      }
+      out_feat[vtx * D + ch] = acc;
+    }
+    if (lane < 3) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (row[c] >= 0) acc += rgb[row[c] * 3 + lane] * w[c];
+      out_rgb[vtx * 3 + lane] = fminf(fmaxf(acc, 0.0f), 1.0f);  // .clamp(0, 1)
+    }
+    if (obj_idx || seg_color) {
+      // mode="nearest": nearbyint of the un-normalised index, zeros outside
+      const float xn = __builtin_rintf(ax.f), yn = __builtin_rintf(ay.f), zn = __builtin_rintf(az.f);
+      const bool in = xn >= 0.0f && xn < (float)nz && yn >= 0.0f && yn < (float)ny && zn >= 0.0f && zn < (float)nx;
+      const int64_t n = in ? ((int64_t)zn * ny + (int64_t)yn) * nz + (int64_t)xn : -1;
+      if (obj_idx && lane == 0) out_obj[vtx] = n >= 0 ? (float)obj_idx[n] : 0.0f;
+      if (seg_color && lane < 3) out_seg[vtx * 3 + lane] = n >= 0 ? fminf(fmaxf(seg_color[n * 3 + lane], 0.0f), 1.0f) : 0.0f;
+    }
+  }
+}
+
 }  // namespace
 }  // namespace saf
 
@@ -161,6 +245,30 @@ int saf_merge_finalize(const saf_volume* vol, int64_t first_voxel, int64_t count
 
 int saf_mean_to_sum(const saf_volume* vol, int64_t first_voxel, int64_t count, void* stream) {
   return scale_volume<false>(vol, first_voxel, count, static_cast<hipStream_t>(stream));
+}
+
+int saf_sample_vertices(const saf_volume* vol, const float* verts_index, int64_t n_verts, float* out_feat,
+                        float* out_rgb, const int32_t* obj_idx, float* out_obj, const float* seg_color, float* out_seg,
+                        void* stream) {
+  if (!vol || !vol->clip_feat || !vol->rgb || !verts_index || !out_feat || !out_rgb || n_verts < 0 ||
+      (obj_idx && !out_obj) || (seg_color && !out_seg))
+    return fail(SAF_E_INVALID, "sample_vertices: bad arguments");
+  if (vol->feat_dtype != SAF_F32 && vol->feat_dtype != SAF_BF16)
+    return fail(SAF_E_UNSUPPORTED, "sample_vertices: feature dtype %d", vol->feat_dtype);
+  if (n_verts == 0) return SAF_OK;
+  int64_t blocks = (n_verts + 3) / 4;
+  const int64_t cap = (int64_t)device_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vol->feat_dtype == SAF_BF16)
+    hipLaunchKernelGGL(sample_vertices_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, vol->nx, vol->ny, vol->nz,
+                       vol->feat_dim, vol->clip_feat, vol->rgb, verts_index, n_verts, out_feat, out_rgb, obj_idx, out_obj,
+                       seg_color, out_seg);
+  else
+    hipLaunchKernelGGL(sample_vertices_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, vol->nx, vol->ny, vol->nz,
+                       vol->feat_dim, vol->clip_feat, vol->rgb, verts_index, n_verts, out_feat, out_rgb, obj_idx, out_obj,
+                       seg_color, out_seg);
+  return check_launch("sample_vertices_kernel");
 }
 
 int saf_label_argmax(const int32_t* labels_one_hot, int64_t n_vox, int32_t n_classes, int32_t* out, void* stream) {

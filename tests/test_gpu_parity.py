@@ -325,6 +325,37 @@ def test_wide_query_scan_16bit_mfma(oracle, dt, dim, out_dt):
     np.testing.assert_allclose(sc.numpy(), text.to(dt).float()[:, ks].T.numpy(), rtol=0, atol=1e-6)
 
 
+def test_extract_mesh_vertex_sampling_golden(golden_dir):
+    """extract_mesh end to end with an injected marching-cubes function, against the reference's output."""
+    from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
+
+    g = np.load(os.path.join(golden_dir, "extract_mesh_sampling.npz"))
+    d = g["clip_feat"].shape[1]
+    nvox = torch.from_numpy(g["nvox"])
+    mc = lambda vol, level=0: (g["verts_index"].copy(), g["faces"].copy(), None, None)
+    for seem in (False, True):
+        if seem:
+            fz = ClipSeemFusion(torch.from_numpy(g["origin"]), float(g["voxel_size"]), nvox, 0.3, False, 10, 10,
+                                FakeClip(d), FakeSeg()).cuda()
+            fz.voxel_obj_idx = torch.from_numpy(g["voxel_obj_idx"]).cuda()
+            fz.objects_segmentation_color = torch.from_numpy(g["objects_segmentation_color"]).cuda()
+        else:
+            fz = ClipFusion(torch.from_numpy(g["origin"]), float(g["voxel_size"]), nvox, 0.3, False, FakeClip(d), None,
+                            10, 10).cuda()
+        fz.clip_feat.copy_(torch.from_numpy(g["clip_feat"]))
+        fz.rgb.copy_(torch.from_numpy(g["rgb"]))
+        fz.weight.fill_(1)
+        out = fz.extract_mesh(marching_cubes=mc)
+        np.testing.assert_allclose(out[0], g["verts_world"], rtol=1e-6, atol=1e-6)
+        assert np.array_equal(out[1], g["faces"])
+        np.testing.assert_allclose(out[2].cpu().numpy(), g["vertex_colors"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(out[3].cpu().numpy(), g["vertex_clip_feats"], rtol=1e-4, atol=2e-6)
+        if seem:
+            assert len(out) == 6
+            assert np.array_equal(out[4].cpu().numpy(), g["seem_vertex_obj_idx"])
+            np.testing.assert_allclose(out[5].cpu().numpy(), g["seem_vertex_segment_color"], rtol=0, atol=1e-7)
+
+
 def test_sum_mode_and_finalize(oracle):
     """SAF_SUM accumulation + saf_merge_finalize == running mean, and mean_to_sum
     is its inverse."""

@@ -180,3 +180,20 @@ def test_query_scan(oracle, golden_dir):
     # redundant_feats branch = plain scores against (T - r)  (clipfusion.py:908-909)
     sc = oracle.query_scan(g["feats_normed"], g["text7"] - g["redundant"], _abi.SAF_Q_SCORES)
     np.testing.assert_allclose(sc.numpy(), g["surgery_redundant"][0], rtol=1e-4, atol=2e-6)
+
+
+def test_extract_mesh_vertex_sampling(oracle, golden_dir):
+    """The sampling half of extract_mesh against the reference's own extract_mesh (marching cubes stubbed
+    to return chosen vertices, including ones on and outside the volume border)."""
+    g = _load(golden_dir, "extract_mesh_sampling.npz")
+    d = g["clip_feat"].shape[1]
+    vol = oracle.OracleVolume(g["origin"], float(g["voxel_size"]), g["nvox"], 0.3, d)
+    vol.clip_feat.copy_(torch.from_numpy(g["clip_feat"]))
+    vol.rgb.copy_(torch.from_numpy(g["rgb"]))
+    feat, rgb, obj, seg = oracle.sample_vertices(vol, g["verts_index"], g["voxel_obj_idx"].reshape(-1),
+                                                 g["objects_segmentation_color"])
+    np.testing.assert_allclose(feat.numpy(), g["vertex_clip_feats"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(rgb.numpy(), g["vertex_colors"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(feat.numpy(), g["seem_vertex_clip_feats"], rtol=1e-4, atol=2e-6)
+    assert np.array_equal(obj.numpy()[:, None], g["seem_vertex_obj_idx"])
+    np.testing.assert_allclose(seg.numpy(), g["seem_vertex_segment_color"], rtol=0, atol=1e-7)
