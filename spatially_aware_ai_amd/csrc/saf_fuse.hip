@@ -1,21 +1,23 @@
-// saf_fuse.hip -- projective voxel fusion of one RGB-D frame on gfx950 (MI355X).
+// saf_fuse.hip -- projective voxel fusion of RGB-D frames on gfx950 (MI355X).
 //
 // Replaces ClipFusion.integrate / ClipSeemFusion.integrate after the backbone calls
-// (reference clipfusion.py:647-721, clip_seem_fusion.py:697-822).  Three launches per frame:
+// (reference clipfusion.py:647-721, clip_seem_fusion.py:697-822).  Two launches per frame:
 //
-//   prep   : re-lays the frame's feature map [D,npy,npx] -> [npy*npx][D] (so a voxel's D-vector
-//            of one tap is contiguous) and zeroes the compact-list counters.
-//   sweep  : one pass over ALL voxels (a2-a4): project the voxel centre, nearest-pixel depth
-//            test, TSDF running mean for tsdf_valid voxels, and wave-ballot + LDS compaction of
-//            the `valid` voxels of a 4096-voxel chunk into one of 16 compact lists (one global
-//            atomic per block).  Compute-bound; no volume row is touched here.
-//   fuse   : (a5-a7) workgroups stage the re-laid feature map in LDS (71,680 B for 512x5x7) and
-//            walk the compact lists; a group of G lanes owns one voxel row: 4-tap bilinear
-//            sample from LDS, running-mean read-modify-write of the D-row with 16-byte accesses
-//            per lane, several rows in flight per wave; rgb / weight / label counter ride along.
-//            HBM-bound: algorithmic bytes = Nv * (2*D*4 + 32 [+8]) per frame.
+//   sweep  : one pass over ALL voxels (rows a2-a4 of SURVEY.md §8): project the voxel centre,
+//            nearest-pixel depth test, TSDF running mean for tsdf_valid voxels (16-byte runs of 4
+//            consecutive voxels), wave-ballot + LDS compaction of the `valid` voxels of a 4096-voxel
+//            chunk into one of 16 compact lists (one global atomic per block), write-through
+//            publication of the lists + a completion counter.  VALU-bound; no feature row is touched.
+//   fuse   : (a5-a7) workgroups stage the frame's feature map into LDS as a conflict-free image and
+//            walk the compact lists; a group of G lanes owns one voxel row: 4-tap bilinear sample
+//            from LDS, running-mean read-modify-write of the D-row with 16-byte non-temporal
+//            accesses, R rows in flight per group; rgb / weight / label counter are done
+//            lane-parallel, once per voxel.  HBM-bound: Nv * (2*D*s + 36 [+8]) bytes per frame.
 //
-// All arithmetic that selects voxels is shared with the oracle's restatement via saf_common.h.
+// saf_fuse_frames pipelines the two over frames: sweeps run ahead on an auxiliary stream, fuse
+// kernels back to back on the caller's stream, sweep(i) -> fuse(i) through a device-side counter
+// (DESIGN.md §4).  All arithmetic that selects voxels is shared with the oracle's restatement in
+// spirit and checked bit-for-bit against it (saf_common.h).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -379,8 +381,6 @@ __device__ __forceinline__ float4 blend(float4 s, float4 old, float a, float b, 
 __device__ __forceinline__ float blend(float s, float old, float a, float b, bool sum) {
   return sum ? old + s : s * a + old * b;
 }
-__device__ __forceinline__ float4 vzero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ float vzero(float) { return 0.f; }
 
 struct Taps {
   int o_nw, o_ne, o_sw, o_se;  // tap positions in [0, P]; P = the zero column (outside the map)
