@@ -88,7 +88,7 @@ def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device):
     if depth_kind == "A":
         depth = torch.rand((n, height, width), generator=g, device=device) * 2.0 + 1.5
     else:
-        depth = torch.stack([syn._analytic_depth(p.cpu(), k.cpu(), width, height) for p, k in zip(poses, ks)]).to(device)
+        depth = torch.stack([syn._analytic_depth(p, k, width, height) for p, k in zip(poses, ks)])
     rgb = torch.rand((n, height, width, 3), generator=g, device=device)
     feat = torch.randn((n, dim, npy, npx), generator=g, device=device)
     return depth, rgb, poses, ks, feat

@@ -74,9 +74,11 @@ def intrinsics(width: int, height: int) -> torch.Tensor:
 
 
 def _analytic_depth(pose: torch.Tensor, k: torch.Tensor, width: int, height: int) -> torch.Tensor:
-    """Depth (camera z) of a sphere r=0.9 m inside an axis-aligned box of half-size 1.2 m."""
-    u = torch.arange(width, dtype=torch.float64)
-    v = torch.arange(height, dtype=torch.float64)
+    """Depth (camera z) of a sphere r=0.9 m inside an axis-aligned box of half-size 1.2 m.  Works on
+    whatever device ``pose`` lives on (the benchmark generates its frames on the GPU)."""
+    dev = pose.device
+    u = torch.arange(width, dtype=torch.float64, device=dev)
+    v = torch.arange(height, dtype=torch.float64, device=dev)
     vv, uu = torch.meshgrid(v, u, indexing="ij")
     kd = k.double()
     rays_cam = torch.stack(
@@ -90,8 +92,9 @@ def _analytic_depth(pose: torch.Tensor, k: torch.Tensor, width: int, height: int
     b = 2 * (d @ o)
     c = (o @ o) - 0.9**2
     disc = b * b - 4 * a * c
-    s_sphere = torch.where(disc > 0, (-b - disc.clamp_min(0).sqrt()) / (2 * a), torch.full_like(a, math.inf))
-    s_sphere = torch.where(s_sphere > 0, s_sphere, torch.full_like(a, math.inf))
+    inf = torch.full_like(a, math.inf)
+    s_sphere = torch.where(disc > 0, (-b - disc.clamp_min(0).sqrt()) / (2 * a), inf)
+    s_sphere = torch.where(s_sphere > 0, s_sphere, inf)
     # box exit (camera is outside the box: take the far faces, i.e. the inside of the room)
     half = 1.2
     inv = 1.0 / d
