@@ -359,7 +359,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "fused RGB-D frames/sec into voxel grid",
+            "metric": f"fused RGB-D frames/sec into {a.grid}^3x{a.dim} voxel grid",
             "value": round(value, 2),
             "unit": "frames/s",
             "n_gpus": world,
