@@ -13,7 +13,8 @@ import threading
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsaf_hip.so")
+# SAF_LIB_PATH selects another build of the same ABI (same-box A/B measurements of two kernel versions)
+LIB_PATH = os.environ.get("SAF_LIB_PATH") or os.path.join(_HERE, "libsaf_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None

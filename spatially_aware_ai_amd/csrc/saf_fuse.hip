@@ -199,6 +199,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(KVol v, KFrame f,
   int bx, by, bz;
   voxel_coords(v, chunk_base < v.N ? chunk_base : 0u, bx, by, bz);
   const SmallDiv dz{1.0f / (float)v.nz, (uint32_t)v.nz}, dy{1.0f / (float)v.ny, (uint32_t)v.ny};
+  const float rtrunc = 1.0f / v.trunc;
   const bool aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
   uint32_t nt_local = 0;
   for (int g = 0; g < kRunsPerThread; ++g) {
@@ -238,7 +239,10 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(KVol v, KFrame f,
     bool any_tv = false;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
-      sdf[j] = (depth[j] - p[j].z) / v.trunc;
+      // (depth - z) / trunc: exact fast division; a = +inf (infinite depth reading) must stay +inf so
+      // that the voxel counts as in front of the surface, NaN / -inf fail both tests either way
+      const float num = depth[j] - p[j].z;
+      sdf[j] = num == INFINITY ? INFINITY : div_by_uniform(num, v.trunc, rtrunc);
       valid[j] = in_view[j] && fabsf(sdf[j]) <= 1.0f;
       tv[j] = in_view[j] && sdf[j] > -1.0f;
       any_tv |= tv[j];
@@ -270,10 +274,10 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(KVol v, KFrame f,
           if (v.accum == SAF_SUM) {
             told[j] = told[j] + t;
           } else {
-            // batch_tsdf / new_weight + tsdf * (tsdf_weight / new_weight)
-            const float a = (float)w1;
-            const float b = (float)w0[j] / (float)w1;
-            told[j] = t / a + told[j] * b;
+            // batch_tsdf / new_weight + tsdf * (tsdf_weight / new_weight).  The TSDF is a VALUE
+            // (compared at 1e-4), not an index: both quotients use the hardware reciprocal (1 ulp).
+            const float rw = __builtin_amdgcn_rcpf((float)w1);
+            told[j] = t * rw + told[j] * ((float)w0[j] * rw);
           }
           w0[j] = w1;
           ++nt_local;
