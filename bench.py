@@ -254,32 +254,56 @@ def main():
         n_launch = max(1, ms["fuse"][1])
         nv_per = st["valid"] / max(1, st["frames"])
         nt_per = st["tsdf_valid"] / max(1, st["frames"])
-        # B_fuse = Nv*(2*D*4 + 2*12 + 2*4) + Nt*16 + H*W*16 + D*npy*npx*4 per frame.
-        # The fuse kernel's share: rows + rgb + weight RMW + its read of the re-laid feature map and
-        # of the compact list; the Nt*16 TSDF term and the depth image belong to the sweep kernel.
         lab = 8 if a.labels else 0  # one label counter RMW per valid voxel
-        fuse_bytes = nv_per * (2 * a.dim * esz + 2 * 12 + 2 * 4 + 4 + lab) + a.dim * npy * npx * 4
-        sweep_bytes = nt_per * 16 + a.height * a.width * 4 + nv_per * 4
-        frame_bytes = (nv_per * (2 * a.dim * esz + 32 + lab) + nt_per * 16 + a.height * a.width * (16 + (4 if a.labels else 0))
-                       + a.dim * npy * npx * 4)
+        windowed = st.get("window_rows", 0) > 0
+        if windowed:
+            # SURVEY.md §8d, one launch covering a frame set S (a window of up to 32 frames):
+            # B_fuse(S) = U_v*(2*D*s + 2*12 + 2*4 [+2*4]) + U_t*(2*4 + 2*4) + sum_f (H*W*(4+12[+4]) + D*npy*npx*4)
+            # with U_v = rows the window read-modify-wrote, U_t = voxels whose TSDF it updated (kernel counters).
+            # The window kernel does the classification sweep itself, so the whole term is its own.
+            n_windows = (a.frames + 31) // 32 * a.steps
+            uv = st["window_rows"] / n_windows
+            ut = st["window_tsdf_voxels"] / n_windows
+            fpl = a.frames * a.steps / n_windows  # frames per launch
+            fuse_bytes = (uv * (2 * a.dim * esz + 2 * 12 + 2 * 4 + lab) + ut * 16
+                          + fpl * (a.height * a.width * (16 + (4 if a.labels else 0)) + a.dim * npy * npx * 4))
+            sweep_bytes = 0
+            frame_bytes = fuse_bytes / fpl
+        else:
+            # B_fuse = Nv*(2*D*4 + 2*12 + 2*4) + Nt*16 + H*W*16 + D*npy*npx*4 per frame.
+            # The fuse kernel's share: rows + rgb + weight RMW + its read of the re-laid feature map and
+            # of the compact list; the Nt*16 TSDF term and the depth image belong to the sweep kernel.
+            fuse_bytes = nv_per * (2 * a.dim * esz + 2 * 12 + 2 * 4 + 4 + lab) + a.dim * npy * npx * 4
+            sweep_bytes = nt_per * 16 + a.height * a.width * 4 + nv_per * 4
+            frame_bytes = (nv_per * (2 * a.dim * esz + 32 + lab) + nt_per * 16 + a.height * a.width * (16 + (4 if a.labels else 0))
+                           + a.dim * npy * npx * 4)
         avg_fuse_s = ms["fuse"][0] / n_launch * 1e-3
         achieved = fuse_bytes / avg_fuse_s / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01", "fuse_traffic.json")
+        kname = "fuse_window_kernel" if windowed else "fuse_kernel"
+        tpath = os.path.join(ROOT, "profiles", "r01", "window_traffic.json" if windowed else "fuse_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("grid") == a.grid and tj.get("dim") == a.dim:
+                if (tj.get("grid") == a.grid and tj.get("dim") == a.dim and tj.get("depth_kind", "A") == a.depth_kind
+                        and tj.get("frames_per_launch", 1) == (32 if windowed else 1)):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {
-            "kernel": "fuse_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(fuse_bytes), "avg_launch_us": round(avg_fuse_s * 1e6, 2),
             "launches": int(n_launch), "valid_voxels_per_frame": round(nv_per, 1),
             "tsdf_voxels_per_frame": round(nt_per, 1),
         }
+        if windowed:
+            roofline["frames_per_launch"] = round(fpl, 1)
+            roofline["rows_per_launch"] = round(uv, 1)
+            roofline["tsdf_voxels_per_launch"] = round(ut, 1)
+            roofline["hits_per_row"] = round(st["valid"] / max(1, st["window_rows"]), 3)
+            roofline["note"] = ("voxel-major window kernel: classifies the window's frames, updates the TSDF and reads/"
+                                "writes every touched feature row once per window; bit-identical to frame-by-frame fusion")
         breakdown = {
             "prep_us": round(ms["prep"][0] / max(1, ms["prep"][1]) * 1e3, 2),
             "sweep_us": round(ms["sweep"][0] / max(1, ms["sweep"][1]) * 1e3, 2),
@@ -290,7 +314,7 @@ def main():
         }
 
     # ---- the same kernel timed alone (one frame per call = no sweep running beside it) ----
-    if roofline is not None and rank == 0:
+    if roofline is not None and rank == 0 and not windowed:
         n_iso = min(32, a.frames)
         prof2 = L.saf_profiler_create(3 * n_iso)
         torch.cuda.synchronize()

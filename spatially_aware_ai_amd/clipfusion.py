@@ -164,7 +164,8 @@ class _FusionVolumeMixin:
         s = self.fuse_stats.cpu().tolist()
         if s[4]:
             raise SafError(f"{s[4]} fuse workgroups timed out waiting for their frame's sweep; the volume is incomplete")
-        return {"valid": s[0], "tsdf_valid": s[1], "frames": s[2], "labels_dropped": s[3]}
+        return {"valid": s[0], "tsdf_valid": s[1], "frames": s[2], "labels_dropped": s[3], "window_rows": s[5],
+                "window_tsdf_voxels": s[6]}
 
     def sample_mesh_vertices(self, verts_index, voxel_obj_idx=None, objects_segmentation_color=None):
         """The sampling half of ``extract_mesh`` (reference clipfusion.py:741-760, clip_seem_fusion.py:843-878)

@@ -356,6 +356,64 @@ def test_extract_mesh_vertex_sampling_golden(golden_dir):
             np.testing.assert_allclose(out[5].cpu().numpy(), g["seem_vertex_segment_color"], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("dim,seem,accum,n_frames", [(512, True, _abi.SAF_RUNNING_MEAN, 40), (256, False, _abi.SAF_RUNNING_MEAN, 33),
+                                                     (768, False, _abi.SAF_SUM, 19), (1024, True, _abi.SAF_RUNNING_MEAN, 15)])
+def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_frames):
+    """saf_fuse_frames with >= 16 frames of a 256-multiple feature dim takes the windowed voxel-major path
+    (one kernel per window of 32 frames: classification, TSDF, and one row read + write per touched voxel,
+    hits applied in frame order).  It must reproduce the frame-by-frame path BIT FOR BIT on every buffer,
+    and agree with the oracle."""
+    from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
+
+    w, h = 64, 48
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid((33, 30, 41))
+    frames = syn.make_frames(909, n_frames, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="B",
+                             missing_depth_frac=0.05)
+    # the same camera twice in a row and a camera inside the grid: voxels hit by several frames of a window
+    frames[3] = dict(frames[2])
+    # non-finite and negative depth readings (inf counts as "in front of the surface", nan / -inf fail both tests)
+    d5 = frames[5]["depth"].clone()
+    d5[0, 3:9, 5:25] = float("inf")
+    d5[0, 12:15, 5:25] = float("nan")
+    d5[0, 20:23, 5:25] = -1.0
+    d5[0, 30:33, 5:25] = float("-inf")
+    frames[5] = dict(frames[5], depth=d5)
+    frames += syn.make_frames(910, 1, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="A", radius=0.6)
+
+    def build():
+        clip, seg = FakeClip(dim), FakeSeg()
+        if seem:
+            fz = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, 10, 10, clip, seg,
+                                keep_xyz_world=False).cuda()
+        else:
+            fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, 10, 10,
+                            keep_xyz_world=False).cuda()
+        fz.accum_mode = accum
+        return fz
+
+    cat = lambda k, fs: torch.cat([f[k] for f in fs]).cuda()
+    labs = lambda fs: [f["labels"].float().cuda() for f in fs] if seem else None
+    one = build()
+    for f in frames:  # frame by frame: the sequential path
+        one.integrate_features(cat("depth", [f]), cat("rgb", [f]), cat("pose", [f]), cat("K", [f]), cat("feat", [f]), labs([f]))
+    win = build()  # one call: windows of 32 frames
+    win.integrate_features(cat("depth", frames), cat("rgb", frames), cat("pose", frames), cat("K", frames),
+                           cat("feat", frames), labs(frames))
+    for name in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat") + (("labels_one_hot",) if seem else ()):
+        assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs between the two paths"
+    s1, s2 = one.stats(), win.stats()
+    assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0
+    assert s1.pop("window_tsdf_voxels") == 0 and s2.pop("window_tsdf_voxels") > 0
+    assert s1 == s2, (s1, s2)
+    assert int(win.fuse_stats[5]) > 0, "the windowed kernel did not run"
+    assert int(win.fuse_stats[5]) < s2["valid"], "no voxel was hit twice inside a window: the test is too weak"
+    vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, dim, 143 if seem else 0, accum)
+    vol.integrate(cat("depth", frames).cpu(), cat("rgb", frames).cpu(), cat("pose", frames).cpu(), cat("K", frames).cpu(),
+                  cat("feat", frames).cpu(), [l.cpu() for l in labs(frames)] if seem else None, rgb_bilinear=seem)
+    _assert_same(vol, win, seem)
+
+
 def test_sum_mode_and_finalize(oracle):
     """SAF_SUM accumulation + saf_merge_finalize == running mean, and mean_to_sum
     is its inverse."""
