@@ -257,18 +257,19 @@ def main():
         lab = 8 if a.labels else 0  # one label counter RMW per valid voxel
         windowed = st.get("window_rows", 0) > 0
         if windowed:
-            # SURVEY.md §8d, one launch covering a frame set S (a window of up to 32 frames):
+            # SURVEY.md §8d, launches covering a frame set S (a window of up to 32 frames):
             # B_fuse(S) = U_v*(2*D*s + 2*12 + 2*4 [+2*4]) + U_t*(2*4 + 2*4) + sum_f (H*W*(4+12[+4]) + D*npy*npx*4)
             # with U_v = rows the window read-modify-wrote, U_t = voxels whose TSDF it updated (kernel counters).
-            # The window kernel does the classification sweep itself, so the whole term is its own.
+            # fuse_window_kernel's share: the rows, rgb / weight / label side, rgb + label images and the maps;
+            # classify_window_kernel's share: the TSDF term and the depth images.
             n_windows = (a.frames + 31) // 32 * a.steps
             uv = st["window_rows"] / n_windows
             ut = st["window_tsdf_voxels"] / n_windows
             fpl = a.frames * a.steps / n_windows  # frames per launch
-            fuse_bytes = (uv * (2 * a.dim * esz + 2 * 12 + 2 * 4 + lab) + ut * 16
-                          + fpl * (a.height * a.width * (16 + (4 if a.labels else 0)) + a.dim * npy * npx * 4))
-            sweep_bytes = 0
-            frame_bytes = fuse_bytes / fpl
+            fuse_bytes = (uv * (2 * a.dim * esz + 2 * 12 + 2 * 4 + lab)
+                          + fpl * (a.height * a.width * (12 + (4 if a.labels else 0)) + a.dim * npy * npx * 4))
+            sweep_bytes = ut * 16 + fpl * a.height * a.width * 4
+            frame_bytes = (fuse_bytes + sweep_bytes) / fpl
         else:
             # B_fuse = Nv*(2*D*4 + 2*12 + 2*4) + Nt*16 + H*W*16 + D*npy*npx*4 per frame.
             # The fuse kernel's share: rows + rgb + weight RMW + its read of the re-laid feature map and
@@ -302,8 +303,9 @@ def main():
             roofline["rows_per_launch"] = round(uv, 1)
             roofline["tsdf_voxels_per_launch"] = round(ut, 1)
             roofline["hits_per_row"] = round(st["valid"] / max(1, st["window_rows"]), 3)
-            roofline["note"] = ("voxel-major window kernel: classifies the window's frames, updates the TSDF and reads/"
-                                "writes every touched feature row once per window; bit-identical to frame-by-frame fusion")
+            roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of 32 "
+                                "frames (hits applied in frame order: bit-identical to frame-by-frame fusion); the window's "
+                                "classification + TSDF run in classify_window_kernel (kernel_breakdown.sweep_us, per window)")
         breakdown = {
             "prep_us": round(ms["prep"][0] / max(1, ms["prep"][1]) * 1e3, 2),
             "sweep_us": round(ms["sweep"][0] / max(1, ms["sweep"][1]) * 1e3, 2),

@@ -897,14 +897,19 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
 // ------------------------------------------------------------------------------------------
 // fuse, voxel-major over a WINDOW of up to 32 frames (saf_fuse_frames with many frames).
 //
-// A running mean is applied hit by hit, but nothing forces a row to travel to HBM between two hits:
-// the windowed sweeps leave a per-voxel frame bitmask; here every touched voxel's D-row is read ONCE,
-// the voxel's hits are applied in frame order -- the same s*a + old*b with a = 1/(w+1), so the result
-// is bit-identical to fusing the frames one after the other -- and written ONCE.  Row bytes fall by the
-// window's hits-per-voxel ratio (1.4 for incoherent depth, 4+ for a coherent scene).
+// A running mean is applied hit by hit, but nothing forces a row to travel to HBM between two hits.
+// Two kernels per window:
+//   classify_window_kernel  every voxel against every frame of the window (the full-grid sweep of
+//                           clipfusion.py:647-695 for 32 frames at once): TSDF running mean kept in registers
+//                           across the frames and written once, per-voxel frame bitmask out;
+//   fuse_window_kernel      every touched voxel's D-row is read ONCE, the voxel's hits are applied in frame
+//                           order -- the same s*a + old*b with a = 1/(w+1), so the result is bit-identical to
+//                           fusing the frames one after the other -- and written ONCE.  Row bytes fall by the
+//                           window's hits-per-voxel ratio (1.4 for incoherent depth, 4+ for a coherent scene).
 //
-// Waves work independently (no workgroup barrier after the prologue).  A wave takes pieces of 256
-// consecutive voxels, compacts the touched ones, and per chunk of <= 64 touched voxels (<= kHitCap hits):
+// fuse_window_kernel: waves work independently (no workgroup barrier after the prologue).  A wave takes
+// pieces of 256 consecutive voxels, compacts the touched ones, and per chunk of <= 64 touched voxels
+// (<= kHitCap hits):
 //   lane-parallel over HITS  : projection, a, b, the map cell of the hit (staged in LDS);
 //   lane-parallel over VOXELS: rgb / weight / label side, hit by hit;
 //   rows, in sub-chunks of SR rows (<= 64 hits): the rows are brought into LDS by LDS-DMA, the hits are
@@ -979,6 +984,159 @@ struct WinCfg {
   static constexpr size_t total = cam_off + (size_t)kWin * sizeof(Cam);
 };
 
+// Classification of one piece (256 consecutive voxels, a lane owns 4 of them) against every frame of a
+// window (clipfusion.py:647-679): the voxels' TSDF running mean is kept in registers across the frames
+// (clipfusion.py:681-695 with B = 1, frame after frame -- order dependent) and written once; mk4[j] collects
+// the frame bitmask of voxel j.  KFU frames at a time: their depth gathers are in flight together.
+template <int KFU, bool SUM>
+__device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa, const Cam* __restrict__ s_cam,
+                                               uint32_t piece_base, int lane, float rtrunc, bool tsdf_aligned,
+                                               uint32_t (&mk4)[4], unsigned long long& nt_done,
+                                               unsigned long long& tsdf_rows_done) {
+  const uint32_t nb = piece_base + (uint32_t)lane * 4u;
+  float xw[4], yw[4], zw[4], told[4];
+  int tw[4];
+  bool inb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    inb[j] = nb + j < v.N;
+    int ix, iy, iz;
+    voxel_coords(v, inb[j] ? nb + j : 0u, ix, iy, iz);
+    xw[j] = v.ax[ix];
+    yw[j] = v.ay[iy];
+    zw[j] = v.az[iz];
+  }
+  const bool vec = tsdf_aligned && nb + 4u <= v.N;
+  if (vec) {
+    const float4 t4 = *reinterpret_cast<const float4*>(v.tsdf + nb);
+    const int4 w4 = *reinterpret_cast<const int4*>(v.tsdf_w + nb);
+    told[0] = t4.x; told[1] = t4.y; told[2] = t4.z; told[3] = t4.w;
+    tw[0] = w4.x; tw[1] = w4.y; tw[2] = w4.z; tw[3] = w4.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      told[j] = inb[j] ? v.tsdf[nb + j] : 0.0f;
+      tw[j] = inb[j] ? v.tsdf_w[nb + j] : 0;
+    }
+  }
+  uint32_t touched = 0;  // bit j: voxel j's TSDF changed
+  // kFU frames at a time: all their depth gathers are in flight together, then the frames are
+  // applied one after the other (the TSDF running mean is order dependent)
+  constexpr int kFU = KFU;
+  for (int f0 = 0; f0 < wa.F; f0 += kFU) {
+    int pix[kFU][4];  // >= 0: pixel; -1: in view, no pixel (zeros padding); -2: not in view
+    float pz[kFU][4];
+#pragma unroll
+    for (int u = 0; u < kFU; ++u) {
+      const bool live = f0 + u < wa.F;
+      const Cam cam = s_cam[live ? f0 + u : 0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Proj p = project(cam, xw[j], yw[j], zw[j]);
+        const bool in_view = live && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
+        const int px = nearest_index(p.gx, p.gy, cam, wa.W);
+        pix[u][j] = in_view ? (px >= 0 ? px : -1) : -2;
+        pz[u][j] = p.z;
+      }
+    }
+    float depth[kFU][4];
+#pragma unroll
+    for (int u = 0; u < kFU; ++u) {
+      const float* __restrict__ dimg = wa.depth[f0 + u < wa.F ? f0 + u : 0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) depth[u][j] = pix[u][j] >= 0 ? dimg[pix[u][j]] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kFU; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in_view = pix[u][j] != -2;
+        const float num = depth[u][j] - pz[u][j];
+        const float sdf = num == INFINITY ? INFINITY : div_by_uniform(num, v.trunc, rtrunc);
+        if (in_view && fabsf(sdf) <= 1.0f) mk4[j] |= 1u << (f0 + u);
+        if (in_view && sdf > -1.0f) {
+          const float t = sdf > 1.0f ? 1.0f : sdf;
+          const int w1 = tw[j] + 1;
+          if (SUM) {
+            told[j] = told[j] + t;
+          } else {
+            const float rw = __builtin_amdgcn_rcpf((float)w1);
+            told[j] = t * rw + told[j] * ((float)tw[j] * rw);
+          }
+          tw[j] = w1;
+          touched |= 1u << j;
+          ++nt_done;
+        }
+      }
+    }
+  }
+  if (touched) {
+    tsdf_rows_done += (unsigned long long)__popc(touched);
+    if (vec) {
+      *reinterpret_cast<float4*>(v.tsdf + nb) = make_float4(told[0], told[1], told[2], told[3]);
+      *reinterpret_cast<int4*>(v.tsdf_w + nb) = make_int4(tw[0], tw[1], tw[2], tw[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (touched & (1u << j)) {
+          v.tsdf[nb + j] = told[j];
+          v.tsdf_w[nb + j] = tw[j];
+        }
+      }
+    }
+  }
+}
+
+// classify_window_kernel: one launch per window, on the auxiliary stream one window AHEAD of the window
+// kernel; leaves the per-voxel frame bitmasks of the window in `hitmask` and the updated TSDF.
+template <bool SUM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_window_kernel(
+    KVol v, WinArgs wa, int tile, uint32_t* __restrict__ hitmask,
+    unsigned long long* __restrict__ stats) {
+  __shared__ Cam s_cam[kWin];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < wa.F) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
+  __syncthreads();
+  if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)wa.F);
+  const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
+  uint32_t piece = blockIdx.x * 4u + (uint32_t)wave;
+  if (piece >= n_pieces) return;
+  if (tile > 0) {
+    // Workgroups are dispatched in index order, so the few thousand pieces in flight at any time are
+    // consecutive indices.  In linear order those are a few whole x-planes of the grid -- seen face-on
+    // they cover the whole depth image of a frame.  Walking the (x-plane, piece-in-plane) rectangle in
+    // tiles of tile x tile keeps the pieces in flight inside a compact box, whose footprint in every
+    // frame's depth image is small enough for the frames of this launch to stay in L2 together.
+    const uint32_t ppx = (uint32_t)(((int64_t)v.ny * v.nz) / kPiece);  // pieces per x-plane (exact, checked by the host)
+    const uint32_t T = (uint32_t)tile, tj = ppx / T, per_tile = T * T;
+    const uint32_t t = piece / per_tile, r = piece - t * per_tile;
+    const uint32_t tx = t / tj, ty = t - tx * tj;
+    piece = (tx * T + r / T) * ppx + ty * T + (r - (r / T) * T);
+  }
+  const float rtrunc = 1.0f / v.trunc;
+  const bool tsdf_aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
+  unsigned long long nt_done = 0, tsdf_rows_done = 0;
+  const uint32_t nb = piece * (uint32_t)kPiece + (uint32_t)lane * 4u;
+  const bool vecm = nb + 3u < v.N;
+  uint32_t mk4[4] = {0u, 0u, 0u, 0u};
+  classify_piece<4, SUM>(v, wa, s_cam, piece * (uint32_t)kPiece, lane, rtrunc, tsdf_aligned, mk4, nt_done, tsdf_rows_done);
+  if (vecm) {
+    *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (nb + k < v.N) hitmask[nb + k] = mk4[k];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    nt_done += __shfl_xor(nt_done, o);
+    tsdf_rows_done += __shfl_xor(tsdf_rows_done, o);
+  }
+  if (stats && lane == 0) {
+    if (nt_done) atomicAdd(&stats[1], nt_done);
+    if (tsdf_rows_done) atomicAdd(&stats[6], tsdf_rows_done);
+  }
+}
+
 // One hit of a sub-chunk, held by the lane with the hit's index.
 struct WinHit {
   int row;  // row slot in the LDS buffer
@@ -1017,7 +1175,9 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, uint32_
     }
   }
   if (g0 == 0) {  // the sub-chunk's rows (LDS-DMA, issued before these loads) have landed after this
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the BUILTIN, not inline asm: the compiler's wait-count pass must see that the LDS-DMA has been
+    // waited for, or it drains vmcnt before every later LDS read (each row's store waited for the last)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
     wave_lds_sync();
   }
 #pragma unroll
@@ -1048,9 +1208,9 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, uint32_
 
 template <int CPL, bool SUM>
 __global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(SAF_WIN_WPE, SAF_WIN_WPE))) void
-fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs,
-                                                                  int img_vecs, unsigned long long* __restrict__ stats,
-                                                                  unsigned int* __restrict__ piece_ctr) {
+fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int img_vecs,
+                   unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
+                   const uint32_t* __restrict__ hitmask) {
   using Cfg = WinCfg<CPL>;
   constexpr int SR = Cfg::SR, P = Cfg::P;
   extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -1086,10 +1246,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs,
   KFrame kf;  // per-hit view of a frame for the scalar side
   kf.H = wa.H; kf.W = wa.W; kf.npy = wa.npy; kf.npx = wa.npx; kf.rgb_bilinear = wa.rgb_bilinear;
   kf.depth = nullptr; kf.pose = nullptr; kf.K = nullptr;
-  unsigned long long hits_done = 0, rows_done = 0, nt_done = 0, tsdf_rows_done = 0;
-  if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)wa.F);
-  const float rtrunc = 1.0f / v.trunc;
-  const bool tsdf_aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
+  unsigned long long hits_done = 0, rows_done = 0;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   WT_DECL;
   // persistent grid (2 workgroups per CU): the other half of every CU stays free for the sweeps of
@@ -1102,102 +1259,16 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs,
     piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece);
     if (piece >= n_pieces) break;
     const uint32_t piece_base = piece * (uint32_t)kPiece;
-    // ---- classify the piece against every frame of the window: a lane owns 4 consecutive voxels
-    //      (clipfusion.py:647-679), keeps their TSDF running mean in registers across the frames
-    //      (clipfusion.py:681-695 with B = 1, frame after frame) and collects the frame bitmask of each
-    uint32_t mk4[4] = {0u, 0u, 0u, 0u};
+    // ---- the piece's touched voxels: (local id, frame mask) left by classify_window_kernel, compacted into LDS
+    uint32_t mk4[4];
     {
       const uint32_t nb = piece_base + (uint32_t)lane * 4u;
-      float xw[4], yw[4], zw[4], told[4];
-      int tw[4];
-      bool inb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        inb[j] = nb + j < v.N;
-        int ix, iy, iz;
-        voxel_coords(v, inb[j] ? nb + j : 0u, ix, iy, iz);
-        xw[j] = v.ax[ix];
-        yw[j] = v.ay[iy];
-        zw[j] = v.az[iz];
-      }
-      const bool vec = tsdf_aligned && nb + 4u <= v.N;
-      if (vec) {
-        const float4 t4 = *reinterpret_cast<const float4*>(v.tsdf + nb);
-        const int4 w4 = *reinterpret_cast<const int4*>(v.tsdf_w + nb);
-        told[0] = t4.x; told[1] = t4.y; told[2] = t4.z; told[3] = t4.w;
-        tw[0] = w4.x; tw[1] = w4.y; tw[2] = w4.z; tw[3] = w4.w;
+      if (nb + 3u < v.N) {
+        const uint4 t = *reinterpret_cast<const uint4*>(hitmask + nb);
+        mk4[0] = t.x; mk4[1] = t.y; mk4[2] = t.z; mk4[3] = t.w;
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          told[j] = inb[j] ? v.tsdf[nb + j] : 0.0f;
-          tw[j] = inb[j] ? v.tsdf_w[nb + j] : 0;
-        }
-      }
-      uint32_t touched = 0;  // bit j: voxel j's TSDF changed
-      // kFU frames at a time: all their depth gathers are in flight together, then the frames are
-      // applied one after the other (the TSDF running mean is order dependent)
-      constexpr int kFU = 8;
-      for (int f0 = 0; f0 < wa.F; f0 += kFU) {
-        int pix[kFU][4];  // >= 0: pixel; -1: in view, no pixel (zeros padding); -2: not in view
-        float pz[kFU][4];
-#pragma unroll
-        for (int u = 0; u < kFU; ++u) {
-          const bool live = f0 + u < wa.F;
-          const Cam cam = s_cam[live ? f0 + u : 0];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const Proj p = project(cam, xw[j], yw[j], zw[j]);
-            const bool in_view = live && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
-            const int px = nearest_index(p.gx, p.gy, cam, wa.W);
-            pix[u][j] = in_view ? (px >= 0 ? px : -1) : -2;
-            pz[u][j] = p.z;
-          }
-        }
-        float depth[kFU][4];
-#pragma unroll
-        for (int u = 0; u < kFU; ++u) {
-          const float* __restrict__ dimg = wa.depth[f0 + u < wa.F ? f0 + u : 0];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) depth[u][j] = pix[u][j] >= 0 ? dimg[pix[u][j]] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < kFU; ++u) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bool in_view = pix[u][j] != -2;
-            const float num = depth[u][j] - pz[u][j];
-            const float sdf = num == INFINITY ? INFINITY : div_by_uniform(num, v.trunc, rtrunc);
-            if (in_view && fabsf(sdf) <= 1.0f) mk4[j] |= 1u << (f0 + u);
-            if (in_view && sdf > -1.0f) {
-              const float t = sdf > 1.0f ? 1.0f : sdf;
-              const int w1 = tw[j] + 1;
-              if (SUM) {
-                told[j] = told[j] + t;
-              } else {
-                const float rw = __builtin_amdgcn_rcpf((float)w1);
-                told[j] = t * rw + told[j] * ((float)tw[j] * rw);
-              }
-              tw[j] = w1;
-              touched |= 1u << j;
-              ++nt_done;
-            }
-          }
-        }
-      }
-      if (touched) {
-        tsdf_rows_done += (unsigned long long)__popc(touched);
-        if (vec) {
-          *reinterpret_cast<float4*>(v.tsdf + nb) = make_float4(told[0], told[1], told[2], told[3]);
-          *reinterpret_cast<int4*>(v.tsdf_w + nb) = make_int4(tw[0], tw[1], tw[2], tw[3]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (touched & (1u << j)) {
-              v.tsdf[nb + j] = told[j];
-              v.tsdf_w[nb + j] = tw[j];
-            }
-          }
-        }
+        for (int k = 0; k < 4; ++k) mk4[k] = nb + k < v.N ? hitmask[nb + k] : 0u;
       }
     }
     int T = 0;
@@ -1292,6 +1363,20 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs,
         const unsigned long long okm = __ballot(lane >= i0 && lane < m && lane < i0 + SR && (incl - pbase) <= 64);
         const int nrows = __popcll(okm);                                         // >= 1 (a voxel has <= 32 hits)
         const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..64
+        // hit l of the sub-chunk (staging entry pbase + l) lives in lane l: its row, a, b and tap weights
+        const bool hit = lane < nh;
+        const uint32_t hfl = hit ? s_hf[pbase + lane] : 0xffffffffu;
+        const uint32_t key = hfl >> 6;  // frame << 16 | cell
+        WinHit rec;
+        rec.row = (int)(hfl & 63u) - i0;
+        rec.a = hit ? s_ha[pbase + lane] : 0.0f;
+        rec.b = hit ? s_hb[pbase + lane] : 0.0f;
+        {
+          const Bilin w = bilinear_setup(hit ? s_hgx[pbase + lane] : 0.0f, hit ? s_hgy[pbase + lane] : 0.0f, half_px, half_py);
+          rec.nw = w.nw; rec.ne = w.ne; rec.sw = w.sw; rec.se = w.se;
+        }
+        // (the staging reads above come BEFORE the LDS-DMA below: the compiler drains vmcnt ahead of any LDS
+        //  read that follows an LDS-DMA, which would expose the rows' whole latency right here)
         // the rows, global -> LDS (one LDS-DMA moves a wave's 64 x 16 B = one 1 KiB piece of a row)
         uint32_t fmask = 0;  // frames with a hit in this sub-chunk
 #pragma unroll
@@ -1305,18 +1390,6 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs,
                                                (__attribute__((address_space(3))) void*)(rows + (r * CPL + c) * 64),
                                                16, 0, 2);
           }
-        }
-        // hit l of the sub-chunk (staging entry pbase + l) lives in lane l: its row, a, b and tap weights
-        const bool hit = lane < nh;
-        const uint32_t hfl = hit ? s_hf[pbase + lane] : 0xffffffffu;
-        const uint32_t key = hfl >> 6;  // frame << 16 | cell
-        WinHit rec;
-        rec.row = (int)(hfl & 63u) - i0;
-        rec.a = hit ? s_ha[pbase + lane] : 0.0f;
-        rec.b = hit ? s_hb[pbase + lane] : 0.0f;
-        {
-          const Bilin w = bilinear_setup(hit ? s_hgx[pbase + lane] : 0.0f, hit ? s_hgy[pbase + lane] : 0.0f, half_px, half_py);
-          rec.nw = w.nw; rec.ne = w.ne; rec.sw = w.sw; rec.se = w.se;
         }
         // groups = hits of one frame in one map cell, frames ascending (a row's hits stay in frame order);
         // group g is kept in lane g: its key and the lane mask of its members
@@ -1352,6 +1425,10 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs,
             default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM>(cx, g0, gk, gm_lo, gm_hi, rec); break;
           }
         }
+        // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
+        // compiler's wait-count pass so, or it would drain vmcnt -- i.e. the previous row's store -- before
+        // each row's LDS read below
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         wave_lds_sync();
         WT(6);
 #pragma unroll
@@ -1372,16 +1449,9 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs,
     }
   }
   WT_FLUSH;
-  // wave totals: hits, tsdf updates, rows and tsdf voxels read-modify-written by this window
-  for (int o = 32; o > 0; o >>= 1) {
-    nt_done += __shfl_xor(nt_done, o);
-    tsdf_rows_done += __shfl_xor(tsdf_rows_done, o);
-  }
   if (stats && lane == 0) {
     if (hits_done) atomicAdd(&stats[0], hits_done);
-    if (nt_done) atomicAdd(&stats[1], nt_done);
-    if (rows_done) atomicAdd(&stats[5], rows_done);
-    if (tsdf_rows_done) atomicAdd(&stats[6], tsdf_rows_done);
+    if (rows_done) atomicAdd(&stats[5], rows_done);  // rows read-modify-written by this window
   }
 }
 
@@ -1612,16 +1682,18 @@ int launch_rows(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned
 // Workspace: the common header (piece counter), then the kWin pixel-major map images of one window.
 // ---------------------------------------------------------------------------------------------
 struct WinLayout {
-  size_t img_bytes, total;
+  size_t img_bytes, maps_bytes, mask_bytes, total;
 };
-WinLayout win_layout(int D, int P) {
+WinLayout win_layout(int64_t n_vox, int D, int P) {
   WinLayout w;
   w.img_bytes = ((size_t)D * (P + 1) * sizeof(float) + 255) & ~(size_t)255;
-  w.total = kHdrBytes + (size_t)kWin * w.img_bytes;
+  w.maps_bytes = (size_t)kWin * w.img_bytes;
+  w.mask_bytes = ((size_t)n_vox * sizeof(uint32_t) + 255) & ~(size_t)255;
+  w.total = kHdrBytes + w.maps_bytes + 2 * w.mask_bytes;
   return w;
 }
 
-using WinFn = void (*)(KVol, WinArgs, const float*, int, unsigned long long*, unsigned int*);
+using WinFn = void (*)(KVol, WinArgs, const float*, int, unsigned long long*, unsigned int*, const uint32_t*);
 template <int CPL>
 WinFn pick_win(bool sum) {
   return sum ? fuse_window_kernel<CPL, true> : fuse_window_kernel<CPL, false>;
@@ -1639,7 +1711,7 @@ bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
       return false;
   }
   if (f0.npx + 3 > 255 || f0.npy + 3 > 255) return false;  // a hit's map cell travels as two bytes
-  return workspace_bytes >= win_layout(kv.D, f0.npy * f0.npx).total;
+  return workspace_bytes >= win_layout(kv.N, kv.D, f0.npy * f0.npx).total;
 }
 
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, uint64_t* stats,
@@ -1653,16 +1725,17 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if ((rc = make_kframe(&frames[i], &t))) return rc;
   }
   const int P = kf0.npy * kf0.npx;
-  const WinLayout wl = win_layout(kv.D, P);
+  const WinLayout wl = win_layout(kv.N, kv.D, P);
+  const bool sum = kv.accum == SAF_SUM;
   const int img_vecs = (int)(wl.img_bytes / sizeof(float4));
   const int prep_blocks = (kv.D * (P + 1) + 255) / 256;
   WinFn fn;
   size_t win_lds;
   switch (kv.D / 256) {
-    case 1: fn = pick_win<1>(kv.accum == SAF_SUM); win_lds = WinCfg<1>::total; break;
-    case 2: fn = pick_win<2>(kv.accum == SAF_SUM); win_lds = WinCfg<2>::total; break;
-    case 3: fn = pick_win<3>(kv.accum == SAF_SUM); win_lds = WinCfg<3>::total; break;
-    default: fn = pick_win<4>(kv.accum == SAF_SUM); win_lds = WinCfg<4>::total; break;
+    case 1: fn = pick_win<1>(sum); win_lds = WinCfg<1>::total; break;
+    case 2: fn = pick_win<2>(sum); win_lds = WinCfg<2>::total; break;
+    case 3: fn = pick_win<3>(sum); win_lds = WinCfg<3>::total; break;
+    default: fn = pick_win<4>(sum); win_lds = WinCfg<4>::total; break;
   }
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1670,38 +1743,83 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", win_lds, hipGetErrorString(e));
   }
   float* maps = reinterpret_cast<float*>(ws + kHdrBytes);
+  uint32_t* masks[2] = {reinterpret_cast<uint32_t*>(ws + kHdrBytes + wl.maps_bytes),
+                        reinterpret_cast<uint32_t*>(ws + kHdrBytes + wl.maps_bytes + wl.mask_bytes)};
   unsigned int* piece_ctr = reinterpret_cast<unsigned int*>(ws);
   static const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
   uint32_t grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : 2);
-  const uint32_t n_wgs = (uint32_t)(((int64_t)kv.N + kPiece * kWinWaves - 1) / (kPiece * kWinWaves));
+  const uint32_t n_pieces = (uint32_t)(((int64_t)kv.N + kPiece - 1) / kPiece);
+  const uint32_t n_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
   if (grid > n_wgs) grid = n_wgs;
-  // Everything is ordered on the caller's stream: map images of the window, then the window kernel.
-  const int n_win = (n_frames + kWin - 1) / kWin;
-  for (int w = 0; w < n_win; ++w) {
-    const int f0 = w * kWin;
-    const int F = n_frames - f0 < kWin ? n_frames - f0 : kWin;
-    WinArgs wa;
-    wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
-    PrepArgs pa;
-    for (int k = 0; k < kWin; ++k) {
-      const saf_frame& fr = frames[f0 + (k < F ? k : 0)];
-      wa.depth[k] = fr.depth; wa.rgb[k] = fr.rgb; wa.pose[k] = fr.pose; wa.K[k] = fr.K; wa.label_map[k] = fr.label_map;
-      pa.feat_map[k] = fr.feat_map;
+  // Split form: the classification of window w+1 (auxiliary stream) runs beside the window kernel of
+  // window w (caller's stream); an event orders each window kernel behind its classification, another
+  // one orders a classification behind the window kernel that last read its mask buffer.
+  hipStream_t aux = nullptr;
+  hipEvent_t fork = nullptr, applied[2] = {nullptr, nullptr}, classified[2] = {nullptr, nullptr};
+  {
+    SAF_HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    SAF_HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b) {
+      SAF_HIP_TRY(hipEventCreateWithFlags(&applied[b], hipEventDisableTiming));
+      SAF_HIP_TRY(hipEventCreateWithFlags(&classified[b], hipEventDisableTiming));
     }
-    if (hipMemsetAsync(piece_ctr, 0, sizeof(unsigned int), s) != hipSuccess)
-      return fail(SAF_E_HIP, "hipMemsetAsync(piece counter)");
-    {
-      ScopedPair t(prof, 0, f0, s);
-      hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, pa, maps,
-                         (int)(wl.img_bytes / sizeof(float)), kv.D, P);
+    SAF_HIP_TRY(hipEventRecord(fork, s));
+    SAF_HIP_TRY(hipStreamWaitEvent(aux, fork, 0));
+  }
+  {
+    const int n_win = (n_frames + kWin - 1) / kWin;
+    for (int w = 0; w < n_win; ++w) {
+      const int f0 = w * kWin;
+      const int F = n_frames - f0 < kWin ? n_frames - f0 : kWin;
+      WinArgs wa;
+      wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
+      PrepArgs pa;
+      for (int k = 0; k < kWin; ++k) {
+        const saf_frame& fr = frames[f0 + (k < F ? k : 0)];
+        wa.depth[k] = fr.depth; wa.rgb[k] = fr.rgb; wa.pose[k] = fr.pose; wa.K[k] = fr.K; wa.label_map[k] = fr.label_map;
+        pa.feat_map[k] = fr.feat_map;
+      }
+      {
+        if (w >= 2) SAF_HIP_TRY(hipStreamWaitEvent(aux, applied[w & 1], 0));  // the mask buffer is free again
+        static const bool serial = getenv("SAF_WIN_SERIAL") && getenv("SAF_WIN_SERIAL")[0] == '1';
+        if (serial && w >= 1) SAF_HIP_TRY(hipStreamWaitEvent(aux, applied[(w - 1) & 1], 0));
+        static const int tile_env = getenv("SAF_WIN_TILE") ? atoi(getenv("SAF_WIN_TILE")) : -1;
+        int tile = tile_env >= 0 ? tile_env : 64;
+        {
+          const int64_t plane = (int64_t)kv.ny * kv.nz;
+          const int64_t ppx = plane / kPiece;
+          if (plane % kPiece != 0) tile = 0;
+          while (tile >= 8 && (ppx % tile != 0 || kv.nx % tile != 0)) tile >>= 1;
+          if (tile < 8) tile = 0;  // linear order
+        }
+        {
+          ScopedPair t(prof, 1, f0, aux);
+          if (sum)
+            hipLaunchKernelGGL(classify_window_kernel<true>, dim3(n_wgs), dim3(256), 0, aux, kv, wa, tile, masks[w & 1],
+                               reinterpret_cast<unsigned long long*>(stats));
+          else
+            hipLaunchKernelGGL(classify_window_kernel<false>, dim3(n_wgs), dim3(256), 0, aux, kv, wa, tile, masks[w & 1],
+                               reinterpret_cast<unsigned long long*>(stats));
+        }
+        if ((rc = check_launch("classify_window_kernel"))) goto done;
+        SAF_HIP_TRY(hipEventRecord(classified[w & 1], aux));
+      }
+      SAF_HIP_TRY(hipMemsetAsync(piece_ctr, 0, sizeof(unsigned int), s));
+      {
+        ScopedPair t(prof, 0, f0, s);
+        hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, pa, maps,
+                           (int)(wl.img_bytes / sizeof(float)), kv.D, P);
+      }
+      if ((rc = check_launch("prep_rows_kernel"))) goto done;
+      SAF_HIP_TRY(hipStreamWaitEvent(s, classified[w & 1], 0));
+      {
+        ScopedPair t(prof, 2, f0, s);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, maps, img_vecs,
+                           reinterpret_cast<unsigned long long*>(stats), piece_ctr, masks[w & 1]);
+      }
+      if ((rc = check_launch("fuse_window_kernel"))) goto done;
+      SAF_HIP_TRY(hipEventRecord(applied[w & 1], s));
     }
-    if ((rc = check_launch("prep_rows_kernel"))) return rc;
-    {
-      ScopedPair t(prof, 2, f0, s);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, maps, img_vecs,
-                         reinterpret_cast<unsigned long long*>(stats), piece_ctr);
-    }
-    if ((rc = check_launch("fuse_window_kernel"))) return rc;
   }
 #ifdef SAF_WIN_TIMING
   {
@@ -1718,6 +1836,13 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     }
   }
 #endif
+done:
+  if (fork) (void)hipEventDestroy(fork);
+  for (int b = 0; b < 2; ++b) {
+    if (applied[b]) (void)hipEventDestroy(applied[b]);
+    if (classified[b]) (void)hipEventDestroy(classified[b]);
+  }
+  if (aux) (void)hipStreamDestroy(aux);
   return rc;
 }
 
@@ -1794,7 +1919,7 @@ int saf_abi_version(void) { return SAF_ABI_VERSION; }
 
 size_t saf_fuse_workspace_bytes(int64_t n_vox, int32_t feat_dim, int32_t npy, int32_t npx) {
   if (n_vox <= 0 || feat_dim <= 0 || npy <= 0 || npx <= 0) return 0;
-  const size_t a = ws_layout(n_vox, feat_dim, npy * npx).total, b = win_layout(feat_dim, npy * npx).total;
+  const size_t a = ws_layout(n_vox, feat_dim, npy * npx).total, b = win_layout(n_vox, feat_dim, npy * npx).total;
   return a > b ? a : b;
 }
 
