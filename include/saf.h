@@ -93,7 +93,10 @@ typedef struct saf_frame {
 /* Counters the fuse kernels add to (device memory, 8 x u64, caller zeroes them when it wants):
  *  [0] sum of Nv (valid voxels)  [1] sum of Nt (tsdf-valid voxels)  [2] frames fused
  *  [3] labels outside [0,n_classes) that were dropped (the reference raises instead)
- *  [4] fuse workgroups that gave up waiting for their frame's sweep (must stay 0)  [5..7] reserved */
+ *  [4] fuse workgroups that gave up waiting for their frame's sweep (must stay 0)
+ *  [5] feature rows read-modify-written by window kernels (= sum over windows of |union of valid sets|;
+ *      0 when the per-frame pipeline ran)  [6] voxels whose TSDF a window's classification updated
+ *      (sum over windows of |union of tsdf-valid sets|)  [7] reserved */
 #define SAF_STATS_WORDS 8
 
 const char* saf_last_error(void);
@@ -114,13 +117,20 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
                    size_t workspace_bytes, uint64_t* stats, void* stream);
 
 /* The same for n_frames frames in order (host array of descriptors); one host call, no host
- * synchronisation between frames -- the loop of clipfusion.py:1125-1133. */
+ * synchronisation between frames -- the loop of clipfusion.py:1125-1133.
+ * Two device paths, identical results bit for bit:
+ *  - per-frame pipeline: one sweep + one fuse kernel per frame (any shape);
+ *  - windowed, voxel-major (16 or more frames of one shape, f32 volume, feat_dim a multiple of 256 up to
+ *    1024): per window of 32 frames one classification kernel (sweep of all 32 frames, TSDF in registers)
+ *    and one row kernel that reads and writes every touched feature row once per window.
+ *    SAF_WINDOW=0 in the environment forces the per-frame pipeline. */
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
                     void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
 
 /*
  * Optional per-kernel timing: a pool of HIP event pairs recorded on the launch stream around each
- * kernel of saf_fuse_frames_profiled (class 0 = prep, 1 = sweep, 2 = fuse).  Recording is
+ * kernel of saf_fuse_frames_profiled (class 0 = prep, 1 = sweep / window classification, 2 = fuse /
+ * window row kernel).  Recording is
  * asynchronous; saf_profiler_read must be called after the stream has been synchronised.
  * Used by bench.py for the roofline line; the product path passes NULL.
  */

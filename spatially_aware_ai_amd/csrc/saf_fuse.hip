@@ -1784,7 +1784,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
         static const bool serial = getenv("SAF_WIN_SERIAL") && getenv("SAF_WIN_SERIAL")[0] == '1';
         if (serial && w >= 1) SAF_HIP_TRY(hipStreamWaitEvent(aux, applied[(w - 1) & 1], 0));
         static const int tile_env = getenv("SAF_WIN_TILE") ? atoi(getenv("SAF_WIN_TILE")) : -1;
-        int tile = tile_env >= 0 ? tile_env : 64;
+        int tile = tile_env >= 0 ? tile_env : 32;
         {
           const int64_t plane = (int64_t)kv.ny * kv.nz;
           const int64_t ppx = plane / kPiece;

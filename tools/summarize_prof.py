@@ -25,16 +25,18 @@ if ks:
     shutil.copy(ks[0], f"{dst}/kernel_stats.csv")
     for r in csv.DictReader(open(ks[0])):
         if "saf::" in r["Name"]:
-            short = r["Name"].split("saf::(anonymous namespace)::")[-1].split("(")[0]
+            short = r["Name"].split("saf::(anonymous namespace)::")[1].split("(")[0] if "saf::(anonymous namespace)::" in r["Name"] else r["Name"]
+            short = short.split("<")[0] + ("<" + short.split("<", 1)[1] if "<" in short else "")
             print(f"{short:40s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.2f} pct {r['Percentage']}")
 if os.path.exists(f"{src}/bench_under_rocprof.json"):
     shutil.copy(f"{src}/bench_under_rocprof.json", f"{dst}/bench_under_rocprof.json")
 
 
 def name_of(k):
-    for n in ("fuse_rows_kernel", "fuse_kernel", "sweep_kernel", "prep_kernel", "query_kernel"):
+    for n in ("fuse_window_kernel", "classify_window_kernel", "fuse_rows_kernel", "fuse_kernel", "sweep_kernel",
+              "prep_rows_kernel", "prep_kernel", "query_kernel"):
         if n in k:
-            return "fuse_kernel" if n.startswith("fuse") else n
+            return "fuse_kernel" if n in ("fuse_rows_kernel", "fuse_kernel") else n
     return None
 
 
@@ -52,7 +54,22 @@ for d, cn in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 if out:
     json.dump(out, open(f"{dst}/pmc_fetch_write.json", "w"), indent=1)
     try:
-        cfg = json.load(open(f"{src}/pmc_fetch.json"))["config"]
+        bj = json.loads(open(f"{src}/pmc_fetch.json").read().strip().splitlines()[-1])
+        cfg = bj["config"]
+        if "fuse_window_kernel" in out["FETCH_SIZE"]:  # the windowed path ran: per-window launches
+            wt = {"grid": cfg["grid"], "dim": cfg["feat_dim"], "frames_per_launch": 32,
+                  "depth_kind": "B" if "depth-B" in cfg["workload"] else "A",
+                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 64 frames (2 windows); "
+                            "FETCH_SIZE x2 (gfx950 correction), KiB -> bytes"}
+            for kn, key in (("fuse_window_kernel", "hbm"), ("classify_window_kernel", "classify_hbm")):
+                f = out["FETCH_SIZE"][kn]["mean_KiB"] * 1024 * 2
+                w = out["WRITE_SIZE"][kn]["mean_KiB"] * 1024
+                wt[f"{key}_read_bytes_per_launch"] = int(f)
+                wt[f"{key}_write_bytes_per_launch"] = int(w)
+                wt[f"{key}_bytes_per_launch"] = int(f + w)
+                print("%s traffic per launch: read %.1f MB write %.1f MB" % (kn, f / 1e6, w / 1e6))
+            json.dump(wt, open(f"{dst}/window_traffic.json", "w"), indent=1)
+            raise SystemExit(0)
         f = out["FETCH_SIZE"]["fuse_kernel"]["mean_KiB"] * 1024 * 2
         w = out["WRITE_SIZE"]["fuse_kernel"]["mean_KiB"] * 1024
         t = {"grid": cfg["grid"], "dim": cfg["feat_dim"], "hbm_read_bytes_per_launch": int(f),
