@@ -356,9 +356,12 @@ def test_extract_mesh_vertex_sampling_golden(golden_dir):
             np.testing.assert_allclose(out[5].cpu().numpy(), g["seem_vertex_segment_color"], rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("dim,seem,accum,n_frames", [(512, True, _abi.SAF_RUNNING_MEAN, 40), (256, False, _abi.SAF_RUNNING_MEAN, 33),
-                                                     (768, False, _abi.SAF_SUM, 19), (1024, True, _abi.SAF_RUNNING_MEAN, 15)])
-def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_frames):
+@pytest.mark.parametrize("dim,seem,accum,n_frames,nvox", [
+    (512, True, _abi.SAF_RUNNING_MEAN, 40, (33, 30, 41)), (256, False, _abi.SAF_RUNNING_MEAN, 33, (33, 30, 41)),
+    (768, False, _abi.SAF_SUM, 19, (33, 30, 41)), (1024, True, _abi.SAF_RUNNING_MEAN, 15, (33, 30, 41)),
+    # ny*nz a multiple of 256 and nx a multiple of 16: the classification walks the grid in 16x16 tiles
+    (256, False, _abi.SAF_RUNNING_MEAN, 35, (64, 64, 64)), (512, True, _abi.SAF_RUNNING_MEAN, 17, (32, 16, 128))])
+def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_frames, nvox):
     """saf_fuse_frames with >= 16 frames of a 256-multiple feature dim takes the windowed voxel-major path
     (one kernel per window of 32 frames: classification, TSDF, and one row read + write per touched voxel,
     hits applied in frame order).  It must reproduce the frame-by-frame path BIT FOR BIT on every buffer,
@@ -367,7 +370,7 @@ def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_
 
     w, h = 64, 48
     npy, npx = syn.feature_map_shape(w, h)
-    grid = syn.make_grid((33, 30, 41))
+    grid = syn.make_grid(nvox, side=2.56 * nvox[0] / max(nvox))  # the longest edge is 2.56 m
     frames = syn.make_frames(909, n_frames, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="B",
                              missing_depth_frac=0.05)
     # the same camera twice in a row and a camera inside the grid: voxels hit by several frames of a window
