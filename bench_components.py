@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Benchmark of saf_label_components (the connected-component core of
+flood_fill_3d, handy_utils.py:295-480) on a synthetic label grid.
+
+    python bench_components.py [--grid 256] [--classes 40] [--iters 10]
+
+Prints one JSON line: voxels/s of the HIP path (HIP-event timed, inputs resident), its algorithmic bytes
+(labels read once + object ids written once, 8 B per voxel) against the HBM peak, and the oracle's C
+restatement of the reference's raster-scan flood fill timed on a smaller grid as the CPU baseline (the
+reference itself is a pure-Python triple loop)."""
+import argparse
+import json
+import time
+
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_labels(n, classes, seed=0):
+    """Blobby label field: class = quantised sum of a few low-frequency waves; ~35 % empty, ~5 % null."""
+    g = torch.Generator().manual_seed(seed)
+    ax = torch.linspace(0, 1, n)
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    f = torch.zeros(n, n, n)
+    for _ in range(6):
+        k = torch.rand(3, generator=g) * 14 + 2
+        p = torch.rand(3, generator=g) * 6.28
+        f += torch.sin(k[0] * x + p[0]) * torch.sin(k[1] * y + p[1]) * torch.sin(k[2] * z + p[2])
+    q = ((f - f.min()) / (f.max() - f.min()) * classes).long().clamp_(0, classes - 1).to(torch.int32)
+    r = torch.rand(n, n, n, generator=g)
+    q[f.abs() < 0.25] = -1
+    q[r < 0.05] = 133
+    return q
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=40)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--cpu-grid", type=int, default=96)
+    a = ap.parse_args()
+    from spatially_aware_ai_amd import label_components
+
+    lab = synthetic_labels(a.grid, a.classes).cuda()
+    ids, first, cls, cnt = label_components(lab)  # warm-up (also sizes the workspace allocator)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        ids, first, cls, cnt = label_components(lab)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    n = lab.numel()
+    cpu = None
+    try:
+        from oracle import oracle as O
+
+        small = synthetic_labels(a.cpu_grid, a.classes).numpy()
+        t0 = time.perf_counter()
+        O.label_components(small)
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(small.size / dt / 1e6, 2), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+               "sample": f"{a.cpu_grid}^3 grid, oracle/saf_oracle.c raster-scan flood fill (1 thread)"}
+    except Exception as e:  # the oracle is optional
+        cpu = {"value": None, "sample": f"unavailable: {e}"}
+    print(json.dumps({
+        "metric": f"label components of a {a.grid}^3 grid", "value": round(n / ms / 1e3, 1), "unit": "Mvoxels/s",
+        "ms": round(ms, 3), "objects": int(first.numel()), "largest": int(cnt.max()) if cnt.numel() else 0,
+        "dtype": "int32", "data": "synthetic",
+        "roofline": {"bound": "hbm", "achieved": round(n * 8 / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(n * 8 / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "note": "algorithmic = labels read once + ids written once; the union-find passes re-read parent[] "
+                             "(4 more N x 4 B arrays live in the workspace)"},
+        "cpu_baseline": cpu}))
+
+
+if __name__ == "__main__":
+    main()

@@ -231,6 +231,23 @@ int saf_sample_vertices(const saf_volume* vol, const float* verts_index, int64_t
 int saf_label_argmax(const int32_t* labels_one_hot, int64_t n_voxels, int32_t n_classes,
                      int32_t* out, void* stream);
 
+/* ---- the connected-component core of flood_fill_3d (handy_utils.py:295-480) ----
+ * labels [nx,ny,nz] i32 class ids (row-major, z fastest), as produced by saf_label_argmax reshaped to the
+ * grid (clip_seem_fusion.py:322-338).  Voxels of `null_class` (133 in the reference, handy_utils.py:383)
+ * and empty voxels (-1) belong to no object.  Objects are the 26-connected sets of equal class
+ * (handy_utils.py:312-344); objects of fewer than `min_voxels` voxels are rejected (3 in the reference,
+ * :390).  The k-th accepted object in raster order of its first voxel gets the index -2 - k
+ * (handy_utils.py:352-353, :447-450 without a trained in-situ model):
+ *   obj_ids   [N] i32   -1 or -2 - k                      (= the reference's voxel_obj_ids)
+ *   n_objects [1] i32   number of accepted objects
+ *   obj_first / obj_class / obj_count [max_objects] i32 (each may be NULL): first voxel (flat index),
+ *   class id and voxel count of object k, for k < max_objects. */
+size_t saf_label_components_workspace_bytes(int64_t n_voxels);
+int saf_label_components(const int32_t* labels, int32_t nx, int32_t ny, int32_t nz, int32_t null_class,
+                         int32_t min_voxels, int32_t* obj_ids, int32_t* n_objects, int32_t max_objects,
+                         int32_t* obj_first, int32_t* obj_class, int32_t* obj_count, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

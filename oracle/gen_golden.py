@@ -11,6 +11,7 @@ detectron2, ... -- the recipe verified in SURVEY.md §8c), drives
   * Clip.run_query                  (clipfusion.py:899-904)
   * Clip.clip_feature_surgery       (clipfusion.py:906-934)
   * the clip_text_query post-processing arithmetic (clip_seem_fusion.py:507-548)
+  * flood_fill_3d, first scan         (handy_utils.py:295-480)
 
 on small seeded inputs and writes inputs + outputs as .npz fixtures under tests/golden/.
 The backbones (CLIP ViT, kMaX-DeepLab) are replaced by seeded feature / label maps: they
@@ -422,6 +423,48 @@ def gen_extract_mesh(ref_cf, ref_csf, out_dir):
     print("extract_mesh sampling:", tuple(vfeat.shape), "good faces", len(faces_out))
 
 
+def gen_label_components(out_dir):
+    """flood_fill_3d (handy_utils.py:295-480) itself, first scan (no trained in-situ model), on small seeded
+    label grids: voxel_obj_ids and the discovered objects in discovery order."""
+    import handy_utils as hu  # imported by clip_seem_fusion with the same stand-ins
+
+    class _NoModel:
+        def __init__(self):
+            self.labels = ["null"]
+            self.model_trained = False
+
+    out = {}
+    cases = [(21, (6, 7, 9), 3, 0.30, 0.10), (22, (12, 10, 14), 4, 0.35, 0.05), (23, (3, 3, 40), 2, 0.2, 0.2),
+             (24, (8, 8, 8), 1, 0.5, 0.0), (25, (5, 6, 4), 130, 0.1, 0.1)]
+    for ci, (seed, shape, ncls, p_empty, p_null) in enumerate(cases):
+        g = np.random.default_rng(seed)
+        lab = g.integers(0, ncls, size=shape).astype(np.int32)
+        r = g.random(shape)
+        lab[r < p_empty] = -1
+        lab[(r >= p_empty) & (r < p_empty + p_null)] = 133
+        feats = np.zeros(shape + (2,), dtype=np.float32)
+        rgb = np.zeros(shape + (3,), dtype=np.float32)
+        import contextlib
+        import io
+
+        with contextlib.redirect_stdout(io.StringIO()):  # the reference prints per call
+            know, ids = hu.flood_fill_3d(lab.copy(), None, feats, rgb, _NoModel())
+        objs = know["unique_objects"]
+        ny, nz = shape[1], shape[2]
+        out[f"c{ci}_labels"] = lab
+        out[f"c{ci}_voxel_obj_ids"] = ids.astype(np.int32)
+        out[f"c{ci}_object_index"] = np.array([o["object_index"] for o in objs.values()], dtype=np.int32)
+        out[f"c{ci}_class_id"] = np.array([o["class_id"] for o in objs.values()], dtype=np.int32)
+        out[f"c{ci}_count"] = np.array([len(o["voxels"]) for o in objs.values()], dtype=np.int32)
+        out[f"c{ci}_first"] = np.array(
+            [min((v[0] * ny + v[1]) * nz + v[2] for v in o["voxels"]) for o in objs.values()], dtype=np.int32)
+        out[f"c{ci}_ids"] = np.array(list(objs.keys()))
+        out[f"c{ci}_class_names"] = np.array(hu.predefined_classes)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(out_dir, "label_components.npz"), **out)
+    print("label_components:", [int(out[f"c{i}_count"].size) for i in range(len(cases))], "objects per case")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -437,6 +480,7 @@ def main():
     gen_query(ref_cf, args.out)
     gen_fusion_c1(ref_cf, args.out)
     gen_extract_mesh(ref_cf, ref_csf, args.out)
+    gen_label_components(args.out)
     with open(os.path.join(args.out, "README.md"), "w") as f:
         f.write(
             "Golden vectors produced by `oracle/gen_golden.py` from the reference's own Python\n"

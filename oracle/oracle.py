@@ -53,6 +53,9 @@ def lib():
         l.saf_oracle_get_threads.restype = C.c_int
         l.saf_oracle_label_argmax.restype = C.c_int
         l.saf_oracle_label_argmax.argtypes = [vp, C.c_int64, C.c_int32, vp]
+        l.saf_oracle_label_components.restype = C.c_int
+        l.saf_oracle_label_components.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp,
+                                                  C.c_int32, vp, vp, vp]
         _lib = l
     return _lib
 
@@ -190,3 +193,22 @@ def label_argmax(labels_one_hot):
     out = torch.zeros(lab.shape[0], dtype=torch.int32)
     assert lib().saf_oracle_label_argmax(_abi.ptr(lab), lab.shape[0], lab.shape[1], _abi.ptr(out)) == 0
     return out
+
+
+def label_components(labels_grid, null_class=133, min_voxels=3, max_objects=None):
+    """flood_fill_3d's object discovery (handy_utils.py:295-480 without a trained in-situ model):
+    (voxel_obj_ids int32[nx,ny,nz], first_voxel[k], class[k], count[k])."""
+    lab = torch.as_tensor(labels_grid, dtype=torch.int32).contiguous()
+    nx, ny, nz = lab.shape
+    n = lab.numel()
+    mo = n if max_objects is None else max_objects
+    ids = torch.empty(n, dtype=torch.int32)
+    nobj = torch.zeros(1, dtype=torch.int32)
+    first = torch.zeros(mo, dtype=torch.int32)
+    cls = torch.zeros(mo, dtype=torch.int32)
+    cnt = torch.zeros(mo, dtype=torch.int32)
+    rc = lib().saf_oracle_label_components(_abi.ptr(lab), nx, ny, nz, null_class, min_voxels, _abi.ptr(ids), _abi.ptr(nobj),
+                                           mo, _abi.ptr(first), _abi.ptr(cls), _abi.ptr(cnt))
+    assert rc == 0
+    k = min(int(nobj[0]), mo)
+    return ids.view(nx, ny, nz), first[:k], cls[:k], cnt[:k]

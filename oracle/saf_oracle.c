@@ -511,3 +511,66 @@ int saf_oracle_sample_vertices(const saf_volume* v, const float* verts, int64_t 
   }
   return SAF_OK;
 }
+
+/* ---- flood_fill_3d's object discovery (handy_utils.py:295-480) ----
+ * Restated as the reference walks: raster order over (x, y, z) (:368-370); visited voxels are skipped
+ * (:375-377); the null class and empty voxels start no object (:383); a depth-first flood fill over the 26
+ * neighbours collects the voxels of the same class (:312-344); objects of fewer than `min_voxels` voxels
+ * are dropped (:390-392); the k-th accepted object gets voxel_obj_ids = -2 - k (:352-353, :447-450, no
+ * trained in-situ model). */
+int saf_oracle_label_components(const int32_t* labels, int32_t nx, int32_t ny, int32_t nz, int32_t null_class,
+                                int32_t min_voxels, int32_t* obj_ids, int32_t* n_objects, int32_t max_objects,
+                                int32_t* obj_first, int32_t* obj_class, int32_t* obj_count) {
+  const int64_t n = (int64_t)nx * ny * nz;
+  uint8_t* visited = (uint8_t*)calloc((size_t)n, 1); /* the reference's visited_voxels */
+  uint8_t* seen = (uint8_t*)calloc((size_t)n, 1);    /* flood_fill's own `visited` set, cleared per fill */
+  int32_t* stack = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n * 26 + 1));
+  int32_t* object_voxels = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  int32_t* touched = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  if (!visited || !seen || !stack || !object_voxels || !touched) return SAF_E_INVALID;
+  for (int64_t i = 0; i < n; ++i) obj_ids[i] = -1;
+  int32_t k = 0;
+  for (int32_t x = 0; x < nx; ++x)
+    for (int32_t y = 0; y < ny; ++y)
+      for (int32_t z = 0; z < nz; ++z) {
+        const int32_t i = (x * ny + y) * nz + z;
+        const int32_t class_id = labels[i];
+        if (visited[i]) continue;
+        visited[i] = 1;
+        if (class_id == null_class || class_id == -1) continue;
+        /* flood_fill((x, y, z), class_id) */
+        int64_t sp = 0, n_obj = 0, n_touched = 0;
+        stack[sp++] = i;
+        while (sp) {
+          const int32_t cur = stack[--sp];
+          if (seen[cur]) continue;
+          seen[cur] = 1;
+          touched[n_touched++] = cur;
+          if (labels[cur] != class_id) continue;
+          object_voxels[n_obj++] = cur;
+          const int32_t cz = cur % nz, cy = (cur / nz) % ny, cx = cur / (nz * ny);
+          for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+              for (int dz = -1; dz <= 1; ++dz) {
+                if (!dx && !dy && !dz) continue;
+                const int32_t xx = cx + dx, yy = cy + dy, zz = cz + dz;
+                if (xx < 0 || xx >= nx || yy < 0 || yy >= ny || zz < 0 || zz >= nz) continue;
+                const int32_t j = (xx * ny + yy) * nz + zz;
+                if (!seen[j]) stack[sp++] = j; /* the reference pushes visited ones too and skips them on pop */
+              }
+        }
+        for (int64_t t = 0; t < n_touched; ++t) seen[touched[t]] = 0;
+        for (int64_t t = 0; t < n_obj; ++t) visited[object_voxels[t]] = 1;
+        if (n_obj < min_voxels) continue;
+        for (int64_t t = 0; t < n_obj; ++t) obj_ids[object_voxels[t]] = -2 - k;
+        if (k < max_objects) {
+          if (obj_first) obj_first[k] = i;
+          if (obj_class) obj_class[k] = class_id;
+          if (obj_count) obj_count[k] = (int32_t)n_obj;
+        }
+        ++k;
+      }
+  *n_objects = k;
+  free(visited); free(seen); free(stack); free(object_voxels); free(touched);
+  return SAF_OK;
+}

@@ -15,6 +15,8 @@ __all__ = [
     "backproject_pcd",
     "get_pix_vecs",
     "scene_bounds",
+    "label_components",
+    "discover_objects",
 ]
 
 
@@ -23,7 +25,7 @@ def __getattr__(name):
         from . import clipfusion as _m
 
         return getattr(_m, name)
-    if name in ("ClipSeemFusion",):
+    if name in ("ClipSeemFusion", "label_components", "discover_objects"):
         from . import clip_seem_fusion as _m
 
         return getattr(_m, name)

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _abi
-from ._lib import check, current_stream_ptr, lib, require_cuda
+from ._lib import SafError, check, current_stream_ptr, lib, require_cuda
 from .clipfusion import _FusionVolumeMixin, _query_scan
 
 N_PANOPTIC_SLOTS = 133 + 10  # clip_seem_fusion.py:655 -- 133 COCO panoptic classes, null = 133, spare slots
@@ -88,6 +88,74 @@ def argmax_with_check(labels_one_hot):
         rc = lib().saf_label_argmax(lab.data_ptr(), lab.shape[0], lab.shape[1], out.data_ptr(), current_stream_ptr())
     check(rc, "saf_label_argmax")
     return out.long()
+
+
+def label_components(labels_grid, null_class=133, min_voxels=3):
+    """The object discovery of ``flood_fill_3d`` (handy_utils.py:295-480, no trained in-situ model) on the
+    HIP device: 26-connected components of equal class over the label grid ``[nx,ny,nz]`` (the reshaped
+    output of ``argmax_with_check``, clip_seem_fusion.py:322-338), the null class and empty voxels (-1)
+    excluded, objects of fewer than ``min_voxels`` voxels rejected.
+
+    Returns ``(voxel_obj_idx int32[nx,ny,nz], first_voxel int32[K], class_id int32[K], count int32[K])``:
+    ``voxel_obj_idx`` is the reference's ``voxel_obj_ids`` (-1, or -2 - k for the k-th object in raster
+    order of its first voxel, handy_utils.py:352-353, :447-450)."""
+    require_cuda(labels_grid, "labels_grid")
+    if labels_grid.dim() != 3:
+        raise SafError(f"labels_grid must be [nx,ny,nz], got {tuple(labels_grid.shape)}")
+    lab = labels_grid.to(torch.int32).contiguous()
+    nx, ny, nz = (int(v) for v in lab.shape)
+    n = lab.numel()
+    dev = lab.device
+    L = lib()
+    ws = torch.empty(L.saf_label_components_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    ids = torch.empty(n, dtype=torch.int32, device=dev)
+    nobj = torch.zeros(1, dtype=torch.int32, device=dev)
+    # an object has >= min_voxels voxels: at most n // min_voxels objects
+    cap = max(1, n // max(1, int(min_voxels)))
+    first = torch.empty(cap, dtype=torch.int32, device=dev)
+    cls = torch.empty(cap, dtype=torch.int32, device=dev)
+    cnt = torch.empty(cap, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.saf_label_components(lab.data_ptr(), nx, ny, nz, int(null_class), int(min_voxels), ids.data_ptr(),
+                                    nobj.data_ptr(), cap, first.data_ptr(), cls.data_ptr(), cnt.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), current_stream_ptr())
+    check(rc, "saf_label_components")
+    k = int(nobj.item())
+    return ids.view(nx, ny, nz), first[:k], cls[:k], cnt[:k]
+
+
+def discover_objects(labels_grid, class_names, class_colors=None, null_class=133, min_voxels=3):
+    """``scene_knowledge["unique_objects"]`` / ``["object_counts"]`` and ``voxel_obj_idx`` as
+    ``flood_fill_3d`` builds them for a first scan (no in-situ model; handy_utils.py:244-292, :352-353,
+    :430-452, :483-498): ids ``"<class label>:<running count>"`` in raster order of the objects' first
+    voxels.  ``voxels`` holds each object's voxel coordinates in raster order (the reference lists them
+    in flood-fill visiting order)."""
+    voxel_obj_idx, first, cls, cnt = label_components(labels_grid, null_class, min_voxels)
+    unique_objects, object_counts = {}, {}
+    flat = voxel_obj_idx.reshape(-1)
+    order = torch.argsort(-flat.long(), stable=True)  # -1 (none) first, then object 0, 1, ... each in raster order
+    n_none = int((flat == -1).sum())
+    order = order[n_none:]
+    ny, nz = int(labels_grid.shape[1]), int(labels_grid.shape[2])
+    coords = torch.stack((order // (ny * nz), (order // nz) % ny, order % nz), dim=1).cpu().numpy()
+    offs = np.concatenate(([0], np.cumsum(cnt.cpu().numpy())))
+    cls_h = cls.cpu().tolist()
+    for k, class_id in enumerate(cls_h):
+        class_label = class_names[class_id]
+        object_counts[class_label] = object_counts.get(class_label, 0) + 1
+        obj_id = f"{class_label}:{object_counts[class_label]}"
+        unique_objects[obj_id] = {
+            "class_id": class_id,
+            "class_label": class_label,
+            "voxels": [tuple(int(c) for c in v) for v in coords[offs[k]:offs[k + 1]]],
+            "object_index": -2 - k,
+            "gt_label": obj_id,
+            "user_modified": False,
+            "merged": False,
+            "removed": False,
+            "color": None if class_colors is None else class_colors[class_id],
+        }
+    return {"unique_objects": unique_objects, "object_counts": object_counts}, voxel_obj_idx
 
 
 class TextQueryEngine:

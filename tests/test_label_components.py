@@ -1,0 +1,172 @@
+"""the connected-component core of flood_fill_3d (handy_utils.py:295-480).
+
+Pinned: tests/golden/label_components.npz holds label grids and the outputs of the reference's own
+flood_fill_3d (first scan, no trained in-situ model; oracle/gen_golden.py).  The C restatement in
+oracle/saf_oracle.c is checked against those goldens and against a second, independent walk written from
+the same reference lines (below); the HIP kernel against the goldens and the restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _walk(labels, null_class=133, min_voxels=3):
+    """handy_utils.py:348-452 for the no-in-situ-model case, on a small numpy grid: raster scan, DFS over the
+    26 neighbours, size filter, ids -2, -3, ..."""
+    nx, ny, nz = labels.shape
+    visited = set()
+    ids = -np.ones(labels.shape, dtype=np.int32)
+    objects = []
+    next_index = -2
+    for x in range(nx):
+        for y in range(ny):
+            for z in range(nz):
+                c = int(labels[x, y, z])
+                if (x, y, z) in visited:
+                    continue
+                visited.add((x, y, z))
+                if c == null_class or c == -1:
+                    continue
+                stack, seen, vox = [(x, y, z)], set(), []
+                while stack:
+                    cur = stack.pop()
+                    if cur in seen:
+                        continue
+                    seen.add(cur)
+                    if labels[cur] == c:
+                        vox.append(cur)
+                        cx, cy, cz = cur
+                        for dx in (-1, 0, 1):
+                            for dy in (-1, 0, 1):
+                                for dz in (-1, 0, 1):
+                                    if dx == dy == dz == 0:
+                                        continue
+                                    q = (cx + dx, cy + dy, cz + dz)
+                                    if 0 <= q[0] < nx and 0 <= q[1] < ny and 0 <= q[2] < nz:
+                                        stack.append(q)
+                visited.update(vox)
+                if len(vox) < min_voxels:
+                    continue
+                for v in vox:
+                    ids[v] = next_index
+                objects.append(((x * ny + y) * nz + z, c, len(vox)))
+                next_index -= 1
+    return ids, objects
+
+
+def _random_labels(seed, shape, n_classes=4, p_empty=0.3, p_null=0.1):
+    g = np.random.default_rng(seed)
+    lab = g.integers(0, n_classes, size=shape).astype(np.int32)
+    r = g.random(shape)
+    lab[r < p_empty] = -1
+    lab[(r >= p_empty) & (r < p_empty + p_null)] = 133
+    return lab
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+
+    return O
+
+
+def _golden_cases():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "label_components.npz"))
+    return g, int(g["n_cases"])
+
+
+def test_oracle_matches_reference_goldens(oracle):
+    g, n = _golden_cases()
+    assert n >= 5
+    for c in range(n):
+        ids, first, cls, cnt = oracle.label_components(g[f"c{c}_labels"])
+        assert np.array_equal(ids.numpy(), g[f"c{c}_voxel_obj_ids"]), f"case {c}"
+        assert np.array_equal(-2 - np.arange(len(first)), g[f"c{c}_object_index"])
+        assert np.array_equal(first.numpy(), g[f"c{c}_first"]) and np.array_equal(cls.numpy(), g[f"c{c}_class_id"])
+        assert np.array_equal(cnt.numpy(), g[f"c{c}_count"])
+
+
+@pytest.mark.gpu
+def test_hip_components_match_reference_goldens():
+    from spatially_aware_ai_amd import discover_objects, label_components
+
+    g, n = _golden_cases()
+    for c in range(n):
+        lab = torch.from_numpy(g[f"c{c}_labels"]).cuda()
+        ids, first, cls, cnt = label_components(lab)
+        assert np.array_equal(ids.cpu().numpy(), g[f"c{c}_voxel_obj_ids"]), f"case {c}"
+        assert np.array_equal(first.cpu().numpy(), g[f"c{c}_first"]) and np.array_equal(cls.cpu().numpy(), g[f"c{c}_class_id"])
+        assert np.array_equal(cnt.cpu().numpy(), g[f"c{c}_count"])
+        know, _ = discover_objects(lab, [str(s) for s in g[f"c{c}_class_names"]])
+        assert list(know["unique_objects"].keys()) == [str(s) for s in g[f"c{c}_ids"]]
+        assert [o["object_index"] for o in know["unique_objects"].values()] == g[f"c{c}_object_index"].tolist()
+
+
+@pytest.mark.parametrize("seed,shape,ncls,min_vox", [(0, (5, 6, 7), 3, 3), (1, (8, 3, 9), 2, 3), (2, (4, 4, 4), 6, 1),
+                                                     (3, (9, 9, 2), 2, 5), (4, (1, 1, 12), 2, 3)])
+def test_oracle_matches_independent_walk(oracle, seed, shape, ncls, min_vox):
+    lab = _random_labels(seed, shape, ncls)
+    ids, first, cls, cnt = oracle.label_components(lab, 133, min_vox)
+    ref_ids, ref_obj = _walk(lab, 133, min_vox)
+    assert np.array_equal(ids.numpy(), ref_ids)
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(first, cls, cnt)] == ref_obj
+
+
+def test_oracle_edge_cases(oracle):
+    empty = -np.ones((3, 4, 5), dtype=np.int32)
+    ids, first, _, _ = oracle.label_components(empty)
+    assert int((ids != -1).sum()) == 0 and len(first) == 0
+    one = np.full((3, 4, 5), 7, dtype=np.int32)
+    ids, first, cls, cnt = oracle.label_components(one)
+    assert int((ids != -2).sum()) == 0 and first.tolist() == [0] and cls.tolist() == [7] and cnt.tolist() == [60]
+    # two voxels touching only at a corner are one object (26-connectivity); a pair is below the size limit
+    lab = -np.ones((5, 5, 5), dtype=np.int32)
+    lab[0, 0, 0] = lab[1, 1, 1] = lab[2, 2, 2] = 4
+    lab[4, 0, 0] = lab[4, 0, 1] = 4
+    ids, first, cls, cnt = oracle.label_components(lab)
+    assert cnt.tolist() == [3] and ids[4, 0, 0] == -1 and ids[1, 1, 1] == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,shape,ncls,min_vox", [(10, (33, 30, 41), 3, 3), (11, (64, 64, 64), 2, 3), (12, (7, 5, 300), 5, 1),
+                                                     (13, (40, 40, 40), 1, 3), (14, (16, 16, 16), 20, 2)])
+def test_hip_components_match_oracle(oracle, seed, shape, ncls, min_vox):
+    from spatially_aware_ai_amd import label_components
+
+    lab = _random_labels(seed, shape, ncls, p_empty=0.45 if ncls <= 2 else 0.3)
+    ids, first, cls, cnt = oracle.label_components(lab, 133, min_vox)
+    g_ids, g_first, g_cls, g_cnt = label_components(torch.from_numpy(lab).cuda(), 133, min_vox)
+    assert torch.equal(g_ids.cpu(), ids)
+    assert torch.equal(g_first.cpu(), first) and torch.equal(g_cls.cpu(), cls) and torch.equal(g_cnt.cpu(), cnt)
+
+
+@pytest.mark.gpu
+def test_hip_components_edge_cases_and_objects(oracle):
+    from spatially_aware_ai_amd import discover_objects, label_components
+
+    empty = torch.full((6, 7, 8), -1, dtype=torch.int32, device="cuda")
+    ids, first, _, _ = label_components(empty)
+    assert int((ids != -1).sum()) == 0 and first.numel() == 0
+    one = torch.full((6, 7, 8), 2, dtype=torch.int32, device="cuda")
+    ids, first, cls, cnt = label_components(one)
+    assert int((ids != -2).sum()) == 0 and cnt.tolist() == [6 * 7 * 8]
+    # a long snake: a single component whose union-find chains are as deep as they get
+    lab = torch.full((4, 4, 200), -1, dtype=torch.int32)
+    lab[1, 2, :] = 9
+    lab[1:4, 2, 199] = 9
+    lab[3, 2, :] = 9
+    ids, first, cls, cnt = label_components(lab.cuda())
+    assert cnt.tolist() == [401] and cls.tolist() == [9] and first.tolist() == [(1 * 4 + 2) * 200]
+    names = [f"class{i}" for i in range(134)]
+    lab = torch.from_numpy(_random_labels(5, (12, 10, 14), 3))
+    know, voxel_obj_idx = discover_objects(lab.cuda(), names)
+    o_ids, o_first, o_cls, o_cnt = oracle.label_components(lab.numpy())
+    assert torch.equal(voxel_obj_idx.cpu(), o_ids)
+    objs = know["unique_objects"]
+    assert len(objs) == len(o_first) and sum(know["object_counts"].values()) == len(o_first)
+    for k, (oid, o) in enumerate(objs.items()):  # dict order = discovery order, as in the reference
+        assert o["object_index"] == -2 - k and o["class_id"] == int(o_cls[k]) and len(o["voxels"]) == int(o_cnt[k])
+        x, y, z = o["voxels"][0]
+        assert (x * 10 + y) * 14 + z == int(o_first[k])
+        assert oid == f"{names[o['class_id']]}:{oid.split(':')[1]}"
