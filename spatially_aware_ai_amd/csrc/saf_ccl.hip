@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void ccl_jump_kernel(int n, int* __restrict__ 
   if (gp != p) __hip_atomic_store(parent + i, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void ccl_flatten_kernel(int n, int* __restrict__ parent, int* __restrict__ count) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+constexpr int kCclSlots = 64;
+__global__ __launch_bounds__(1024) void ccl_flatten_kernel(int n, int* __restrict__ parent, int* __restrict__ count) {
+  const int i = blockIdx.x * 1024 + threadIdx.x;
   int r = -1;
   if (i < n && ld_parent(parent, i) >= 0) {
     r = find_halving(parent, i);
@@ -111,16 +112,41 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(int n, int* __restrict
     // so writing it cannot turn another voxel's chain into a cycle)
     __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // size count, aggregated per wave: neighbouring voxels mostly share their root, and a large object would
-  // otherwise serialise hundreds of thousands of atomics on one address
+  // size count, aggregated per workgroup: neighbouring voxels mostly share their root, and a large object
+  // would otherwise serialise hundreds of thousands of atomics on one address.  Per wave the lanes of one
+  // root elect a leader (ballots); the leaders then merge through a small LDS table (linear probing) and
+  // each distinct root of the workgroup costs one global atomic.
+  __shared__ int s_key[kCclSlots], s_val[kCclSlots];
+  for (int k = threadIdx.x; k < kCclSlots; k += 1024) {
+    s_key[k] = -1;
+    s_val[k] = 0;
+  }
+  __syncthreads();
   unsigned long long todo = __ballot(r >= 0);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int r0 = __builtin_amdgcn_readlane(r, leader);
     const unsigned long long same = __ballot(r == r0);
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&count[r0], __popcll(same));
+    if ((int)(threadIdx.x & 63) == leader) {
+      const int add = __popcll(same);
+      unsigned slot = ((unsigned)r0 * 2654435761u) % kCclSlots;
+      bool placed = false;
+      for (int probe = 0; probe < kCclSlots; ++probe) {
+        const int old = atomicCAS(&s_key[slot], -1, r0);
+        if (old == -1 || old == r0) {
+          atomicAdd(&s_val[slot], add);
+          placed = true;
+          break;
+        }
+        slot = (slot + 1) % kCclSlots;
+      }
+      if (!placed) atomicAdd(&count[r0], add);  // table full (more distinct roots than slots): go direct
+    }
     todo &= ~same;
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kCclSlots; k += 1024)
+    if (s_key[k] >= 0) atomicAdd(&count[s_key[k]], s_val[k]);
 }
 
 __global__ __launch_bounds__(256) void ccl_flag_kernel(int n, const int* __restrict__ parent, const int* __restrict__ count,
@@ -199,7 +225,7 @@ int saf_label_components(const int32_t* labels, int32_t nx, int32_t ny, int32_t 
   hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks), dim3(256), 0, s, labels, n, null_class, parent, count);
   hipLaunchKernelGGL(ccl_union_kernel, dim3(blocks), dim3(256), 0, s, labels, nx, ny, nz, null_class, parent);
   for (int round = 0; round < 4; ++round) hipLaunchKernelGGL(ccl_jump_kernel, dim3(blocks), dim3(256), 0, s, n, parent);
-  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(blocks), dim3(256), 0, s, n, parent, count);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, n, parent, count);
   hipLaunchKernelGGL(ccl_flag_kernel, dim3(blocks), dim3(256), 0, s, n, parent, count, min_voxels, flag);
   int rc = check_launch("ccl kernels");
   if (rc) return rc;
