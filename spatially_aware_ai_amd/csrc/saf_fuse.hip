@@ -1148,12 +1148,26 @@ struct WinCtx {
   int img_vecs, DV, npx, npy, zero_row, lane;
   float4* rows;
 };
+// Channel chunk c of a lane (a float4 of the D-channel map row).  f32 volume: lane + 64 c.  bf16 volume:
+// a lane's 16-byte row unit holds 8 channels = chunks 2 (lane + 64 (c / 2)) + c % 2.
+template <bool BF16>
+__device__ __forceinline__ constexpr int win_chunk_off(int c) {
+  return BF16 ? (c >> 1) * 128 + (c & 1) : c * 64;
+}
+// bf16 volume: the rows of a sub-chunk travel through registers (16 bytes = 8 channels per lane and unit)
+// and are widened into the f32 LDS rows once they have landed.
+template <int SR, int UPL>
+struct WinRaw {
+  uint4 u[SR * UPL];
+  int nrows;
+};
+__device__ __forceinline__ float bf16_round(float x) { return bf16_lo(f32_to_bf16_bits(x)); }
 
 // NB groups: request the four map rows of every group, then blend group after group into the LDS rows
 // (the waits are counted: group u is processed while the rows of groups u+1.. are still in flight).
-template <int NB, int CPL, bool SUM>
+template <int NB, int CPL, bool SUM, bool BF16, int SR>
 __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, uint32_t gk, uint32_t gm_lo, uint32_t gm_hi,
-                                          const WinHit& rec) {
+                                          const WinHit& rec, const WinRaw<SR, BF16 ? CPL / 2 : 1>& raw) {
   float4 tp[NB][4][CPL];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
@@ -1165,19 +1179,33 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, uint32_
     const int o_ne = (x1ok && y0ok) ? y0 * cx.npx + x0 + 1 : cx.zero_row;
     const int o_sw = (x0ok && y1ok) ? (y0 + 1) * cx.npx + x0 : cx.zero_row;
     const int o_se = (x1ok && y1ok) ? (y0 + 1) * cx.npx + x0 + 1 : cx.zero_row;
-    const float4* img = cx.imgs + (int64_t)fb * cx.img_vecs + cx.lane;
+    const float4* img = cx.imgs + (int64_t)fb * cx.img_vecs + (BF16 ? 2 * cx.lane : cx.lane);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      tp[u][0][c] = img[o_nw * cx.DV + c * 64];
-      tp[u][1][c] = img[o_ne * cx.DV + c * 64];
-      tp[u][2][c] = img[o_sw * cx.DV + c * 64];
-      tp[u][3][c] = img[o_se * cx.DV + c * 64];
+      tp[u][0][c] = img[o_nw * cx.DV + win_chunk_off<BF16>(c)];
+      tp[u][1][c] = img[o_ne * cx.DV + win_chunk_off<BF16>(c)];
+      tp[u][2][c] = img[o_sw * cx.DV + win_chunk_off<BF16>(c)];
+      tp[u][3][c] = img[o_se * cx.DV + win_chunk_off<BF16>(c)];
     }
   }
-  if (g0 == 0) {  // the sub-chunk's rows (LDS-DMA, issued before these loads) have landed after this
+  if (g0 == 0) {  // the sub-chunk's rows (issued before these loads) have landed after this
     // the BUILTIN, not inline asm: the compiler's wait-count pass must see that the LDS-DMA has been
     // waited for, or it drains vmcnt before every later LDS read (each row's store waited for the last)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
+    if (BF16) {
+      constexpr int UPL = CPL / 2;
+#pragma unroll
+      for (int r = 0; r < SR; ++r) {
+        if (r < raw.nrows) {
+#pragma unroll
+          for (int k = 0; k < UPL; ++k) {
+            const uint4 w = raw.u[r * UPL + k];
+            cx.rows[(r * CPL + 2 * k) * 64 + cx.lane] = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+            cx.rows[(r * CPL + 2 * k + 1) * 64 + cx.lane] = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
+          }
+        }
+      }
+    }
     wave_lds_sync();
   }
 #pragma unroll
@@ -1200,19 +1228,25 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, uint32_
       for (int c = 0; c < CPL; ++c) {
         float4* rp = cx.rows + (r * CPL + c) * 64 + cx.lane;
         const float4 sv = lerp_taps(tp[u][0][c], tp[u][1][c], tp[u][2][c], tp[u][3][c], w);
-        *rp = blend(sv, *rp, a, b, SUM);
+        float4 nv = blend(sv, *rp, a, b, SUM);
+        if (BF16) {  // the per-frame path stores bf16 after every hit: round to nearest even, keep as f32
+          nv.x = bf16_round(nv.x); nv.y = bf16_round(nv.y); nv.z = bf16_round(nv.z); nv.w = bf16_round(nv.w);
+        }
+        *rp = nv;
       }
     }
   }
 }
 
-template <int CPL, bool SUM>
+template <int CPL, bool SUM, bool BF16>
 __global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(SAF_WIN_WPE, SAF_WIN_WPE))) void
 fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int img_vecs,
                    unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
                    const uint32_t* __restrict__ hitmask) {
   using Cfg = WinCfg<CPL>;
-  constexpr int SR = Cfg::SR, P = Cfg::P;
+  constexpr int SR = Cfg::SR;
+  // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
+  constexpr int P = BF16 && Cfg::P > 2 ? Cfg::P - 1 : Cfg::P;
   extern __shared__ __align__(16) unsigned char s_dyn[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4* rows = reinterpret_cast<float4*>(s_dyn + Cfg::rows_off) + (size_t)wave * SR * CPL * 64;
@@ -1241,7 +1275,9 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
   int chs[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) chs[c] = lane + c * 64;
+  constexpr int UPL = BF16 ? CPL / 2 : 1;  // 16-byte units of a bf16 row per lane
   float4* feat = reinterpret_cast<float4*>(v.feat);
+  float4* featb = reinterpret_cast<float4*>(v.feat);  // bf16 volume: D / 8 units of 16 bytes per row
   const float4* imgs = reinterpret_cast<const float4*>(map_imgs);
   KFrame kf;  // per-hit view of a frame for the scalar side
   kf.H = wa.H; kf.W = wa.W; kf.npy = wa.npy; kf.npx = wa.npx; kf.rgb_bilinear = wa.rgb_bilinear;
@@ -1379,18 +1415,30 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
         //  read that follows an LDS-DMA, which would expose the rows' whole latency right here)
         // the rows, global -> LDS (one LDS-DMA moves a wave's 64 x 16 B = one 1 KiB piece of a row)
         uint32_t fmask = 0;  // frames with a hit in this sub-chunk
+        WinRaw<SR, UPL> raw;
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
           if (r < nrows) {
             const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
             fmask |= (uint32_t)__builtin_amdgcn_readlane((int)mk, i0 + r);
+            if (BF16) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + row + chs[c]),
-                                               (__attribute__((address_space(3))) void*)(rows + (r * CPL + c) * 64),
-                                               16, 0, 2);
+              for (int k = 0; k < UPL; ++k) {
+                const float4 t = ld_stream(featb + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * (DV / 2) +
+                                           lane + k * 64);
+                raw.u[r * UPL + k] = make_uint4(__builtin_bit_cast(uint32_t, t.x), __builtin_bit_cast(uint32_t, t.y),
+                                                __builtin_bit_cast(uint32_t, t.z), __builtin_bit_cast(uint32_t, t.w));
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < CPL; ++c)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + row + chs[c]),
+                                                 (__attribute__((address_space(3))) void*)(rows + (r * CPL + c) * 64),
+                                                 16, 0, 2);
+            }
           }
         }
+        raw.nrows = nrows;
         // groups = hits of one frame in one map cell, frames ascending (a row's hits stay in frame order);
         // group g is kept in lane g: its key and the lane mask of its members
         uint32_t gk = 0, gm_lo = 0, gm_hi = 0;
@@ -1417,12 +1465,12 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
         for (int g0 = 0; g0 < G; g0 += P) {
           const int nb = min(P, G - g0);
           switch (nb) {
-            case 1: win_batch<1, CPL, SUM>(cx, g0, gk, gm_lo, gm_hi, rec); break;
-            case 2: win_batch<(P >= 2 ? 2 : 1), CPL, SUM>(cx, g0, gk, gm_lo, gm_hi, rec); break;
-            case 3: win_batch<(P >= 3 ? 3 : 1), CPL, SUM>(cx, g0, gk, gm_lo, gm_hi, rec); break;
-            case 4: win_batch<(P >= 4 ? 4 : 1), CPL, SUM>(cx, g0, gk, gm_lo, gm_hi, rec); break;
-            case 5: win_batch<(P >= 5 ? 5 : 1), CPL, SUM>(cx, g0, gk, gm_lo, gm_hi, rec); break;
-            default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM>(cx, g0, gk, gm_lo, gm_hi, rec); break;
+            case 1: win_batch<1, CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
+            case 2: win_batch<(P >= 2 ? 2 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
+            case 3: win_batch<(P >= 3 ? 3 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
+            case 4: win_batch<(P >= 4 ? 4 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
+            case 5: win_batch<(P >= 5 ? 5 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
+            default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
           }
         }
         // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
@@ -1435,8 +1483,21 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
         for (int r = 0; r < SR; ++r) {
           if (r < nrows) {
             const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
+            if (BF16) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) st_stream(&feat[row + chs[c]], rows[(r * CPL + c) * 64 + lane]);
+              for (int k = 0; k < UPL; ++k) {
+                const float4 lo = rows[(r * CPL + 2 * k) * 64 + lane], hi = rows[(r * CPL + 2 * k + 1) * 64 + lane];
+                float4 o;  // the LDS values are bf16-exact already: the packing is lossless
+                o.x = __builtin_bit_cast(float, pack_bf16(lo.x, lo.y));
+                o.y = __builtin_bit_cast(float, pack_bf16(lo.z, lo.w));
+                o.z = __builtin_bit_cast(float, pack_bf16(hi.x, hi.y));
+                o.w = __builtin_bit_cast(float, pack_bf16(hi.z, hi.w));
+                st_stream(featb + (row / 2) + lane + k * 64, o);
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) st_stream(&feat[row + chs[c]], rows[(r * CPL + c) * 64 + lane]);
+            }
           }
         }
         wave_lds_sync();  // the row buffer is rewritten by the next sub-chunk
@@ -1695,14 +1756,24 @@ WinLayout win_layout(int64_t n_vox, int D, int P) {
 
 using WinFn = void (*)(KVol, WinArgs, const float*, int, unsigned long long*, unsigned int*, const uint32_t*);
 template <int CPL>
-WinFn pick_win(bool sum) {
-  return sum ? fuse_window_kernel<CPL, true> : fuse_window_kernel<CPL, false>;
+WinFn pick_win(bool sum, bool bf16) {
+  if (bf16) {
+    if (CPL % 2 != 0) return nullptr;
+    constexpr int C2 = CPL % 2 == 0 ? CPL : 2;
+    return sum ? fuse_window_kernel<C2, true, true> : fuse_window_kernel<C2, false, true>;
+  }
+  return sum ? fuse_window_kernel<CPL, true, false> : fuse_window_kernel<CPL, false, false>;
 }
 
 // Shapes the windowed path takes; everything else runs the per-frame pipeline.
 bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
   static const bool enabled = !(getenv("SAF_WINDOW") && getenv("SAF_WINDOW")[0] == '0');
-  if (!enabled || n_frames < kWinMinFrames || kv.bf16 || kv.D % 256 != 0 || kv.D > 1024) return false;
+  if (!enabled || n_frames < kWinMinFrames || kv.D % 256 != 0 || kv.D > 1024) return false;
+  // bf16 volumes: implemented and bit-identical, but no faster than the per-frame pipeline (rows are half
+  // the bytes, the map taps are not: 3527 vs 3685 frames/s with labels, 4310 vs 4055 on the coherent
+  // scene) -- opt-in with SAF_WINDOW_BF16=1
+  static const bool bf16_on = getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '1';
+  if (kv.bf16 && (!bf16_on || kv.D % 512 != 0)) return false;  // a lane moves 8 bf16 channels: 512 per wave
   const saf_frame& f0 = frames[0];
   for (int32_t i = 0; i < n_frames; ++i) {
     const saf_frame& f = frames[i];
@@ -1732,10 +1803,10 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   WinFn fn;
   size_t win_lds;
   switch (kv.D / 256) {
-    case 1: fn = pick_win<1>(sum); win_lds = WinCfg<1>::total; break;
-    case 2: fn = pick_win<2>(sum); win_lds = WinCfg<2>::total; break;
-    case 3: fn = pick_win<3>(sum); win_lds = WinCfg<3>::total; break;
-    default: fn = pick_win<4>(sum); win_lds = WinCfg<4>::total; break;
+    case 1: fn = pick_win<1>(sum, kv.bf16 != 0); win_lds = WinCfg<1>::total; break;
+    case 2: fn = pick_win<2>(sum, kv.bf16 != 0); win_lds = WinCfg<2>::total; break;
+    case 3: fn = pick_win<3>(sum, kv.bf16 != 0); win_lds = WinCfg<3>::total; break;
+    default: fn = pick_win<4>(sum, kv.bf16 != 0); win_lds = WinCfg<4>::total; break;
   }
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -6,6 +6,7 @@ Bar: index sets (weight, tsdf_weight, label histogram, argmax) bit-exact; fp32 b
 1e-4 relative."""
 import os
 
+os.environ.setdefault("SAF_WINDOW_BF16", "1")  # the opt-in bf16 variant of the windowed path is tested too (read once by the library)
 import numpy as np
 import pytest
 import torch
@@ -356,12 +357,18 @@ def test_extract_mesh_vertex_sampling_golden(golden_dir):
             np.testing.assert_allclose(out[5].cpu().numpy(), g["seem_vertex_segment_color"], rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("dim,seem,accum,n_frames,nvox", [
-    (512, True, _abi.SAF_RUNNING_MEAN, 40, (33, 30, 41)), (256, False, _abi.SAF_RUNNING_MEAN, 33, (33, 30, 41)),
-    (768, False, _abi.SAF_SUM, 19, (33, 30, 41)), (1024, True, _abi.SAF_RUNNING_MEAN, 15, (33, 30, 41)),
+@pytest.mark.parametrize("dim,seem,accum,n_frames,nvox,fdt", [
+    (512, True, _abi.SAF_RUNNING_MEAN, 40, (33, 30, 41), torch.float32),
+    (256, False, _abi.SAF_RUNNING_MEAN, 33, (33, 30, 41), torch.float32),
+    (768, False, _abi.SAF_SUM, 19, (33, 30, 41), torch.float32),
+    (1024, True, _abi.SAF_RUNNING_MEAN, 15, (33, 30, 41), torch.float32),
     # ny*nz a multiple of 256 and nx a multiple of 16: the classification walks the grid in 16x16 tiles
-    (256, False, _abi.SAF_RUNNING_MEAN, 35, (64, 64, 64)), (512, True, _abi.SAF_RUNNING_MEAN, 17, (32, 16, 128))])
-def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_frames, nvox):
+    (256, False, _abi.SAF_RUNNING_MEAN, 35, (64, 64, 64), torch.float32),
+    (512, True, _abi.SAF_RUNNING_MEAN, 17, (32, 16, 128), torch.float32),
+    # bf16 volumes (BASELINE config 3): every hit rounds to bf16, so the stored bits must be identical too
+    (512, True, _abi.SAF_RUNNING_MEAN, 36, (33, 30, 41), torch.bfloat16),
+    (1024, False, _abi.SAF_SUM, 17, (33, 30, 41), torch.bfloat16)])
+def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_frames, nvox, fdt):
     """saf_fuse_frames with >= 16 frames of a 256-multiple feature dim takes the windowed voxel-major path
     (one kernel per window of 32 frames: classification, TSDF, and one row read + write per touched voxel,
     hits applied in frame order).  It must reproduce the frame-by-frame path BIT FOR BIT on every buffer,
@@ -388,10 +395,10 @@ def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_
         clip, seg = FakeClip(dim), FakeSeg()
         if seem:
             fz = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, 10, 10, clip, seg,
-                                keep_xyz_world=False).cuda()
+                                keep_xyz_world=False, feat_dtype=fdt).cuda()
         else:
             fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, 10, 10,
-                            keep_xyz_world=False).cuda()
+                            keep_xyz_world=False, feat_dtype=fdt).cuda()
         fz.accum_mode = accum
         return fz
 
@@ -411,10 +418,15 @@ def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_
     assert s1 == s2, (s1, s2)
     assert int(win.fuse_stats[5]) > 0, "the windowed kernel did not run"
     assert int(win.fuse_stats[5]) < s2["valid"], "no voxel was hit twice inside a window: the test is too weak"
-    vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, dim, 143 if seem else 0, accum)
+    vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, dim, 143 if seem else 0, accum,
+                              feat_dtype=fdt)
     vol.integrate(cat("depth", frames).cpu(), cat("rgb", frames).cpu(), cat("pose", frames).cpu(), cat("K", frames).cpu(),
                   cat("feat", frames).cpu(), [l.cpu() for l in labs(frames)] if seem else None, rgb_bilinear=seem)
-    _assert_same(vol, win, seem)
+    if fdt == torch.bfloat16:
+        assert torch.equal(win.weight.cpu(), vol.weight) and torch.equal(win.tsdf_weight.cpu(), vol.tsdf_weight)
+        assert torch.equal(win.clip_feat.cpu().view(torch.int16), vol.clip_feat.view(torch.int16)), "bf16 bits differ"
+    else:
+        _assert_same(vol, win, seem)
 
 
 def test_sum_mode_and_finalize(oracle):
