@@ -585,3 +585,39 @@ def test_full_size_properties_128():
     assert torch.equal(fusion2.weight, 2 * w1)
     torch.testing.assert_close(fusion2.clip_feat, c1, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(fusion2.tsdf, t1, rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_windowed_equals_per_frame_256():
+    """BASELINE configs 3/4 grid at FULL size (256^3 x 512 fp32, 640x480): the windowed path (one call, 32-frame
+    windows, tile-ordered classification) against the per-frame pipeline (calls of 8 frames) -- every buffer
+    of the 34 GB volume bit for bit -- plus the size-independent properties."""
+    from spatially_aware_ai_amd import ClipFusion
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90e9:
+        pytest.skip("needs ~80 GB of device memory for two full-size volumes")
+    w, h, d, n_frames = 640, 480, 512, 40
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid(256)
+    frames = syn.make_frames(77, n_frames - 8, width=w, height=h, feat_dim=d, npy=npy, npx=npx, depth_kind="A")
+    frames += syn.make_frames(78, 8, width=w, height=h, feat_dim=d, npy=npy, npx=npx, depth_kind="B", missing_depth_frac=0.1)
+    clip = FakeClip(d)
+    cat = lambda k, fs: torch.cat([f[k] for f in fs]).cuda()
+    build = lambda: ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, 160, 80,
+                               keep_xyz_world=False).cuda()
+    one = build()
+    for s0 in range(0, n_frames, 8):  # < 16 frames per call: the per-frame pipeline
+        fs = frames[s0:s0 + 8]
+        one.integrate_features(cat("depth", fs), cat("rgb", fs), cat("pose", fs), cat("K", fs), cat("feat", fs))
+    win = build()
+    win.integrate_features(cat("depth", frames), cat("rgb", frames), cat("pose", frames), cat("K", frames), cat("feat", frames))
+    s1, s2 = one.stats(), win.stats()
+    assert s1["window_rows"] == 0 and 0 < s2["window_rows"] < s2["valid"]
+    for k in ("valid", "tsdf_valid", "frames"):
+        assert s1[k] == s2[k], (k, s1[k], s2[k])
+    for name in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat"):
+        assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs between the two paths at full size"
+    assert int(win.weight.sum()) == s2["valid"] and int(win.tsdf_weight.sum()) == s2["tsdf_valid"]
+    assert float(win.clip_feat[win.weight == 0].abs().max()) == 0.0
+    fmax = max(float(f["feat"].abs().max()) for f in frames)
+    assert float(win.clip_feat.abs().max()) <= fmax * (1 + 1e-5) and float(win.tsdf.abs().max()) <= 1.0
