@@ -976,9 +976,7 @@ struct WinCfg {
   static constexpr size_t tm_bytes = (size_t)kWinWaves * kPiece * 4;
   static constexpr size_t tv_off = tm_off + tm_bytes;
   static constexpr size_t tv_bytes = (size_t)kWinWaves * kPiece * 2;
-  static constexpr size_t sort_off = tv_off + tv_bytes;
-  static constexpr size_t sort_bytes = (size_t)kWinWaves * 64 * 4;
-  static constexpr size_t ptr_off = sort_off + sort_bytes;
+  static constexpr size_t ptr_off = tv_off + tv_bytes;
   static constexpr size_t ptr_bytes = (size_t)2 * kWin * sizeof(const float*);
   static constexpr size_t cam_off = ptr_off + ptr_bytes;
   static constexpr size_t total = cam_off + (size_t)kWin * sizeof(Cam);
@@ -1285,8 +1283,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
   unsigned long long hits_done = 0, rows_done = 0;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   WT_DECL;
-  // persistent grid (2 workgroups per CU): the other half of every CU stays free for the sweeps of
-  // the next window, which run concurrently on the auxiliary stream.  Pieces are handed out by an
+  // persistent grid (2 workgroups of 4 waves per CU, 71 KB of LDS each).  Pieces are handed out by an
   // atomic counter: a coherent scene concentrates its hits in few pieces (a wall = whole columns).
   const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
   for (;;) {
@@ -1899,7 +1896,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_win_t), sizeof(t)) == hipSuccess) {
       unsigned long long tot = 0;
       for (int k = 0; k < 8; ++k) tot += t[k];
-      fprintf(stderr, "[win timing] classify %.1f%% expand %.1f%% project %.1f%% scalars %.1f%% group %.1f%% - %.1f%% batches %.1f%% store %.1f%% (total %.3g wave-cycles)\n",
+      fprintf(stderr, "[win timing] masks %.1f%% expand %.1f%% project %.1f%% scalars %.1f%% records+groups+row issue %.1f%% - %.1f%% tap batches %.1f%% row store %.1f%% (total %.3g wave-cycles)\n",
               100.0 * t[0] / tot, 100.0 * t[1] / tot, 100.0 * t[2] / tot, 100.0 * t[3] / tot, 100.0 * t[4] / tot,
               100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, (double)tot);
       memset(t, 0, sizeof(t));
