@@ -35,6 +35,7 @@ from spatially_aware_ai_amd import _abi  # noqa: E402
 from spatially_aware_ai_amd import synthetic as syn  # noqa: E402
 from spatially_aware_ai_amd._lib import check, lib  # noqa: E402
 
+WIN = 64  # frames per window of the windowed path (include/saf.h SAF_WINDOW_FRAMES)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 
 
@@ -257,12 +258,12 @@ def main():
         lab = 8 if a.labels else 0  # one label counter RMW per valid voxel
         windowed = st.get("window_rows", 0) > 0
         if windowed:
-            # SURVEY.md §8d, launches covering a frame set S (a window of up to 32 frames):
+            # SURVEY.md §8d, launches covering a frame set S (a window of up to WIN = 64 frames):
             # B_fuse(S) = U_v*(2*D*s + 2*12 + 2*4 [+2*4]) + U_t*(2*4 + 2*4) + sum_f (H*W*(4+12[+4]) + D*npy*npx*4)
             # with U_v = rows the window read-modify-wrote, U_t = voxels whose TSDF it updated (kernel counters).
             # fuse_window_kernel's share: the rows, rgb / weight / label side, rgb + label images and the maps;
             # classify_window_kernel's share: the TSDF term and the depth images.
-            n_windows = (a.frames + 31) // 32 * a.steps
+            n_windows = (a.frames + WIN - 1) // WIN * a.steps
             uv = st["window_rows"] / n_windows
             ut = st["window_tsdf_voxels"] / n_windows
             fpl = a.frames * a.steps / n_windows  # frames per launch
@@ -287,7 +288,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if (tj.get("grid") == a.grid and tj.get("dim") == a.dim and tj.get("depth_kind", "A") == a.depth_kind
-                        and tj.get("frames_per_launch", 1) == (32 if windowed else 1)):
+                        and tj.get("frames_per_launch", 1) == (WIN if windowed else 1)):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -303,7 +304,7 @@ def main():
             roofline["rows_per_launch"] = round(uv, 1)
             roofline["tsdf_voxels_per_launch"] = round(ut, 1)
             roofline["hits_per_row"] = round(st["valid"] / max(1, st["window_rows"]), 3)
-            roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of 32 "
+            roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of 64 "
                                 "frames (hits applied in frame order: bit-identical to frame-by-frame fusion); the window's "
                                 "classification + TSDF run in classify_window_kernel (kernel_breakdown.sweep_us, per window)")
         breakdown = {

@@ -98,6 +98,8 @@ typedef struct saf_frame {
  *      0 when the per-frame pipeline ran)  [6] voxels whose TSDF a window's classification updated
  *      (sum over windows of |union of tsdf-valid sets|)  [7] reserved */
 #define SAF_STATS_WORDS 8
+/* frames per window of the windowed path of saf_fuse_frames (stats[5] and [6] count per window) */
+#define SAF_WINDOW_FRAMES 64
 
 const char* saf_last_error(void);
 int saf_abi_version(void);
@@ -121,7 +123,7 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
  * Two device paths, identical results bit for bit:
  *  - per-frame pipeline: one sweep + one fuse kernel per frame (any shape);
  *  - windowed, voxel-major (16 or more frames of one shape, f32 volume, feat_dim a multiple of 256 up to
- *    1024): per window of 32 frames one classification kernel (sweep of all 32 frames, TSDF in registers)
+ *    1024): per window of 64 frames one classification kernel (sweep of all 64 frames, TSDF in registers)
  *    and one row kernel that reads and writes every touched feature row once per window.
  *    SAF_WINDOW=0 in the environment forces the per-frame pipeline. */
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,

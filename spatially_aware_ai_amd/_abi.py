@@ -18,6 +18,7 @@ SAF_F32, SAF_BF16, SAF_F16 = 0, 1, 2
 SAF_RUNNING_MEAN, SAF_SUM = 0, 1
 SAF_Q_SCORES, SAF_Q_SOFTMAX, SAF_Q_SURGERY = 0, 1, 2
 SAF_STATS_WORDS = 8
+SAF_WINDOW_FRAMES = 64
 
 _fp = C.c_void_p  # every data pointer travels as an integer address
 
