@@ -16,16 +16,11 @@
 //
 // saf_fuse_frames pipelines the two over frames: sweeps run ahead on an auxiliary stream, fuse
 // kernels back to back on the caller's stream, sweep(i) -> fuse(i) through a device-side counter
-// (DESIGN.md §4).  All arithmetic that selects voxels is shared with the oracle's restatement in
-// spirit and checked bit-for-bit against it (saf_common.h).
-#include <math.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include "saf_common.h"
-#include "saf_host.h"
-
-#pragma clang fp contract(off)
+// (DESIGN.md §4).  Calls of 16 or more frames of one shape take the windowed path of saf_window.hip instead
+// (bit-identical).  All arithmetic that selects voxels is shared with the oracle's restatement in
+// spirit and checked bit-for-bit against it (saf_common.h); the device building blocks shared with the
+// windowed path live in saf_fuse_dev.h.
+#include "saf_fuse_dev.h"
 
 namespace saf {
 
@@ -35,49 +30,6 @@ char* err_buf() {
 }
 
 namespace {
-
-// ------------------------------------------------------------------------------------------
-// kernel-side descriptors (POD, passed by value)
-// ------------------------------------------------------------------------------------------
-struct KVol {
-  int nx, ny, nz, D, n_classes, accum, bf16;
-  uint32_t N;
-  float trunc;
-  const float *ax, *ay, *az;
-  float* tsdf;
-  int* tsdf_w;
-  int* weight;
-  float* rgb;
-  float* feat;
-  int* labels;
-  FastDiv div_nz, div_ny;
-};
-
-struct KFrame {
-  int H, W, npy, npx, rgb_bilinear;
-  const float *depth, *rgb, *pose, *K, *label_map;
-};
-
-FastDiv make_fastdiv(uint32_t d) {
-  // q = (n * mul) >> shift is exact for every n < 2^31: with L = ceil(log2 d), S = 31 + L and
-  // mul = ceil(2^S / d), the error term e = mul*d - 2^S is < d <= 2^L, so n*e < 2^S.
-  uint32_t L = 0;
-  while ((1ull << L) < d) ++L;
-  FastDiv f;
-  f.shift = 31 + L;
-  f.mul = (uint32_t)(((1ull << f.shift) + d - 1) / d);
-  f.d = d;
-  f.pad = 0;
-  return f;
-}
-
-__device__ __forceinline__ void voxel_coords(const KVol& v, uint32_t n, int& ix, int& iy, int& iz) {
-  uint32_t t = fdiv(n, v.div_nz);
-  iz = (int)(n - t * (uint32_t)v.nz);
-  uint32_t x = fdiv(t, v.div_ny);
-  iy = (int)(t - x * (uint32_t)v.ny);
-  ix = (int)x;
-}
 
 // Workspace: a header with eight rotating sets of list counters (frame i uses set i & 7 and zeroes
 // set (i+1) & 7 for its successor) and the sweep-completion counter, then kListBuffers buffers
@@ -139,21 +91,6 @@ __device__ __forceinline__ void fill_map_image(float* __restrict__ dst, const fl
     const int cv = (int)(((float)t + 0.5f) * rp), p = t - cv * ppad;
     dst[o] = p < P ? feat_map[(size_t)((cv << vshift) + k) * P + p] : 0.0f;
   }
-}
-
-// Pixel-major image for the windowed path, whose taps are read from global memory (L2): row p holds
-// the D channels of map position p contiguously (a wave's tap load is one contiguous D*4 bytes), row P
-// is the zero row of the taps outside the map.
-struct PrepArgs {
-  const float* feat_map[64];  // >= kWin
-};
-__global__ __launch_bounds__(256) void prep_rows_kernel(PrepArgs pa, float* __restrict__ imgs, int img_floats, int D,
-                                                        int P) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= (P + 1) * D) return;
-  const float* __restrict__ feat_map = pa.feat_map[blockIdx.y];
-  const int c = o % D, p = o / D;
-  imgs[(size_t)blockIdx.y * img_floats + o] = p < P ? feat_map[(size_t)c * P + p] : 0.0f;
 }
 
 // Only when the image does not fit LDS: build it once per frame in the workspace.
@@ -364,115 +301,6 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_kernel(KVol v, KFrame f,
     (void)__hip_atomic_fetch_add(&sweep_done[blockIdx.x % kDoneShards], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ------------------------------------------------------------------------------------------
-// fuse: gather + running-mean RMW of the valid voxel rows
-// ------------------------------------------------------------------------------------------
-template <int VEC>
-struct VecT;
-template <>
-struct VecT<4> {
-  using type = float4;
-};
-template <>
-struct VecT<1> {
-  using type = float;
-};
-
-__device__ __forceinline__ float4 lerp_taps(float4 a, float4 b, float4 c, float4 d, const Bilin& w) {
-  // (nw_val*nw + ne_val*ne) + sw_val*sw + se_val*se, left to right (GridSamplerKernel.cpp)
-  float4 r;
-  r.x = ((a.x * w.nw + b.x * w.ne) + c.x * w.sw) + d.x * w.se;
-  r.y = ((a.y * w.nw + b.y * w.ne) + c.y * w.sw) + d.y * w.se;
-  r.z = ((a.z * w.nw + b.z * w.ne) + c.z * w.sw) + d.z * w.se;
-  r.w = ((a.w * w.nw + b.w * w.ne) + c.w * w.sw) + d.w * w.se;
-  return r;
-}
-__device__ __forceinline__ float lerp_taps(float a, float b, float c, float d, const Bilin& w) {
-  return ((a * w.nw + b * w.ne) + c * w.sw) + d * w.se;
-}
-__device__ __forceinline__ float4 blend(float4 s, float4 old, float a, float b, bool sum) {
-  float4 r;
-  if (sum) {
-    r.x = old.x + s.x; r.y = old.y + s.y; r.z = old.z + s.z; r.w = old.w + s.w;
-  } else {
-    // clip_feat.T * a + self.clip_feat[valid] * b          clipfusion.py:720
-    r.x = s.x * a + old.x * b; r.y = s.y * a + old.y * b;
-    r.z = s.z * a + old.z * b; r.w = s.w * a + old.w * b;
-  }
-  return r;
-}
-__device__ __forceinline__ float blend(float s, float old, float a, float b, bool sum) {
-  return sum ? old + s : s * a + old * b;
-}
-
-struct Taps {
-  int o_nw, o_ne, o_sw, o_se;  // tap positions in [0, P]; P = the zero column (outside the map)
-};
-__device__ __forceinline__ Taps tap_offsets(const Bilin& b, int npx, int npy) {
-  const bool x0 = b.x0 >= 0 && b.x0 < npx, x1 = b.x0 + 1 >= 0 && b.x0 + 1 < npx;
-  const bool y0 = b.y0 >= 0 && b.y0 < npy, y1 = b.y0 + 1 >= 0 && b.y0 + 1 < npy;
-  const int zero = npx * npy;
-  Taps t;
-  t.o_nw = (x0 && y0) ? b.y0 * npx + b.x0 : zero;
-  t.o_ne = (x1 && y0) ? b.y0 * npx + b.x0 + 1 : zero;
-  t.o_sw = (x0 && y1) ? (b.y0 + 1) * npx + b.x0 : zero;
-  t.o_se = (x1 && y1) ? (b.y0 + 1) * npx + b.x0 + 1 : zero;
-  return t;
-}
-
-// rgb / weight / label side of one valid voxel, done by lane `gl` of the group of `G` lanes.
-__device__ __forceinline__ void fuse_scalars(const KVol& v, const KFrame& f, const Cam& cam, uint32_t n, float gx,
-                                             float gy, int w0, float a, float b, int gl, int G,
-                                             unsigned long long* stats) {
-  const bool sum = v.accum == SAF_SUM;
-  if (gl < 3) {
-    const int pix = nearest_index(gx, gy, cam, f.W);
-    Bilin bi;
-    int x0ok = 0, x1ok = 0, y0ok = 0, y1ok = 0;
-    if (f.rgb_bilinear) {
-      bi = bilinear_setup(gx, gy, cam.sfx, cam.sfy);
-      x0ok = bi.x0 >= 0 && bi.x0 < f.W;
-      x1ok = bi.x0 + 1 >= 0 && bi.x0 + 1 < f.W;
-      y0ok = bi.y0 >= 0 && bi.y0 < f.H;
-      y1ok = bi.y0 + 1 >= 0 && bi.y0 + 1 < f.H;
-    }
-    for (int ch = gl; ch < 3; ch += G) {
-      float s;
-      if (f.rgb_bilinear) {  // clip_seem_fusion.py:793-798
-        const float* img = f.rgb + ch;
-        const int64_t r0 = (int64_t)bi.y0 * f.W, r1 = r0 + f.W;
-        const float nw = (x0ok && y0ok) ? img[(r0 + bi.x0) * 3] : 0.f;
-        const float ne = (x1ok && y0ok) ? img[(r0 + bi.x0 + 1) * 3] : 0.f;
-        const float sw = (x0ok && y1ok) ? img[(r1 + bi.x0) * 3] : 0.f;
-        const float se = (x1ok && y1ok) ? img[(r1 + bi.x0 + 1) * 3] : 0.f;
-        s = lerp_taps(nw, ne, sw, se, bi);
-      } else {  // clipfusion.py:701-706
-        s = pix >= 0 ? f.rgb[(int64_t)pix * 3 + ch] : 0.f;
-      }
-      float* dst = v.rgb + (int64_t)n * 3 + ch;
-      *dst = blend(s, *dst, a, b, sum);
-    }
-    if (gl == 0) {
-      v.weight[n] = w0 + 1;  // clipfusion.py:715, :721
-      if (v.labels && f.label_map) {
-        // labels = grid_sample(pano_seg.float(), nearest); one_hot(labels.long())  clip_seem_fusion.py:786-822
-        const float lf = pix >= 0 ? f.label_map[pix] : 0.f;
-        const long long l = (long long)lf;
-        if (l >= 0 && l < v.n_classes) {
-          int* c = v.labels + (int64_t)n * v.n_classes + l;
-          *c = *c + 1;
-        } else if (stats) {
-          atomicAdd(&stats[3], 1ull);
-        }
-      }
-    }
-  }
-}
-
-// Block until the sweep of this frame has published all its blocks (device-side dependency: no
-// event packet sits between consecutive fuse kernels on the caller's stream).  The sweep never
-// waits on anything and always fits beside a fuse workgroup, so this cannot deadlock; the spin is
-// bounded anyway (~2 s of the 100 MHz wall clock) and reports through stats[4].
 __device__ __forceinline__ unsigned long long sweep_blocks_done(const unsigned long long* __restrict__ sweep_done) {
   unsigned long long n = 0;
 #pragma unroll
@@ -516,66 +344,6 @@ __device__ __forceinline__ void add_frame_stats(const unsigned long long* __rest
     atomicAdd(&stats[0], nv);
     atomicAdd(&stats[1], nt);
     atomicAdd(&stats[2], 1ull);
-  }
-}
-
-// rgb / weight / label side of one valid voxel handled entirely by ONE lane (the lane-parallel
-// part of fuse_rows_kernel): the three channel loads are issued together, then blended and stored.
-__device__ __forceinline__ void fuse_scalars_lane(const KVol& v, const KFrame& f, const Cam& cam, uint32_t n,
-                                                  float gx, float gy, int w0, float a, float b,
-                                                  unsigned long long* stats) {
-  const bool sum = v.accum == SAF_SUM;
-  const int pix = nearest_index(gx, gy, cam, f.W);
-  float s0, s1, s2;
-  if (f.rgb_bilinear) {  // clip_seem_fusion.py:793-798
-    const Bilin bi = bilinear_setup(gx, gy, cam.sfx, cam.sfy);
-    const bool x0ok = bi.x0 >= 0 && bi.x0 < f.W, x1ok = bi.x0 + 1 >= 0 && bi.x0 + 1 < f.W;
-    const bool y0ok = bi.y0 >= 0 && bi.y0 < f.H, y1ok = bi.y0 + 1 >= 0 && bi.y0 + 1 < f.H;
-    const int64_t r0 = (int64_t)bi.y0 * f.W, r1 = r0 + f.W;
-    const float* pnw = f.rgb + ((x0ok && y0ok) ? (r0 + bi.x0) * 3 : 0);
-    const float* pne = f.rgb + ((x1ok && y0ok) ? (r0 + bi.x0 + 1) * 3 : 0);
-    const float* psw = f.rgb + ((x0ok && y1ok) ? (r1 + bi.x0) * 3 : 0);
-    const float* pse = f.rgb + ((x1ok && y1ok) ? (r1 + bi.x0 + 1) * 3 : 0);
-    const float mnw = (x0ok && y0ok) ? 1.f : 0.f, mne = (x1ok && y0ok) ? 1.f : 0.f;
-    const float msw = (x0ok && y1ok) ? 1.f : 0.f, mse = (x1ok && y1ok) ? 1.f : 0.f;
-    // out-of-image taps: value forced to +0 (x * 0 would keep NaN/inf of pixel 0 alive)
-    float nw[3], ne[3], sw[3], se[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      nw[ch] = pnw[ch]; ne[ch] = pne[ch]; sw[ch] = psw[ch]; se[ch] = pse[ch];
-    }
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      nw[ch] = mnw != 0.f ? nw[ch] : 0.f; ne[ch] = mne != 0.f ? ne[ch] : 0.f;
-      sw[ch] = msw != 0.f ? sw[ch] : 0.f; se[ch] = mse != 0.f ? se[ch] : 0.f;
-    }
-    s0 = lerp_taps(nw[0], ne[0], sw[0], se[0], bi);
-    s1 = lerp_taps(nw[1], ne[1], sw[1], se[1], bi);
-    s2 = lerp_taps(nw[2], ne[2], sw[2], se[2], bi);
-  } else {  // clipfusion.py:701-706
-    const float* px = f.rgb + (int64_t)(pix >= 0 ? pix : 0) * 3;
-    const float t0 = px[0], t1 = px[1], t2 = px[2];
-    s0 = pix >= 0 ? t0 : 0.f;
-    s1 = pix >= 0 ? t1 : 0.f;
-    s2 = pix >= 0 ? t2 : 0.f;
-  }
-  float* dst = v.rgb + (int64_t)n * 3;
-  const float o0 = dst[0], o1 = dst[1], o2 = dst[2];
-  dst[0] = blend(s0, o0, a, b, sum);
-  dst[1] = blend(s1, o1, a, b, sum);
-  dst[2] = blend(s2, o2, a, b, sum);
-  v.weight[n] = w0 + 1;  // clipfusion.py:715, :721
-  if (v.labels && f.label_map) {
-    // labels = grid_sample(pano_seg.float(), nearest); one_hot(labels.long())  clip_seem_fusion.py:786-822
-    const float lraw = f.label_map[pix >= 0 ? pix : 0];
-    const float lf = pix >= 0 ? lraw : 0.f;
-    const long long l = (long long)lf;
-    if (l >= 0 && l < v.n_classes) {
-      int* c = v.labels + (int64_t)n * v.n_classes + l;
-      *c = *c + 1;
-    } else if (stats) {
-      atomicAdd(&stats[3], 1ull);
-    }
   }
 }
 
@@ -894,639 +662,6 @@ __global__ __launch_bounds__(kFuseThreads) void fuse_rows_kernel(KVol v, KFrame 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// fuse, voxel-major over a WINDOW of up to 64 frames (saf_fuse_frames with many frames).
-//
-// A running mean is applied hit by hit, but nothing forces a row to travel to HBM between two hits.
-// Per window, on the caller's stream:
-//   classify_window_kernel  (one launch per 32 frames) every voxel against 32 frames (the full-grid sweep of
-//                           clipfusion.py:647-695): TSDF running mean kept in registers across the frames
-//                           and written once, one 32-bit frame mask per voxel into that launch's mask plane;
-//   fuse_window_kernel      every touched voxel's D-row is read ONCE, the voxel's hits are applied in frame
-//                           order -- the same s*a + old*b with a = 1/(w+1), so the result is bit-identical to
-//                           fusing the frames one after the other -- and written ONCE.  Row bytes fall by the
-//                           window's hits-per-voxel ratio (1.8 for incoherent depth, 7 for a coherent scene).
-//
-// fuse_window_kernel: waves work independently (no workgroup barrier after the prologue).  A wave takes
-// pieces of 256 consecutive voxels, compacts the touched ones, and per chunk of <= 64 touched voxels
-// (<= kHitCap hits):
-//   lane-parallel over HITS  : projection, a, b, the map cell of the hit (staged in LDS);
-//   lane-parallel over VOXELS: rgb / weight / label side, hit by hit;
-//   rows, in sub-chunks of SR rows (<= 64 hits): the rows are brought into LDS by LDS-DMA, the hits are
-//   regrouped frame-major by (frame, map cell) -- every hit of a group blends the same four map rows,
-//   which are loaded from the window's map images (L2) ONCE per group, P groups in flight -- each hit
-//   updates its row in LDS, and the rows are streamed back.
-// ------------------------------------------------------------------------------------------
-constexpr int kWin = SAF_WINDOW_FRAMES;  // frames per window: two 32-bit mask words per voxel
-static_assert(kWin == 64, "the mask layout and the 6-bit frame field assume 64-frame windows");
-constexpr int kMaskWords = kWin / 32;
-constexpr int kWinMinFrames = 16;  // shorter calls run the per-frame pipeline
-#ifndef SAF_WIN_HITCAP
-#define SAF_WIN_HITCAP 128
-#endif
-constexpr int kHitCap = SAF_WIN_HITCAP;
-constexpr int kWinThreads = 256;
-constexpr int kWinWaves = kWinThreads / 64;
-constexpr int kPiece = 256;
-
-struct WinArgs {
-  int F, H, W, npy, npx, rgb_bilinear;
-  const float* depth[kWin];
-  const float* rgb[kWin];
-  const float* pose[kWin];
-  const float* K[kWin];
-  const float* label_map[kWin];
-};
-
-__device__ __forceinline__ void wave_lds_sync() {
-  // LDS operations of one wave execute in order; this only stops the compiler from moving them
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-#ifdef SAF_WIN_TIMING  // development aid: per-phase wave cycles of the window kernel, printed by the host
-__device__ unsigned long long g_win_t[16];
-#define WT_DECL unsigned long long wt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last_ = __builtin_readcyclecounter()
-#define WT(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); wt_[k] += n_ - wt_last_; wt_last_ = n_; } while (0)
-#define WT_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_win_t[k_], wt_[k_]); } while (0)
-#else
-#define WT_DECL
-#define WT(k)
-#define WT_FLUSH
-#endif
-
-#ifndef SAF_WIN_P2
-#define SAF_WIN_P2 4
-#endif
-#ifndef SAF_WIN_SR2
-#define SAF_WIN_SR2 6
-#endif
-#ifndef SAF_WIN_WPE
-#define SAF_WIN_WPE 2
-#endif
-template <int CPL>
-struct WinCfg {
-  static constexpr int SR = CPL == 1 ? 8 : (CPL == 2 ? SAF_WIN_SR2 : 3);  // rows of a sub-chunk (LDS resident)
-  static constexpr int P = CPL == 1 ? 6 : (CPL == 2 ? SAF_WIN_P2 : 2);  // tap groups in flight
-  // dynamic LDS layout (bytes)
-  static constexpr size_t rows_off = 0;
-  static constexpr size_t rows_bytes = (size_t)kWinWaves * SR * CPL * 64 * sizeof(float4);
-  static constexpr size_t stage_off = rows_off + rows_bytes;  // 6 arrays of kHitCap words per wave
-  static constexpr size_t stage_bytes = (size_t)kWinWaves * 6 * kHitCap * 4;
-  static constexpr size_t tm_off = stage_off + stage_bytes;
-  static constexpr size_t tm_bytes = (size_t)kWinWaves * kPiece * 4 * kMaskWords;
-  static constexpr size_t tv_off = tm_off + tm_bytes;
-  static constexpr size_t tv_bytes = (size_t)kWinWaves * kPiece * 2;
-  static constexpr size_t ptr_off = tv_off + tv_bytes;
-  static constexpr size_t ptr_bytes = (size_t)2 * kWin * sizeof(const float*);
-  static constexpr size_t cam_off = ptr_off + ptr_bytes;
-  static constexpr size_t total = cam_off + (size_t)kWin * sizeof(Cam);
-};
-
-// Classification of one piece (256 consecutive voxels, a lane owns 4 of them) against every frame of a
-// window (clipfusion.py:647-679): the voxels' TSDF running mean is kept in registers across the frames
-// (clipfusion.py:681-695 with B = 1, frame after frame -- order dependent) and written once; mk4[j] collects
-// the frame bitmask of voxel j.  KFU frames at a time: their depth gathers are in flight together.
-template <int KFU, bool SUM>
-__device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa, const Cam* __restrict__ s_cam,
-                                               uint32_t piece_base, int lane, float rtrunc, bool tsdf_aligned,
-                                               int f_begin, int f_end, uint32_t (&mk4)[4], unsigned long long& nt_done,
-                                               unsigned long long& tsdf_rows_done) {
-  const uint32_t nb = piece_base + (uint32_t)lane * 4u;
-  float xw[4], yw[4], zw[4], told[4];
-  int tw[4];
-  bool inb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    inb[j] = nb + j < v.N;
-    int ix, iy, iz;
-    voxel_coords(v, inb[j] ? nb + j : 0u, ix, iy, iz);
-    xw[j] = v.ax[ix];
-    yw[j] = v.ay[iy];
-    zw[j] = v.az[iz];
-  }
-  const bool vec = tsdf_aligned && nb + 4u <= v.N;
-  if (vec) {
-    const float4 t4 = *reinterpret_cast<const float4*>(v.tsdf + nb);
-    const int4 w4 = *reinterpret_cast<const int4*>(v.tsdf_w + nb);
-    told[0] = t4.x; told[1] = t4.y; told[2] = t4.z; told[3] = t4.w;
-    tw[0] = w4.x; tw[1] = w4.y; tw[2] = w4.z; tw[3] = w4.w;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      told[j] = inb[j] ? v.tsdf[nb + j] : 0.0f;
-      tw[j] = inb[j] ? v.tsdf_w[nb + j] : 0;
-    }
-  }
-  uint32_t touched = 0;  // bit j: voxel j's TSDF changed
-  // kFU frames at a time: all their depth gathers are in flight together, then the frames are
-  // applied one after the other (the TSDF running mean is order dependent)
-  constexpr int kFU = KFU;
-  for (int f0 = f_begin; f0 < f_end; f0 += kFU) {
-    int pix[kFU][4];  // >= 0: pixel; -1: in view, no pixel (zeros padding); -2: not in view
-    float pz[kFU][4];
-#pragma unroll
-    for (int u = 0; u < kFU; ++u) {
-      const bool live = f0 + u < f_end;
-      const Cam cam = s_cam[live ? f0 + u : 0];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const Proj p = project(cam, xw[j], yw[j], zw[j]);
-        const bool in_view = live && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
-        const int px = nearest_index(p.gx, p.gy, cam, wa.W);
-        pix[u][j] = in_view ? (px >= 0 ? px : -1) : -2;
-        pz[u][j] = p.z;
-      }
-    }
-    float depth[kFU][4];
-#pragma unroll
-    for (int u = 0; u < kFU; ++u) {
-      const float* __restrict__ dimg = wa.depth[f0 + u < f_end ? f0 + u : 0];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) depth[u][j] = pix[u][j] >= 0 ? dimg[pix[u][j]] : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < kFU; ++u) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool in_view = pix[u][j] != -2;
-        const float num = depth[u][j] - pz[u][j];
-        const float sdf = num == INFINITY ? INFINITY : div_by_uniform(num, v.trunc, rtrunc);
-        if (in_view && fabsf(sdf) <= 1.0f) mk4[j] |= 1u << (f0 + u - f_begin);
-        if (in_view && sdf > -1.0f) {
-          const float t = sdf > 1.0f ? 1.0f : sdf;
-          const int w1 = tw[j] + 1;
-          if (SUM) {
-            told[j] = told[j] + t;
-          } else {
-            const float rw = __builtin_amdgcn_rcpf((float)w1);
-            told[j] = t * rw + told[j] * ((float)tw[j] * rw);
-          }
-          tw[j] = w1;
-          touched |= 1u << j;
-          ++nt_done;
-        }
-      }
-    }
-  }
-  if (touched) {
-    tsdf_rows_done += (unsigned long long)__popc(touched);
-    if (vec) {
-      *reinterpret_cast<float4*>(v.tsdf + nb) = make_float4(told[0], told[1], told[2], told[3]);
-      *reinterpret_cast<int4*>(v.tsdf_w + nb) = make_int4(tw[0], tw[1], tw[2], tw[3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (touched & (1u << j)) {
-          v.tsdf[nb + j] = told[j];
-          v.tsdf_w[nb + j] = tw[j];
-        }
-      }
-    }
-  }
-}
-
-// classify_window_kernel: one launch per 32 frames of a window [f_begin, f_end); leaves that mask word of
-// every voxel in its plane of `hitmask` and the updated TSDF.  (One launch over all 64 frames keeps the TSDF
-// in registers twice as long but puts 64 depth-image footprints in L2 at once: 4.2 ms against 2 x 1.9 ms.)
-template <bool SUM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_window_kernel(
-    KVol v, WinArgs wa, int f_begin, int f_end, int tile, uint32_t* __restrict__ hitmask,
-    unsigned long long* __restrict__ stats) {
-  __shared__ Cam s_cam[kWin];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid >= f_begin && tid < f_end) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
-  __syncthreads();
-  if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)(f_end - f_begin));
-  const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
-  uint32_t piece = blockIdx.x * 4u + (uint32_t)wave;
-  if (piece >= n_pieces) return;
-  if (tile > 0) {
-    // Workgroups are dispatched in index order, so the few thousand pieces in flight at any time are
-    // consecutive indices.  In linear order those are a few whole x-planes of the grid -- seen face-on
-    // they cover the whole depth image of a frame.  Walking the (x-plane, piece-in-plane) rectangle in
-    // tiles of tile x tile keeps the pieces in flight inside a compact box, whose footprint in every
-    // frame's depth image is small enough for the frames of this launch to stay in L2 together.
-    const uint32_t ppx = (uint32_t)(((int64_t)v.ny * v.nz) / kPiece);  // pieces per x-plane (exact, checked by the host)
-    const uint32_t T = (uint32_t)tile, tj = ppx / T, per_tile = T * T;
-    const uint32_t t = piece / per_tile, r = piece - t * per_tile;
-    const uint32_t tx = t / tj, ty = t - tx * tj;
-    piece = (tx * T + r / T) * ppx + ty * T + (r - (r / T) * T);
-  }
-  const float rtrunc = 1.0f / v.trunc;
-  const bool tsdf_aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
-  unsigned long long nt_done = 0, tsdf_rows_done = 0;
-  const uint32_t nb = piece * (uint32_t)kPiece + (uint32_t)lane * 4u;
-  uint32_t mk4[4] = {0u, 0u, 0u, 0u};
-  classify_piece<4, SUM>(v, wa, s_cam, piece * (uint32_t)kPiece, lane, rtrunc, tsdf_aligned, f_begin, f_end, mk4, nt_done,
-                         tsdf_rows_done);
-  if (nb + 3u < v.N) {
-    *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (nb + k < v.N) hitmask[nb + k] = mk4[k];
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    nt_done += __shfl_xor(nt_done, o);
-    tsdf_rows_done += __shfl_xor(tsdf_rows_done, o);
-  }
-  if (stats && lane == 0) {
-    if (nt_done) atomicAdd(&stats[1], nt_done);
-    if (tsdf_rows_done) atomicAdd(&stats[6], tsdf_rows_done);
-  }
-}
-
-// One hit of a sub-chunk, held by the lane with the hit's index.
-struct WinHit {
-  int row;  // row slot in the LDS buffer
-  float a, b, nw, ne, sw, se;
-};
-template <int CPL>
-struct WinCtx {
-  const float4* imgs;
-  int img_vecs, DV, npx, npy, zero_row, lane;
-  float4* rows;
-};
-// Channel chunk c of a lane (a float4 of the D-channel map row).  f32 volume: lane + 64 c.  bf16 volume:
-// a lane's 16-byte row unit holds 8 channels = chunks 2 (lane + 64 (c / 2)) + c % 2.
-template <bool BF16>
-__device__ __forceinline__ constexpr int win_chunk_off(int c) {
-  return BF16 ? (c >> 1) * 128 + (c & 1) : c * 64;
-}
-// bf16 volume: the rows of a sub-chunk travel through registers (16 bytes = 8 channels per lane and unit)
-// and are widened into the f32 LDS rows once they have landed.
-template <int SR, int UPL>
-struct WinRaw {
-  uint4 u[SR * UPL];
-  int nrows;
-};
-__device__ __forceinline__ float bf16_round(float x) { return bf16_lo(f32_to_bf16_bits(x)); }
-
-// NB groups: request the four map rows of every group, then blend group after group into the LDS rows
-// (the waits are counted: group u is processed while the rows of groups u+1.. are still in flight).
-template <int NB, int CPL, bool SUM, bool BF16, int SR>
-__device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, uint32_t gk, uint32_t gm_lo, uint32_t gm_hi,
-                                          const WinHit& rec, const WinRaw<SR, BF16 ? CPL / 2 : 1>& raw) {
-  float4 tp[NB][4][CPL];
-#pragma unroll
-  for (int u = 0; u < NB; ++u) {
-    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)gk, g0 + u);
-    const int fb = (int)(k >> 16), x0 = (int)(k & 255u) - 2, y0 = (int)((k >> 8) & 255u) - 2;
-    const bool x0ok = x0 >= 0 && x0 < cx.npx, x1ok = x0 + 1 >= 0 && x0 + 1 < cx.npx;
-    const bool y0ok = y0 >= 0 && y0 < cx.npy, y1ok = y0 + 1 >= 0 && y0 + 1 < cx.npy;
-    const int o_nw = (x0ok && y0ok) ? y0 * cx.npx + x0 : cx.zero_row;
-    const int o_ne = (x1ok && y0ok) ? y0 * cx.npx + x0 + 1 : cx.zero_row;
-    const int o_sw = (x0ok && y1ok) ? (y0 + 1) * cx.npx + x0 : cx.zero_row;
-    const int o_se = (x1ok && y1ok) ? (y0 + 1) * cx.npx + x0 + 1 : cx.zero_row;
-    const float4* img = cx.imgs + (int64_t)fb * cx.img_vecs + (BF16 ? 2 * cx.lane : cx.lane);
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      tp[u][0][c] = img[o_nw * cx.DV + win_chunk_off<BF16>(c)];
-      tp[u][1][c] = img[o_ne * cx.DV + win_chunk_off<BF16>(c)];
-      tp[u][2][c] = img[o_sw * cx.DV + win_chunk_off<BF16>(c)];
-      tp[u][3][c] = img[o_se * cx.DV + win_chunk_off<BF16>(c)];
-    }
-  }
-  if (g0 == 0) {  // the sub-chunk's rows (issued before these loads) have landed after this
-    // the BUILTIN, not inline asm: the compiler's wait-count pass must see that the LDS-DMA has been
-    // waited for, or it drains vmcnt before every later LDS read (each row's store waited for the last)
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
-    if (BF16) {
-      constexpr int UPL = CPL / 2;
-#pragma unroll
-      for (int r = 0; r < SR; ++r) {
-        if (r < raw.nrows) {
-#pragma unroll
-          for (int k = 0; k < UPL; ++k) {
-            const uint4 w = raw.u[r * UPL + k];
-            cx.rows[(r * CPL + 2 * k) * 64 + cx.lane] = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
-            cx.rows[(r * CPL + 2 * k + 1) * 64 + cx.lane] = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
-          }
-        }
-      }
-    }
-    wave_lds_sync();
-  }
-#pragma unroll
-  for (int u = 0; u < NB; ++u) {
-    unsigned long long mm = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)gm_lo, g0 + u) |
-                            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)gm_hi, g0 + u) << 32);
-    while (mm) {
-      const int l = __ffsll((long long)mm) - 1;
-      mm &= mm - 1ull;
-      const int r = __builtin_amdgcn_readlane(rec.row, l);
-      const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.a), l));
-      const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.b), l));
-      Bilin w;
-      w.x0 = 0; w.y0 = 0;
-      w.nw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.nw), l));
-      w.ne = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.ne), l));
-      w.sw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.sw), l));
-      w.se = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.se), l));
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        float4* rp = cx.rows + (r * CPL + c) * 64 + cx.lane;
-        const float4 sv = lerp_taps(tp[u][0][c], tp[u][1][c], tp[u][2][c], tp[u][3][c], w);
-        float4 nv = blend(sv, *rp, a, b, SUM);
-        if (BF16) {  // the per-frame path stores bf16 after every hit: round to nearest even, keep as f32
-          nv.x = bf16_round(nv.x); nv.y = bf16_round(nv.y); nv.z = bf16_round(nv.z); nv.w = bf16_round(nv.w);
-        }
-        *rp = nv;
-      }
-    }
-  }
-}
-
-template <int CPL, bool SUM, bool BF16>
-__global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(SAF_WIN_WPE, SAF_WIN_WPE))) void
-fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int img_vecs,
-                   unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
-                   const uint32_t* __restrict__ hitmask, uint32_t mask_plane) {
-  using Cfg = WinCfg<CPL>;
-  constexpr int SR = Cfg::SR;
-  // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
-  constexpr int P = BF16 && Cfg::P > 2 ? Cfg::P - 1 : Cfg::P;
-  extern __shared__ __align__(16) unsigned char s_dyn[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float4* rows = reinterpret_cast<float4*>(s_dyn + Cfg::rows_off) + (size_t)wave * SR * CPL * 64;
-  uint32_t* stage = reinterpret_cast<uint32_t*>(s_dyn + Cfg::stage_off) + (size_t)wave * 6 * kHitCap;
-  uint32_t* s_hf = stage;  // voxel lane (6 bits) | cell << 6 (16 bits) | frame of the window << 22 (6 bits)
-  int* s_hw = reinterpret_cast<int*>(stage + kHitCap);
-  float* s_ha = reinterpret_cast<float*>(stage + 2 * kHitCap);
-  float* s_hb = reinterpret_cast<float*>(stage + 3 * kHitCap);
-  float* s_hgx = reinterpret_cast<float*>(stage + 4 * kHitCap);
-  float* s_hgy = reinterpret_cast<float*>(stage + 5 * kHitCap);
-  uint32_t* s_tm = reinterpret_cast<uint32_t*>(s_dyn + Cfg::tm_off) + wave * kPiece * kMaskWords;
-  uint16_t* s_tv = reinterpret_cast<uint16_t*>(s_dyn + Cfg::tv_off) + wave * kPiece;
-  const float** s_rgb = reinterpret_cast<const float**>(s_dyn + Cfg::ptr_off);
-  const float** s_lab = s_rgb + kWin;
-  Cam* s_cam = reinterpret_cast<Cam*>(s_dyn + Cfg::cam_off);
-
-  if (tid < wa.F) {
-    s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
-    s_rgb[tid] = wa.rgb[tid];
-    s_lab[tid] = wa.label_map[tid];
-  }
-  __syncthreads();
-  const int DV = v.D >> 2;
-  const float half_px = (float)wa.npx / 2.0f, half_py = (float)wa.npy / 2.0f;
-  const int zero_row = wa.npx * wa.npy;
-  int chs[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) chs[c] = lane + c * 64;
-  constexpr int UPL = BF16 ? CPL / 2 : 1;  // 16-byte units of a bf16 row per lane
-  float4* feat = reinterpret_cast<float4*>(v.feat);
-  float4* featb = reinterpret_cast<float4*>(v.feat);  // bf16 volume: D / 8 units of 16 bytes per row
-  const float4* imgs = reinterpret_cast<const float4*>(map_imgs);
-  KFrame kf;  // per-hit view of a frame for the scalar side
-  kf.H = wa.H; kf.W = wa.W; kf.npy = wa.npy; kf.npx = wa.npx; kf.rgb_bilinear = wa.rgb_bilinear;
-  kf.depth = nullptr; kf.pose = nullptr; kf.K = nullptr;
-  unsigned long long hits_done = 0, rows_done = 0;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  WT_DECL;
-  // persistent grid (2 workgroups of 4 waves per CU, 71 KB of LDS each).  Pieces are handed out by an
-  // atomic counter: a coherent scene concentrates its hits in few pieces (a wall = whole columns).
-  const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
-  for (;;) {
-    uint32_t piece = 0;
-    if (lane == 0) piece = atomicAdd(piece_ctr, 1u);
-    piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece);
-    if (piece >= n_pieces) break;
-    const uint32_t piece_base = piece * (uint32_t)kPiece;
-    // ---- the piece's touched voxels: (local id, frame mask) left by classify_window_kernel, compacted into LDS
-    uint32_t mk4[4][kMaskWords];
-    {
-      const uint32_t nb = piece_base + (uint32_t)lane * 4u;
-      // mask word w of every voxel lives in plane w (written by the classification launch of frames 32 w ..)
-#pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) {
-        const uint32_t* mrow = hitmask + (size_t)w * mask_plane + nb;
-        if (w * 32 >= wa.F) {
-          mk4[0][w] = mk4[1][w] = mk4[2][w] = mk4[3][w] = 0u;  // a short window has no second plane
-        } else if (nb + 3u < v.N) {
-          const uint4 t = *reinterpret_cast<const uint4*>(mrow);
-          mk4[0][w] = t.x; mk4[1][w] = t.y; mk4[2][w] = t.z; mk4[3][w] = t.w;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) mk4[k][w] = nb + k < v.N ? mrow[k] : 0u;
-        }
-      }
-    }
-    int T = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool touched = (mk4[k][0] | mk4[k][1]) != 0u;
-      const unsigned long long bal = __ballot(touched);
-      if (touched) {
-        const int slot = T + __popcll(bal & lt_mask);
-        s_tv[slot] = (uint16_t)(lane * 4 + k);
-        s_tm[slot * kMaskWords] = mk4[k][0];
-        s_tm[slot * kMaskWords + 1] = mk4[k][1];
-      }
-      T += __popcll(bal);
-    }
-    wave_lds_sync();
-    WT(0);
-    rows_done += (unsigned long long)T;
-    int pos = 0;
-    while (pos < T) {
-      const int cnt = min(64, T - pos);
-      const uint32_t vl = lane < cnt ? s_tv[pos + lane] : 0u;
-      const uint32_t mk0 = lane < cnt ? s_tm[(pos + lane) * kMaskWords] : 0u;
-      const uint32_t mk1 = lane < cnt ? s_tm[(pos + lane) * kMaskWords + 1] : 0u;
-      const int h = __popc(mk0) + __popc(mk1);
-      // inclusive prefix sum of h over the wave
-      int incl = h;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-      }
-      const int prefix = incl - h;
-      const unsigned long long fits = __ballot(lane < cnt && incl <= kHitCap);
-      const int m = fits == ~0ull ? 64 : (__ffsll((long long)~fits) - 1);  // leading voxels whose hits fit (>= 1)
-      const bool active = lane < m;
-      const uint32_t n_l = piece_base + vl;
-      const int w0 = active ? v.weight[n_l] : 0;
-      const int htot = __builtin_amdgcn_readlane(incl, m - 1);
-      // ---- expand the masks into the hit list (frame order within a voxel)
-      if (active) {
-        unsigned long long mm = (unsigned long long)mk0 | ((unsigned long long)mk1 << 32);
-        int r = 0;
-        while (mm) {
-          const int fbit = __ffsll((long long)mm) - 1;
-          mm &= mm - 1ull;
-          s_hf[prefix + r] = (uint32_t)lane | ((uint32_t)fbit << 22);
-          s_hw[prefix + r] = w0 + r;
-          ++r;
-        }
-      }
-      wave_lds_sync();
-      WT(1);
-      // ---- lane-parallel over hits: projection, a = 1/(w+1), b = w*a          clipfusion.py:647-659, :716-717
-      for (int j0 = 0; j0 < htot; j0 += 64) {
-        const int j = j0 + lane;
-        const uint32_t hf = j < htot ? s_hf[j] : 0u;
-        const uint32_t n = (uint32_t)__shfl((int)n_l, (int)(hf & 63u));
-        if (j < htot) {
-          const int fb = (int)(hf >> 22);
-          int ix, iy, iz;
-          voxel_coords(v, n, ix, iy, iz);
-          const Cam cam = s_cam[fb];
-          const Proj p = project(cam, v.ax[ix], v.ay[iy], v.az[iz]);
-          const int wi = s_hw[j];
-          const float a = 1.0f / (float)(wi + 1);
-          s_ha[j] = a;
-          s_hb[j] = (float)wi * a;
-          s_hgx[j] = p.gx;
-          s_hgy[j] = p.gy;
-          // the hit's map cell: (y0, x0) of its four taps; every cell wholly outside the map is one cell
-          const Bilin bw = bilinear_setup(p.gx, p.gy, half_px, half_py);
-          const int cx = min(max(bw.x0, -2), wa.npx) + 2, cy = min(max(bw.y0, -2), wa.npy) + 2;
-          s_hf[j] = hf | ((uint32_t)((cy << 8) | cx) << 6);
-        }
-      }
-      wave_lds_sync();
-      WT(2);
-      // ---- lane-parallel over voxels: rgb / weight / label side, hit by hit in frame order
-      if (active) {
-        for (int r = 0; r < h; ++r) {
-          const int j = prefix + r;
-          const int fb = (int)(s_hf[j] >> 22);
-          kf.rgb = s_rgb[fb];
-          kf.label_map = s_lab[fb];
-          const Cam cam = s_cam[fb];
-          fuse_scalars_lane(v, kf, cam, n_l, s_hgx[j], s_hgy[j], w0 + r, s_ha[j], s_hb[j], stats);
-        }
-      }
-      WT(3);
-      // ---- rows: sub-chunks of <= SR rows and <= 64 hits
-      int i0 = 0;
-      while (i0 < m) {
-        const int pbase = __builtin_amdgcn_readlane(prefix, i0);
-        const unsigned long long okm = __ballot(lane >= i0 && lane < m && lane < i0 + SR && (incl - pbase) <= 64);
-        const int nrows = __popcll(okm);                                         // >= 1 (a voxel has <= 64 hits)
-        const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..64
-        // hit l of the sub-chunk (staging entry pbase + l) lives in lane l: its row, a, b and tap weights
-        const bool hit = lane < nh;
-        const uint32_t hfl = hit ? s_hf[pbase + lane] : 0xffffffffu;
-        const uint32_t key = hfl >> 6;  // frame << 16 | cell
-        WinHit rec;
-        rec.row = (int)(hfl & 63u) - i0;
-        rec.a = hit ? s_ha[pbase + lane] : 0.0f;
-        rec.b = hit ? s_hb[pbase + lane] : 0.0f;
-        {
-          const Bilin w = bilinear_setup(hit ? s_hgx[pbase + lane] : 0.0f, hit ? s_hgy[pbase + lane] : 0.0f, half_px, half_py);
-          rec.nw = w.nw; rec.ne = w.ne; rec.sw = w.sw; rec.se = w.se;
-        }
-        // (the staging reads above come BEFORE the LDS-DMA below: the compiler drains vmcnt ahead of any LDS
-        //  read that follows an LDS-DMA, which would expose the rows' whole latency right here)
-        // the rows, global -> LDS (one LDS-DMA moves a wave's 64 x 16 B = one 1 KiB piece of a row)
-        unsigned long long fmask = 0;  // frames with a hit in this sub-chunk
-        WinRaw<SR, UPL> raw;
-#pragma unroll
-        for (int r = 0; r < SR; ++r) {
-          if (r < nrows) {
-            const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
-            fmask |= (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mk0, i0 + r) |
-                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mk1, i0 + r) << 32);
-            if (BF16) {
-#pragma unroll
-              for (int k = 0; k < UPL; ++k) {
-                const float4 t = ld_stream(featb + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * (DV / 2) +
-                                           lane + k * 64);
-                raw.u[r * UPL + k] = make_uint4(__builtin_bit_cast(uint32_t, t.x), __builtin_bit_cast(uint32_t, t.y),
-                                                __builtin_bit_cast(uint32_t, t.z), __builtin_bit_cast(uint32_t, t.w));
-              }
-            } else {
-#pragma unroll
-              for (int c = 0; c < CPL; ++c)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + row + chs[c]),
-                                                 (__attribute__((address_space(3))) void*)(rows + (r * CPL + c) * 64),
-                                                 16, 0, 2);
-            }
-          }
-        }
-        raw.nrows = nrows;
-        // groups = hits of one frame in one map cell, frames ascending (a row's hits stay in frame order);
-        // group g is kept in lane g: its key and the lane mask of its members
-        uint32_t gk = 0, gm_lo = 0, gm_hi = 0;
-        int G = 0;
-        while (fmask) {
-          const uint32_t f = (uint32_t)__ffsll((long long)fmask) - 1u;
-          fmask &= fmask - 1ull;
-          unsigned long long rem = __ballot(hit && (key >> 16) == f);
-          while (rem) {
-            const int l0 = __ffsll((long long)rem) - 1;
-            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, l0);
-            const unsigned long long mm = __ballot(hit && key == k0);
-            rem &= ~mm;
-            if (lane == G) {
-              gk = k0;
-              gm_lo = (uint32_t)mm;
-              gm_hi = (uint32_t)(mm >> 32);
-            }
-            ++G;
-          }
-        }
-        WT(4);
-        const WinCtx<CPL> cx{imgs, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
-        for (int g0 = 0; g0 < G; g0 += P) {
-          const int nb = min(P, G - g0);
-          switch (nb) {
-            case 1: win_batch<1, CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            case 2: win_batch<(P >= 2 ? 2 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            case 3: win_batch<(P >= 3 ? 3 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            case 4: win_batch<(P >= 4 ? 4 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            case 5: win_batch<(P >= 5 ? 5 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-          }
-        }
-        // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
-        // compiler's wait-count pass so, or it would drain vmcnt -- i.e. the previous row's store -- before
-        // each row's LDS read below
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        wave_lds_sync();
-        WT(6);
-#pragma unroll
-        for (int r = 0; r < SR; ++r) {
-          if (r < nrows) {
-            const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
-            if (BF16) {
-#pragma unroll
-              for (int k = 0; k < UPL; ++k) {
-                const float4 lo = rows[(r * CPL + 2 * k) * 64 + lane], hi = rows[(r * CPL + 2 * k + 1) * 64 + lane];
-                float4 o;  // the LDS values are bf16-exact already: the packing is lossless
-                o.x = __builtin_bit_cast(float, pack_bf16(lo.x, lo.y));
-                o.y = __builtin_bit_cast(float, pack_bf16(lo.z, lo.w));
-                o.z = __builtin_bit_cast(float, pack_bf16(hi.x, hi.y));
-                o.w = __builtin_bit_cast(float, pack_bf16(hi.z, hi.w));
-                st_stream(featb + (row / 2) + lane + k * 64, o);
-              }
-            } else {
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) st_stream(&feat[row + chs[c]], rows[(r * CPL + c) * 64 + lane]);
-            }
-          }
-        }
-        wave_lds_sync();  // the row buffer is rewritten by the next sub-chunk
-        WT(7);
-        i0 += nrows;
-      }
-      hits_done += (unsigned long long)htot;
-      pos += m;
-      wave_lds_sync();  // the staging area is rewritten by the next chunk
-    }
-  }
-  WT_FLUSH;
-  if (stats && lane == 0) {
-    if (hits_done) atomicAdd(&stats[0], hits_done);
-    if (rows_done) atomicAdd(&stats[5], rows_done);  // rows read-modify-written by this window
-  }
-}
-
 using FuseFn = void (*)(KVol, KFrame, const unsigned long long*, const uint32_t*, uint32_t, const float*,
                         const float*, int, unsigned long long*, const unsigned long long*, unsigned long long);
 
@@ -1644,52 +779,6 @@ int make_kvol(const saf_volume* vol, KVol* kv) {
   return SAF_OK;
 }
 
-int make_kframe(const saf_frame* fr, KFrame* kf) {
-  if (!fr) return fail(SAF_E_INVALID, "frame is NULL");
-  if (fr->height <= 0 || fr->width <= 0 || fr->npy <= 0 || fr->npx <= 0)
-    return fail(SAF_E_INVALID, "bad frame shape %dx%d map %dx%d", fr->height, fr->width, fr->npy, fr->npx);
-  if ((int64_t)fr->height * fr->width >= (1ll << 30)) return fail(SAF_E_UNSUPPORTED, "image too large");
-  if (!fr->depth || !fr->rgb || !fr->pose || !fr->K || !fr->feat_map) return fail(SAF_E_INVALID, "frame has a NULL buffer");
-  kf->H = fr->height; kf->W = fr->width; kf->npy = fr->npy; kf->npx = fr->npx;
-  kf->rgb_bilinear = fr->rgb_bilinear;
-  kf->depth = fr->depth; kf->rgb = fr->rgb; kf->pose = fr->pose; kf->K = fr->K;
-  kf->label_map = fr->label_map;
-  return SAF_OK;
-}
-
-}  // namespace
-}  // namespace saf
-
-// Pool of event pairs; opaque to callers (include/saf.h).
-struct saf_profiler {
-  struct Pair {
-    hipEvent_t a, b;
-    int cls;
-  };
-  Pair* pairs;
-  int capacity, used;
-  int stride;  // record only frames whose index within the call is a multiple of this
-};
-
-namespace saf {
-namespace {
-
-struct ScopedPair {
-  saf_profiler* p;
-  hipStream_t s;
-  int idx;
-  ScopedPair(saf_profiler* prof, int cls, int64_t frame_no, hipStream_t stream) : p(prof), s(stream), idx(-1) {
-    if (p && p->used < p->capacity && frame_no % p->stride == 0) {
-      idx = p->used++;
-      p->pairs[idx].cls = cls;
-      (void)hipEventRecord(p->pairs[idx].a, s);
-    }
-  }
-  ~ScopedPair() {
-    if (idx >= 0) (void)hipEventRecord(p->pairs[idx].b, s);
-  }
-};
-
 struct FrameJob {
   KFrame kf;
   WsLayout w;
@@ -1748,162 +837,6 @@ int launch_rows(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned
     hipError_t e_ = (call);                                                                \
     if (e_ != hipSuccess) { rc = fail(SAF_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); goto done; } \
   } while (0)
-
-// ---------------------------------------------------------------------------------------------
-// Windowed (voxel-major) path of saf_fuse_frames: see fuse_window_kernel.
-// Workspace: the common header (piece counter), the kWin pixel-major map images of one window, and the
-// window's frame bitmasks (kMaskWords words per voxel).
-// ---------------------------------------------------------------------------------------------
-struct WinLayout {
-  size_t img_bytes, maps_bytes, mask_bytes, total;
-  uint32_t mask_plane;
-};
-WinLayout win_layout(int64_t n_vox, int D, int P) {
-  WinLayout w;
-  w.img_bytes = ((size_t)D * (P + 1) * sizeof(float) + 255) & ~(size_t)255;
-  w.maps_bytes = (size_t)kWin * w.img_bytes;
-  w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
-  w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
-  w.total = kHdrBytes + w.maps_bytes + w.mask_bytes;
-  return w;
-}
-
-using WinFn = void (*)(KVol, WinArgs, const float*, int, unsigned long long*, unsigned int*, const uint32_t*, uint32_t);
-template <int CPL>
-WinFn pick_win(bool sum, bool bf16) {
-  if (bf16) {
-    if (CPL % 2 != 0) return nullptr;
-    constexpr int C2 = CPL % 2 == 0 ? CPL : 2;
-    return sum ? fuse_window_kernel<C2, true, true> : fuse_window_kernel<C2, false, true>;
-  }
-  return sum ? fuse_window_kernel<CPL, true, false> : fuse_window_kernel<CPL, false, false>;
-}
-
-// Shapes the windowed path takes; everything else runs the per-frame pipeline.
-bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
-  static const bool enabled = !(getenv("SAF_WINDOW") && getenv("SAF_WINDOW")[0] == '0');
-  if (!enabled || n_frames < kWinMinFrames || kv.D % 256 != 0 || kv.D > 1024) return false;
-  // bf16 volumes: implemented and bit-identical, but no faster than the per-frame pipeline (rows are half
-  // the bytes, the map taps are not: 3527 vs 3685 frames/s with labels, 4310 vs 4055 on the coherent
-  // scene) -- opt-in with SAF_WINDOW_BF16=1
-  static const bool bf16_on = getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '1';
-  if (kv.bf16 && (!bf16_on || kv.D % 512 != 0)) return false;  // a lane moves 8 bf16 channels: 512 per wave
-  const saf_frame& f0 = frames[0];
-  for (int32_t i = 0; i < n_frames; ++i) {
-    const saf_frame& f = frames[i];
-    if (f.height != f0.height || f.width != f0.width || f.npy != f0.npy || f.npx != f0.npx ||
-        f.rgb_bilinear != f0.rgb_bilinear || (f.label_map == nullptr) != (f0.label_map == nullptr))
-      return false;
-  }
-  if (f0.npx + 3 > 255 || f0.npy + 3 > 255) return false;  // a hit's map cell travels as two bytes
-  return workspace_bytes >= win_layout(kv.N, kv.D, f0.npy * f0.npx).total;
-}
-
-int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, uint64_t* stats,
-                       saf_profiler* prof, hipStream_t s) {
-  unsigned char* ws = static_cast<unsigned char*>(workspace);
-  int rc = SAF_OK;
-  KFrame kf0;
-  if ((rc = make_kframe(&frames[0], &kf0))) return rc;
-  for (int32_t i = 1; i < n_frames; ++i) {
-    KFrame t;
-    if ((rc = make_kframe(&frames[i], &t))) return rc;
-  }
-  const int P = kf0.npy * kf0.npx;
-  const WinLayout wl = win_layout(kv.N, kv.D, P);
-  const bool sum = kv.accum == SAF_SUM;
-  const int img_vecs = (int)(wl.img_bytes / sizeof(float4));
-  const int prep_blocks = (kv.D * (P + 1) + 255) / 256;
-  WinFn fn;
-  size_t win_lds;
-  switch (kv.D / 256) {
-    case 1: fn = pick_win<1>(sum, kv.bf16 != 0); win_lds = WinCfg<1>::total; break;
-    case 2: fn = pick_win<2>(sum, kv.bf16 != 0); win_lds = WinCfg<2>::total; break;
-    case 3: fn = pick_win<3>(sum, kv.bf16 != 0); win_lds = WinCfg<3>::total; break;
-    default: fn = pick_win<4>(sum, kv.bf16 != 0); win_lds = WinCfg<4>::total; break;
-  }
-  {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)win_lds);
-    if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", win_lds, hipGetErrorString(e));
-  }
-  float* maps = reinterpret_cast<float*>(ws + kHdrBytes);
-  uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrBytes + wl.maps_bytes);
-  unsigned int* piece_ctr = reinterpret_cast<unsigned int*>(ws);
-  static const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
-  uint32_t grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : 2);
-  const uint32_t n_pieces = (uint32_t)(((int64_t)kv.N + kPiece - 1) / kPiece);
-  const uint32_t n_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
-  if (grid > n_wgs) grid = n_wgs;
-  // Everything is ordered on the caller's stream: classification, map images, row kernel, window after
-  // window.  Running the classification of window w+1 beside the row kernel of window w (second stream)
-  // was measured: the pair costs the sum of the two either way (both are limited by the memory system),
-  // and with 64-frame windows the row kernel's 156 KB of LDS per CU leave no room for it.
-  static const int tile_env = getenv("SAF_WIN_TILE") ? atoi(getenv("SAF_WIN_TILE")) : -1;
-  int tile = tile_env >= 0 ? tile_env : 32;
-  {
-    const int64_t plane = (int64_t)kv.ny * kv.nz;
-    const int64_t ppx = plane / kPiece;
-    if (plane % kPiece != 0) tile = 0;
-    while (tile >= 8 && (ppx % tile != 0 || kv.nx % tile != 0)) tile >>= 1;
-    if (tile < 8) tile = 0;  // linear order
-  }
-  const int n_win = (n_frames + kWin - 1) / kWin;
-  for (int w = 0; w < n_win; ++w) {
-    const int f0 = w * kWin;
-    const int F = n_frames - f0 < kWin ? n_frames - f0 : kWin;
-    WinArgs wa;
-    wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
-    PrepArgs pa;
-    for (int k = 0; k < kWin; ++k) {
-      const saf_frame& fr = frames[f0 + (k < F ? k : 0)];
-      wa.depth[k] = fr.depth; wa.rgb[k] = fr.rgb; wa.pose[k] = fr.pose; wa.K[k] = fr.K; wa.label_map[k] = fr.label_map;
-      pa.feat_map[k] = fr.feat_map;
-    }
-    for (int fb = 0; fb < F; fb += 32) {
-      const int fe = fb + 32 < F ? fb + 32 : F;
-      uint32_t* plane = masks + (size_t)(fb / 32) * wl.mask_plane;
-      ScopedPair t(prof, 1, f0 + fb, s);
-      if (sum)
-        hipLaunchKernelGGL(classify_window_kernel<true>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, tile, plane,
-                           reinterpret_cast<unsigned long long*>(stats));
-      else
-        hipLaunchKernelGGL(classify_window_kernel<false>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, tile, plane,
-                           reinterpret_cast<unsigned long long*>(stats));
-    }
-    if ((rc = check_launch("classify_window_kernel"))) return rc;
-    if (hipMemsetAsync(piece_ctr, 0, sizeof(unsigned int), s) != hipSuccess)
-      return fail(SAF_E_HIP, "hipMemsetAsync(piece counter)");
-    {
-      ScopedPair t(prof, 0, f0, s);
-      hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, pa, maps,
-                         (int)(wl.img_bytes / sizeof(float)), kv.D, P);
-    }
-    if ((rc = check_launch("prep_rows_kernel"))) return rc;
-    {
-      ScopedPair t(prof, 2, f0, s);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, maps, img_vecs,
-                         reinterpret_cast<unsigned long long*>(stats), piece_ctr, masks, wl.mask_plane);
-    }
-    if ((rc = check_launch("fuse_window_kernel"))) return rc;
-  }
-#ifdef SAF_WIN_TIMING
-  {
-    (void)hipStreamSynchronize(s);
-    unsigned long long t[16];
-    if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_win_t), sizeof(t)) == hipSuccess) {
-      unsigned long long tot = 0;
-      for (int k = 0; k < 8; ++k) tot += t[k];
-      fprintf(stderr, "[win timing] masks %.1f%% expand %.1f%% project %.1f%% scalars %.1f%% records+groups+row issue %.1f%% - %.1f%% tap batches %.1f%% row store %.1f%% (total %.3g wave-cycles)\n",
-              100.0 * t[0] / tot, 100.0 * t[1] / tot, 100.0 * t[2] / tot, 100.0 * t[3] / tot, 100.0 * t[4] / tot,
-              100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, (double)tot);
-      memset(t, 0, sizeof(t));
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_win_t), t, sizeof(t));
-    }
-  }
-#endif
-  return rc;
-}
 
 // Frames in order.  A single frame runs sweep -> fuse on the caller's stream.  For two or more
 // frames the sweeps (VALU-bound; they touch only the TSDF buffers and their own list buffer) are
@@ -1978,7 +911,7 @@ int saf_abi_version(void) { return SAF_ABI_VERSION; }
 
 size_t saf_fuse_workspace_bytes(int64_t n_vox, int32_t feat_dim, int32_t npy, int32_t npx) {
   if (n_vox <= 0 || feat_dim <= 0 || npy <= 0 || npx <= 0) return 0;
-  const size_t a = ws_layout(n_vox, feat_dim, npy * npx).total, b = win_layout(n_vox, feat_dim, npy * npx).total;
+  const size_t a = ws_layout(n_vox, feat_dim, npy * npx).total, b = window_workspace_bytes(n_vox, feat_dim, npy * npx);
   return a > b ? a : b;
 }
 
