@@ -123,8 +123,9 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
  * Two device paths, identical results bit for bit:
  *  - per-frame pipeline: one sweep + one fuse kernel per frame (any shape);
  *  - windowed, voxel-major (16 or more frames of one shape, f32 volume, feat_dim a multiple of 256 up to
- *    1024): per window of 64 frames one classification kernel (sweep of all 64 frames, TSDF in registers)
- *    and one row kernel that reads and writes every touched feature row once per window.
+ *    1024): per window of SAF_WINDOW_FRAMES frames two classification launches (sweep of 32 frames each,
+ *    TSDF in registers, one frame-mask word per voxel) and one row kernel that reads and writes every
+ *    touched feature row once per window.
  *    SAF_WINDOW=0 in the environment forces the per-frame pipeline. */
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
                     void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
