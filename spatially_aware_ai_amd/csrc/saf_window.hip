@@ -294,29 +294,44 @@ struct WinRaw {
 };
 __device__ __forceinline__ float bf16_round(float x) { return bf16_lo(f32_to_bf16_bits(x)); }
 
+// Lane g: the float4 offsets of group g's four map rows (frame image + tap position, or the image's zero row).
+struct WinGroupOffs {
+  int nw, ne, sw, se;
+};
+template <int CPL>
+__device__ __forceinline__ WinGroupOffs win_group_offsets(const WinCtx<CPL>& cx, uint32_t k) {
+  const int fb = (int)(k >> 16), x0 = (int)(k & 255u) - 2, y0 = (int)((k >> 8) & 255u) - 2;
+  const bool x0ok = x0 >= 0 && x0 < cx.npx, x1ok = x0 + 1 >= 0 && x0 + 1 < cx.npx;
+  const bool y0ok = y0 >= 0 && y0 < cx.npy, y1ok = y0 + 1 >= 0 && y0 + 1 < cx.npy;
+  const int base = fb * cx.img_vecs;  // < 2^31: kWin images of (P + 1) * D / 4 float4 each
+  WinGroupOffs o;
+  o.nw = base + ((x0ok && y0ok) ? y0 * cx.npx + x0 : cx.zero_row) * cx.DV;
+  o.ne = base + ((x1ok && y0ok) ? y0 * cx.npx + x0 + 1 : cx.zero_row) * cx.DV;
+  o.sw = base + ((x0ok && y1ok) ? (y0 + 1) * cx.npx + x0 : cx.zero_row) * cx.DV;
+  o.se = base + ((x1ok && y1ok) ? (y0 + 1) * cx.npx + x0 + 1 : cx.zero_row) * cx.DV;
+  return o;
+}
+
 // NB groups: request the four map rows of every group, then blend group after group into the LDS rows
 // (the waits are counted: group u is processed while the rows of groups u+1.. are still in flight).
 template <int NB, int CPL, bool SUM, bool BF16, int SR>
-__device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, uint32_t gk, uint32_t gm_lo, uint32_t gm_hi,
-                                          const WinHit& rec, const WinRaw<SR, BF16 ? CPL / 2 : 1>& raw) {
+__device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, const WinGroupOffs& go, uint32_t gm_lo,
+                                          uint32_t gm_hi, const WinHit& rec, const WinRaw<SR, BF16 ? CPL / 2 : 1>& raw) {
   float4 tp[NB][4][CPL];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
-    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)gk, g0 + u);
-    const int fb = (int)(k >> 16), x0 = (int)(k & 255u) - 2, y0 = (int)((k >> 8) & 255u) - 2;
-    const bool x0ok = x0 >= 0 && x0 < cx.npx, x1ok = x0 + 1 >= 0 && x0 + 1 < cx.npx;
-    const bool y0ok = y0 >= 0 && y0 < cx.npy, y1ok = y0 + 1 >= 0 && y0 + 1 < cx.npy;
-    const int o_nw = (x0ok && y0ok) ? y0 * cx.npx + x0 : cx.zero_row;
-    const int o_ne = (x1ok && y0ok) ? y0 * cx.npx + x0 + 1 : cx.zero_row;
-    const int o_sw = (x0ok && y1ok) ? (y0 + 1) * cx.npx + x0 : cx.zero_row;
-    const int o_se = (x1ok && y1ok) ? (y0 + 1) * cx.npx + x0 + 1 : cx.zero_row;
-    const float4* img = cx.imgs + (int64_t)fb * cx.img_vecs + (BF16 ? 2 * cx.lane : cx.lane);
+    // the group's four map rows as float4 offsets into the window's images (computed lane-parallel by
+    // win_group_offsets: the row kernel issues as many scalar as vector instructions, this keeps the
+    // per-group address arithmetic off the scalar unit)
+    const int o_nw = __builtin_amdgcn_readlane(go.nw, g0 + u), o_ne = __builtin_amdgcn_readlane(go.ne, g0 + u);
+    const int o_sw = __builtin_amdgcn_readlane(go.sw, g0 + u), o_se = __builtin_amdgcn_readlane(go.se, g0 + u);
+    const float4* img = cx.imgs + (BF16 ? 2 * cx.lane : cx.lane);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      tp[u][0][c] = img[o_nw * cx.DV + win_chunk_off<BF16>(c)];
-      tp[u][1][c] = img[o_ne * cx.DV + win_chunk_off<BF16>(c)];
-      tp[u][2][c] = img[o_sw * cx.DV + win_chunk_off<BF16>(c)];
-      tp[u][3][c] = img[o_se * cx.DV + win_chunk_off<BF16>(c)];
+      tp[u][0][c] = img[o_nw + win_chunk_off<BF16>(c)];
+      tp[u][1][c] = img[o_ne + win_chunk_off<BF16>(c)];
+      tp[u][2][c] = img[o_sw + win_chunk_off<BF16>(c)];
+      tp[u][3][c] = img[o_se + win_chunk_off<BF16>(c)];
     }
   }
   if (g0 == 0) {  // the sub-chunk's rows (issued before these loads) have landed after this
@@ -603,15 +618,16 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
         }
         WT(4);
         const WinCtx<CPL> cx{imgs, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
+        const WinGroupOffs go = win_group_offsets(cx, gk);
         for (int g0 = 0; g0 < G; g0 += P) {
           const int nb = min(P, G - g0);
           switch (nb) {
-            case 1: win_batch<1, CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            case 2: win_batch<(P >= 2 ? 2 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            case 3: win_batch<(P >= 3 ? 3 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            case 4: win_batch<(P >= 4 ? 4 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            case 5: win_batch<(P >= 5 ? 5 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
-            default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM, BF16, SR>(cx, g0, gk, gm_lo, gm_hi, rec, raw); break;
+            case 1: win_batch<1, CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
+            case 2: win_batch<(P >= 2 ? 2 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
+            case 3: win_batch<(P >= 3 ? 3 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
+            case 4: win_batch<(P >= 4 ? 4 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
+            case 5: win_batch<(P >= 5 ? 5 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
+            default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
           }
         }
         // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
