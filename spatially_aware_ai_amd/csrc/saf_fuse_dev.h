@@ -179,12 +179,11 @@ __device__ __forceinline__ void fuse_scalars(const KVol& v, const KFrame& f, con
 // bounded anyway (~2 s of the 100 MHz wall clock) and reports through stats[4].
 // rgb / weight / label side of one valid voxel handled entirely by ONE lane (the lane-parallel
 // part of fuse_rows_kernel): the three channel loads are issued together, then blended and stored.
-__device__ __forceinline__ void fuse_scalars_lane(const KVol& v, const KFrame& f, const Cam& cam, uint32_t n,
-                                                  float gx, float gy, int w0, float a, float b,
-                                                  unsigned long long* stats) {
-  const bool sum = v.accum == SAF_SUM;
+// The frame's rgb sample for one valid voxel (nearest in ClipFusion, bilinear in ClipSeemFusion); returns the
+// nearest pixel index (-1 outside), which the label lookup shares.
+__device__ __forceinline__ int sample_rgb_lane(const KFrame& f, const Cam& cam, float gx, float gy, float& s0, float& s1,
+                                               float& s2) {
   const int pix = nearest_index(gx, gy, cam, f.W);
-  float s0, s1, s2;
   if (f.rgb_bilinear) {  // clip_seem_fusion.py:793-798
     const Bilin bi = bilinear_setup(gx, gy, cam.sfx, cam.sfy);
     const bool x0ok = bi.x0 >= 0 && bi.x0 < f.W, x1ok = bi.x0 + 1 >= 0 && bi.x0 + 1 < f.W;
@@ -217,24 +216,41 @@ __device__ __forceinline__ void fuse_scalars_lane(const KVol& v, const KFrame& f
     s1 = pix >= 0 ? t1 : 0.f;
     s2 = pix >= 0 ? t2 : 0.f;
   }
+  return pix;
+}
+// labels = grid_sample(pano_seg.float(), nearest); one_hot(labels.long())          clip_seem_fusion.py:786-822
+// ATOMIC: several hits of one voxel may be counted by different lanes at the same time (integer adds commute).
+template <bool ATOMIC>
+__device__ __forceinline__ void count_label_lane(const KVol& v, const KFrame& f, uint32_t n, int pix,
+                                                 unsigned long long* stats) {
+  if (v.labels && f.label_map) {
+    const float lraw = f.label_map[pix >= 0 ? pix : 0];
+    const float lf = pix >= 0 ? lraw : 0.f;
+    const long long l = (long long)lf;
+    if (l >= 0 && l < v.n_classes) {
+      int* c = v.labels + (int64_t)n * v.n_classes + l;
+      if (ATOMIC)
+        atomicAdd(c, 1);
+      else
+        *c = *c + 1;
+    } else if (stats) {
+      atomicAdd(&stats[3], 1ull);
+    }
+  }
+}
+__device__ __forceinline__ void fuse_scalars_lane(const KVol& v, const KFrame& f, const Cam& cam, uint32_t n,
+                                                  float gx, float gy, int w0, float a, float b,
+                                                  unsigned long long* stats) {
+  const bool sum = v.accum == SAF_SUM;
+  float s0, s1, s2;
+  const int pix = sample_rgb_lane(f, cam, gx, gy, s0, s1, s2);
   float* dst = v.rgb + (int64_t)n * 3;
   const float o0 = dst[0], o1 = dst[1], o2 = dst[2];
   dst[0] = blend(s0, o0, a, b, sum);
   dst[1] = blend(s1, o1, a, b, sum);
   dst[2] = blend(s2, o2, a, b, sum);
   v.weight[n] = w0 + 1;  // clipfusion.py:715, :721
-  if (v.labels && f.label_map) {
-    // labels = grid_sample(pano_seg.float(), nearest); one_hot(labels.long())  clip_seem_fusion.py:786-822
-    const float lraw = f.label_map[pix >= 0 ? pix : 0];
-    const float lf = pix >= 0 ? lraw : 0.f;
-    const long long l = (long long)lf;
-    if (l >= 0 && l < v.n_classes) {
-      int* c = v.labels + (int64_t)n * v.n_classes + l;
-      *c = *c + 1;
-    } else if (stats) {
-      atomicAdd(&stats[3], 1ull);
-    }
-  }
+  count_label_lane<false>(v, f, n, pix, stats);
 }
 
 int make_kframe(const saf_frame* fr, KFrame* kf) {

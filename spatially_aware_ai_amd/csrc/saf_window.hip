@@ -504,13 +504,17 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
           const int fbit = __ffsll((long long)mm) - 1;
           mm &= mm - 1ull;
           s_hf[prefix + r] = (uint32_t)lane | ((uint32_t)fbit << 22);
-          s_hw[prefix + r] = w0 + r;
           ++r;
         }
       }
       wave_lds_sync();
       WT(1);
-      // ---- lane-parallel over hits: projection, a = 1/(w+1), b = w*a          clipfusion.py:647-659, :716-717
+      // ---- lane-parallel over hits: projection, the hit's map cell, the frame's rgb sample and the label
+      //      count (clipfusion.py:647-659, :701-706; clip_seem_fusion.py:786-822).  The samples come from up
+      //      to 64 different images: fetched here, one round of 64 hits at a time, they cost two exposed
+      //      latencies per chunk instead of one per hit of the chunk's busiest voxel.  They are parked in
+      //      the a / b / w slots of the staging area until the blend below replaces them.
+      float* s_hs2 = reinterpret_cast<float*>(s_hw);
       for (int j0 = 0; j0 < htot; j0 += 64) {
         const int j = j0 + lane;
         const uint32_t hf = j < htot ? s_hf[j] : 0u;
@@ -521,31 +525,43 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
           voxel_coords(v, n, ix, iy, iz);
           const Cam cam = s_cam[fb];
           const Proj p = project(cam, v.ax[ix], v.ay[iy], v.az[iz]);
-          const int wi = s_hw[j];
-          const float a = 1.0f / (float)(wi + 1);
-          s_ha[j] = a;
-          s_hb[j] = (float)wi * a;
           s_hgx[j] = p.gx;
           s_hgy[j] = p.gy;
           // the hit's map cell: (y0, x0) of its four taps; every cell wholly outside the map is one cell
           const Bilin bw = bilinear_setup(p.gx, p.gy, half_px, half_py);
           const int cx = min(max(bw.x0, -2), wa.npx) + 2, cy = min(max(bw.y0, -2), wa.npy) + 2;
           s_hf[j] = hf | ((uint32_t)((cy << 8) | cx) << 6);
+          kf.rgb = s_rgb[fb];
+          kf.label_map = s_lab[fb];
+          float s0, s1, s2;
+          const int pix = sample_rgb_lane(kf, cam, p.gx, p.gy, s0, s1, s2);
+          s_ha[j] = s0;
+          s_hb[j] = s1;
+          s_hs2[j] = s2;
+          count_label_lane<true>(v, kf, n, pix, stats);
         }
       }
       wave_lds_sync();
       WT(2);
-      // ---- lane-parallel over voxels: rgb / weight / label side, hit by hit in frame order
+      // ---- lane-parallel over voxels: the rgb running mean over the voxel's hits in frame order, in
+      //      registers (clipfusion.py:715-721); a = 1/(w+1), b = w*a of every hit take the samples' slots
       if (active) {
+        float* dst = v.rgb + (int64_t)n_l * 3;
+        float o0 = dst[0], o1 = dst[1], o2 = dst[2];
         for (int r = 0; r < h; ++r) {
           const int j = prefix + r;
-          const int fb = (int)(s_hf[j] >> 22);
-          kf.rgb = s_rgb[fb];
-          kf.label_map = s_lab[fb];
-          const Cam cam = s_cam[fb];
-          fuse_scalars_lane(v, kf, cam, n_l, s_hgx[j], s_hgy[j], w0 + r, s_ha[j], s_hb[j], stats);
+          const int wi = w0 + r;
+          const float a = 1.0f / (float)(wi + 1), b = (float)wi * a;
+          o0 = blend(s_ha[j], o0, a, b, SUM);
+          o1 = blend(s_hb[j], o1, a, b, SUM);
+          o2 = blend(s_hs2[j], o2, a, b, SUM);
+          s_ha[j] = a;
+          s_hb[j] = b;
         }
+        dst[0] = o0; dst[1] = o1; dst[2] = o2;
+        v.weight[n_l] = w0 + h;
       }
+      wave_lds_sync();
       WT(3);
       // ---- rows: sub-chunks of <= SR rows and <= 64 hits
       int i0 = 0;
