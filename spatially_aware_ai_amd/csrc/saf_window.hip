@@ -585,15 +585,36 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
         // (the staging reads above come BEFORE the LDS-DMA below: the compiler drains vmcnt ahead of any LDS
         //  read that follows an LDS-DMA, which would expose the rows' whole latency right here)
         // the rows, global -> LDS (one LDS-DMA moves a wave's 64 x 16 B = one 1 KiB piece of a row)
+        // A voxel of weight 0 has never been written: its row is all zeros by construction (rows are only
+        // written together with a weight increment, clipfusion.py:715-721), so it is not read -- in a fresh
+        // volume that is every row's first window.  (For the running mean the old row would be multiplied by
+        // b = 0 anyway.)  Zero rows are written to LDS first: an LDS store after an LDS-DMA makes the compiler
+        // drain vmcnt.
         unsigned long long fmask = 0;  // frames with a hit in this sub-chunk
         WinRaw<SR, UPL> raw;
+        uint32_t fresh = 0;  // bit r: row r of the sub-chunk is untouched so far
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+          if (r < nrows && __builtin_amdgcn_readlane(w0, i0 + r) == 0) {
+            fresh |= 1u << r;
+            if (!BF16) {
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) rows[(r * CPL + c) * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+        }
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
           if (r < nrows) {
             const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
             fmask |= (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mk0, i0 + r) |
                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mk1, i0 + r) << 32);
-            if (BF16) {
+            if (fresh & (1u << r)) {
+              if (BF16) {
+#pragma unroll
+                for (int k = 0; k < UPL; ++k) raw.u[r * UPL + k] = make_uint4(0u, 0u, 0u, 0u);
+              }
+            } else if (BF16) {
 #pragma unroll
               for (int k = 0; k < UPL; ++k) {
                 const float4 t = ld_stream(featb + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * (DV / 2) +
