@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-frames 0 \
    > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || echo "trace FAILED"
-PM="python3 bench.py --cpu-frames 0 --frames 128 --steps 1 --warmup 0 --no-profile-events"
+PM="python3 bench.py --cpu-frames 0 --steps 1 --warmup 0 --no-profile-events"  # the whole 512-frame job: a row is not read in the window that first touches it
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $PM \
    > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || echo "pmc fetch FAILED"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $PM \

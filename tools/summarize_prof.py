@@ -59,7 +59,7 @@ if out:
         if "fuse_window_kernel" in out["FETCH_SIZE"]:  # the windowed path ran: per-window launches
             wt = {"grid": cfg["grid"], "dim": cfg["feat_dim"], "frames_per_launch": 64,
                   "depth_kind": "B" if "depth-B" in cfg["workload"] else "A",
-                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 128 frames (2 windows); "
+                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one 512-frame job (8 windows); "
                             "FETCH_SIZE x2 (gfx950 correction), KiB -> bytes"}
             for kn, key in (("fuse_window_kernel", "hbm"), ("classify_window_kernel", "classify_hbm")):
                 f = out["FETCH_SIZE"][kn]["mean_KiB"] * 1024 * 2
