@@ -748,10 +748,10 @@ size_t window_workspace_bytes(int64_t n_vox, int D, int P) { return win_layout(n
 bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
   static const bool enabled = !(getenv("SAF_WINDOW") && getenv("SAF_WINDOW")[0] == '0');
   if (!enabled || n_frames < kWinMinFrames || kv.D % 256 != 0 || kv.D > 1024) return false;
-  // bf16 volumes: implemented and bit-identical, but no faster than the per-frame pipeline (rows are half
-  // the bytes, the map taps are not: 3527 vs 3685 frames/s with labels, 4310 vs 4055 on the coherent
-  // scene) -- opt-in with SAF_WINDOW_BF16=1
-  static const bool bf16_on = getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '1';
+  // bf16 volumes: the rows are half the bytes, the map taps are not, so the gain is smaller than for f32
+  // (4253 vs 3916 frames/s, 3935 vs 3586 with labels, 4544 vs 3976 on the coherent scene);
+  // SAF_WINDOW_BF16=0 keeps them on the per-frame pipeline
+  static const bool bf16_on = !(getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '0');
   if (kv.bf16 && (!bf16_on || kv.D % 512 != 0)) return false;  // a lane moves 8 bf16 channels: 512 per wave
   const saf_frame& f0 = frames[0];
   for (int32_t i = 0; i < n_frames; ++i) {

@@ -6,7 +6,6 @@ Bar: index sets (weight, tsdf_weight, label histogram, argmax) bit-exact; fp32 b
 1e-4 relative."""
 import os
 
-os.environ.setdefault("SAF_WINDOW_BF16", "1")  # the opt-in bf16 variant of the windowed path is tested too (read once by the library)
 import numpy as np
 import pytest
 import torch
