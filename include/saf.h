@@ -122,8 +122,8 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
  * synchronisation between frames -- the loop of clipfusion.py:1125-1133.
  * Two device paths, identical results bit for bit:
  *  - per-frame pipeline: one sweep + one fuse kernel per frame (any shape);
- *  - windowed, voxel-major (16 or more frames of one shape, f32 volume, feat_dim a multiple of 256 up to
- *    1024): per window of SAF_WINDOW_FRAMES frames two classification launches (sweep of 32 frames each,
+ *  - windowed, voxel-major (16 or more frames of one shape; f32 volume with feat_dim a multiple of 256, or
+ *    bf16 volume with feat_dim a multiple of 512; feat_dim <= 1024): per window of SAF_WINDOW_FRAMES frames two classification launches (sweep of 32 frames each,
  *    TSDF in registers, one frame-mask word per voxel) and one row kernel that reads and writes every
  *    touched feature row once per window.
  *    SAF_WINDOW=0 in the environment forces the per-frame pipeline. */
