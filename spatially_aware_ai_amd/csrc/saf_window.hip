@@ -118,25 +118,17 @@ struct WinCfg {
 // window (clipfusion.py:647-679): the voxels' TSDF running mean is kept in registers across the frames
 // (clipfusion.py:681-695 with B = 1, frame after frame -- order dependent) and written once; mk4[j] collects
 // the frame bitmask of voxel j.  KFU frames at a time: their depth gathers are in flight together.
+// The classification of a lane's 4 consecutive voxels (flat indices nb .. nb+3, world coordinates xw/yw/zw,
+// inb = inside the grid) against the frames of `live` (bit k = frame f_begin + k), ascending.
 template <int KFU, bool SUM>
-__device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa, const Cam* __restrict__ s_cam,
-                                               uint32_t piece_base, int lane, float rtrunc, bool tsdf_aligned,
-                                               int f_begin, int f_end, uint32_t (&mk4)[4], unsigned long long& nt_done,
-                                               unsigned long long& tsdf_rows_done) {
-  const uint32_t nb = piece_base + (uint32_t)lane * 4u;
-  float xw[4], yw[4], zw[4], told[4];
+__device__ __forceinline__ void classify_voxels(const KVol& v, const WinArgs& wa, const Cam* __restrict__ s_cam, uint32_t nb,
+                                                const float (&xw)[4], const float (&yw)[4], const float (&zw)[4],
+                                                const bool (&inb)[4], float rtrunc, bool tsdf_aligned, int f_begin,
+                                                uint32_t live, uint32_t (&mk4)[4], unsigned long long& nt_done,
+                                                unsigned long long& tsdf_rows_done) {
+  float told[4];
   int tw[4];
-  bool inb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    inb[j] = nb + j < v.N;
-    int ix, iy, iz;
-    voxel_coords(v, inb[j] ? nb + j : 0u, ix, iy, iz);
-    xw[j] = v.ax[ix];
-    yw[j] = v.ay[iy];
-    zw[j] = v.az[iz];
-  }
-  const bool vec = tsdf_aligned && nb + 4u <= v.N;
+  const bool vec = tsdf_aligned && inb[3] && (nb & 3u) == 0u;
   if (vec) {
     const float4 t4 = *reinterpret_cast<const float4*>(v.tsdf + nb);
     const int4 w4 = *reinterpret_cast<const int4*>(v.tsdf_w + nb);
@@ -153,17 +145,23 @@ __device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa,
   // kFU frames at a time: all their depth gathers are in flight together, then the frames are
   // applied one after the other (the TSDF running mean is order dependent)
   constexpr int kFU = KFU;
-  for (int f0 = f_begin; f0 < f_end; f0 += kFU) {
+  while (live) {
+    int fr[kFU];  // local frame index (bit of `live`), -1 past the end
+#pragma unroll
+    for (int u = 0; u < kFU; ++u) {
+      fr[u] = live ? __ffs((int)live) - 1 : -1;
+      live &= live - (live ? 1u : 0u);
+    }
     int pix[kFU][4];  // >= 0: pixel; -1: in view, no pixel (zeros padding); -2: not in view
     float pz[kFU][4];
 #pragma unroll
     for (int u = 0; u < kFU; ++u) {
-      const bool live = f0 + u < f_end;
-      const Cam cam = s_cam[live ? f0 + u : 0];
+      const bool on = fr[u] >= 0;
+      const Cam cam = s_cam[f_begin + (on ? fr[u] : 0)];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const Proj p = project(cam, xw[j], yw[j], zw[j]);
-        const bool in_view = live && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
+        const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
         const int px = nearest_index(p.gx, p.gy, cam, wa.W);
         pix[u][j] = in_view ? (px >= 0 ? px : -1) : -2;
         pz[u][j] = p.z;
@@ -172,7 +170,7 @@ __device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa,
     float depth[kFU][4];
 #pragma unroll
     for (int u = 0; u < kFU; ++u) {
-      const float* __restrict__ dimg = wa.depth[f0 + u < f_end ? f0 + u : 0];
+      const float* __restrict__ dimg = wa.depth[f_begin + (fr[u] >= 0 ? fr[u] : 0)];
 #pragma unroll
       for (int j = 0; j < 4; ++j) depth[u][j] = pix[u][j] >= 0 ? dimg[pix[u][j]] : 0.0f;
     }
@@ -183,7 +181,7 @@ __device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa,
         const bool in_view = pix[u][j] != -2;
         const float num = depth[u][j] - pz[u][j];
         const float sdf = num == INFINITY ? INFINITY : div_by_uniform(num, v.trunc, rtrunc);
-        if (in_view && fabsf(sdf) <= 1.0f) mk4[j] |= 1u << (f0 + u - f_begin);
+        if (in_view && fabsf(sdf) <= 1.0f) mk4[j] |= 1u << fr[u];
         if (in_view && sdf > -1.0f) {
           const float t = sdf > 1.0f ? 1.0f : sdf;
           const int w1 = tw[j] + 1;
@@ -217,22 +215,74 @@ __device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa,
   }
 }
 
+// Classification of one piece of 256 consecutive voxels (a lane owns 4 of them) against frames
+// [f_begin, f_end) (clipfusion.py:647-695): used when the grid does not tile into bricks.
+template <int KFU, bool SUM>
+__device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa, const Cam* __restrict__ s_cam,
+                                               uint32_t piece_base, int lane, float rtrunc, bool tsdf_aligned,
+                                               int f_begin, int f_end, uint32_t (&mk4)[4], unsigned long long& nt_done,
+                                               unsigned long long& tsdf_rows_done) {
+  const uint32_t nb = piece_base + (uint32_t)lane * 4u;
+  float xw[4], yw[4], zw[4];
+  bool inb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    inb[j] = nb + j < v.N;
+    int ix, iy, iz;
+    voxel_coords(v, inb[j] ? nb + j : 0u, ix, iy, iz);
+    xw[j] = v.ax[ix];
+    yw[j] = v.ay[iy];
+    zw[j] = v.az[iz];
+  }
+  const int nf = f_end - f_begin;
+  const uint32_t live = nf >= 32 ? 0xffffffffu : ((1u << nf) - 1u);
+  classify_voxels<KFU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, f_begin, live, mk4, nt_done,
+                            tsdf_rows_done);
+}
+
+// Counters of a classification launch.  One atomic per WAVE on stats[1] / stats[6] would be 131 k atomics on
+// two addresses per launch -- they serialise in L2 and took 0.7 ms of a 1.8 ms kernel.  The four waves of a
+// workgroup are summed in LDS and added to one of 64 shards in the workspace header; the window's row kernel
+// folds the shards into stats[].
+constexpr int kClsShards = 64;
+constexpr size_t kClsAccOff = 1024;  // 64 x {tsdf updates, tsdf voxels} u64 in the workspace header
+__device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsigned long long tsdf_rows_done, int lane, int wave,
+                                               unsigned long long (&s_acc)[4][2], unsigned long long* __restrict__ cls_acc) {
+  for (int o = 32; o > 0; o >>= 1) {
+    nt_done += __shfl_xor(nt_done, o);
+    tsdf_rows_done += __shfl_xor(tsdf_rows_done, o);
+  }
+  if (lane == 0) {
+    s_acc[wave][0] = nt_done;
+    s_acc[wave][1] = tsdf_rows_done;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && cls_acc) {
+    const unsigned long long a = s_acc[0][0] + s_acc[1][0] + s_acc[2][0] + s_acc[3][0];
+    const unsigned long long b = s_acc[0][1] + s_acc[1][1] + s_acc[2][1] + s_acc[3][1];
+    unsigned long long* shard = cls_acc + 2 * (blockIdx.x % kClsShards);
+    if (a) atomicAdd(&shard[0], a);
+    if (b) atomicAdd(&shard[1], b);
+  }
+}
+
 // classify_window_kernel: one launch per 32 frames of a window [f_begin, f_end); leaves that mask word of
 // every voxel in its plane of `hitmask` and the updated TSDF.  (One launch over all 64 frames keeps the TSDF
 // in registers twice as long but puts 64 depth-image footprints in L2 at once: 4.2 ms against 2 x 1.9 ms.)
 template <bool SUM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_window_kernel(
     KVol v, WinArgs wa, int f_begin, int f_end, int tile, uint32_t* __restrict__ hitmask,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, unsigned long long* __restrict__ cls_acc) {
   __shared__ Cam s_cam[kWin];
+  __shared__ unsigned long long s_acc[4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid >= f_begin && tid < f_end) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
   __syncthreads();
   if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)(f_end - f_begin));
   const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
   uint32_t piece = blockIdx.x * 4u + (uint32_t)wave;
-  if (piece >= n_pieces) return;
-  if (tile > 0) {
+  const bool on = piece < n_pieces;  // (no early return: the workgroup meets again in cls_accumulate)
+  if (on && tile > 0) {
     // Workgroups are dispatched in index order, so the few thousand pieces in flight at any time are
     // consecutive indices.  In linear order those are a few whole x-planes of the grid -- seen face-on
     // they cover the whole depth image of a frame.  Walking the (x-plane, piece-in-plane) rectangle in
@@ -247,25 +297,128 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
   const float rtrunc = 1.0f / v.trunc;
   const bool tsdf_aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
   unsigned long long nt_done = 0, tsdf_rows_done = 0;
-  const uint32_t nb = piece * (uint32_t)kPiece + (uint32_t)lane * 4u;
-  uint32_t mk4[4] = {0u, 0u, 0u, 0u};
-  classify_piece<4, SUM>(v, wa, s_cam, piece * (uint32_t)kPiece, lane, rtrunc, tsdf_aligned, f_begin, f_end, mk4, nt_done,
-                         tsdf_rows_done);
-  if (nb + 3u < v.N) {
-    *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);
-  } else {
+  if (on) {
+    const uint32_t nb = piece * (uint32_t)kPiece + (uint32_t)lane * 4u;
+    uint32_t mk4[4] = {0u, 0u, 0u, 0u};
+    classify_piece<4, SUM>(v, wa, s_cam, piece * (uint32_t)kPiece, lane, rtrunc, tsdf_aligned, f_begin, f_end, mk4, nt_done,
+                           tsdf_rows_done);
+    if (nb + 3u < v.N) {
+      *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (nb + k < v.N) hitmask[nb + k] = mk4[k];
+      for (int k = 0; k < 4; ++k)
+        if (nb + k < v.N) hitmask[nb + k] = mk4[k];
+    }
+  }
+  cls_accumulate(nt_done, tsdf_rows_done, lane, wave, s_acc, stats ? cls_acc : nullptr);
+}
+
+// ---- brick-shaped pieces: the classification of grids that tile into 4 x 4 x 16 bricks ----
+// A z-column piece is almost never outside a frame's view as a whole; a compact brick often is -- outside
+// the frustum, or farther than anything the frame has seen (z beyond the image's largest depth + trunc:
+// neither valid nor tsdf_valid).  The wave tests its brick against the launch's 32 frames lane-parallel
+// (lane k tests frame k: bounding sphere against the frustum planes and the depth bound, generous margins)
+// and classifies only the frames that survive; the arithmetic of the surviving frames is unchanged.
+constexpr int kBrickX = 4, kBrickY = 4, kBrickZ = 16;
+constexpr size_t kDmaxOff = 256;  // 32 floats in the workspace header: largest depth of each frame of a launch
+
+// dmax[k] = max over the pixels of frame k of max(depth, 0) (NaN ignored, +inf kept): non-negative floats
+// order like their bit patterns, so an integer atomicMax does it.
+__global__ __launch_bounds__(256) void depth_max_kernel(WinArgs wa, int f_begin, int hw, int* __restrict__ dmax_bits) {
+  const float* __restrict__ d = wa.depth[f_begin + blockIdx.y];
+  float m = 0.0f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+    const float x = d[i];
+    m = x > m ? x : m;
   }
   for (int o = 32; o > 0; o >>= 1) {
-    nt_done += __shfl_xor(nt_done, o);
-    tsdf_rows_done += __shfl_xor(tsdf_rows_done, o);
+    const float t = __shfl_xor(m, o);
+    m = t > m ? t : m;
   }
-  if (stats && lane == 0) {
-    if (nt_done) atomicAdd(&stats[1], nt_done);
-    if (tsdf_rows_done) atomicAdd(&stats[6], tsdf_rows_done);
+  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(&dmax_bits[blockIdx.y], __builtin_bit_cast(int, m));
+}
+
+template <bool SUM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_bricks_kernel(
+    KVol v, WinArgs wa, int f_begin, int f_end, int tiled, const float* __restrict__ dmax, uint32_t* __restrict__ hitmask,
+    unsigned long long* __restrict__ stats, unsigned long long* __restrict__ cls_acc) {
+  __shared__ Cam s_cam[kWin];
+  __shared__ unsigned long long s_acc[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_f = f_end - f_begin;
+  if (tid >= f_begin && tid < f_end) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
+  __syncthreads();
+  if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_f);
+  const uint32_t nbx = (uint32_t)v.nx / kBrickX, nby = (uint32_t)v.ny / kBrickY, nbz = (uint32_t)v.nz / kBrickZ;
+  const uint32_t q_raw = blockIdx.x * 4u + (uint32_t)wave;
+  const bool on = q_raw < nbx * nby * nbz;  // (no early return: the workgroup meets again in cls_accumulate)
+  const uint32_t q = on ? q_raw : 0u;
+  // bricks in flight form a compact box: z fastest, then 8 x 8 tiles of brick columns (32 x 32 voxels)
+  const uint32_t bz = q % nbz, t = q / nbz;
+  uint32_t bx, by;
+  if (tiled) {
+    const uint32_t tiles_y = nby / 8u, tt = t / 64u, r = t % 64u;
+    bx = (tt / tiles_y) * 8u + r / 8u;
+    by = (tt % tiles_y) * 8u + r % 8u;
+  } else {
+    bx = t / nby;
+    by = t % nby;
   }
+  const int ix = (int)bx * kBrickX + (lane & 3), iy = (int)by * kBrickY + ((lane >> 2) & 3);
+  const int iz0 = (int)bz * kBrickZ + (lane >> 4) * 4;
+  const uint32_t nb = ((uint32_t)ix * (uint32_t)v.ny + (uint32_t)iy) * (uint32_t)v.nz + (uint32_t)iz0;
+  float xw[4], yw[4], zw[4];
+  bool inb[4];
+  const float x_l = v.ax[ix], y_l = v.ay[iy];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xw[j] = x_l;
+    yw[j] = y_l;
+    zw[j] = v.az[iz0 + j];
+    inb[j] = true;
+  }
+  // ---- which frames can touch this brick at all?  lane k tests frame k
+  uint32_t live;
+  {
+    const float x0 = v.ax[bx * kBrickX], x1 = v.ax[bx * kBrickX + kBrickX - 1];
+    const float y0 = v.ay[by * kBrickY], y1 = v.ay[by * kBrickY + kBrickY - 1];
+    const float z0 = v.az[bz * kBrickZ], z1 = v.az[bz * kBrickZ + kBrickZ - 1];
+    const float cxw = 0.5f * (x0 + x1), cyw = 0.5f * (y0 + y1), czw = 0.5f * (z0 + z1);
+    const float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
+    const float rho = sqrtf(hx * hx + hy * hy + hz * hz) * 1.02f + 1e-4f;  // voxel CENTRES are what is tested
+    bool dead = false;
+    if (lane < n_f) {
+      const Cam c = s_cam[f_begin + lane];
+      const bool pinhole = c.k01 == 0.0f && c.k10 == 0.0f && c.k20 == 0.0f && c.k21 == 0.0f && c.k22 == 1.0f;
+      const float dx = cxw - c.tx, dy = cyw - c.ty, dz = czw - c.tz;
+      const float xc = c.r00 * dx + c.r10 * dy + c.r20 * dz;  // R^T (X - t)
+      const float yc = c.r01 * dx + c.r11 * dy + c.r21 * dz;
+      const float zc = c.r02 * dx + c.r12 * dy + c.r22 * dz;
+      const float far_z = dmax[lane] + v.trunc * 1.01f + 1e-4f;  // beyond it: sdf < -1 for every pixel (inf: never)
+      dead = zc + rho <= 0.0f || zc - rho > far_z;
+      if (pinhole) {
+        // in view <=> -0.5 <= u/z <= W - 0.5 and -0.5 <= v/z <= H - 0.5 with u = k00 x + k02 z, v = k11 y + k12 z:
+        // four planes through the camera centre; the brick is outside if its centre is farther than rho behind one
+        const float a1 = c.k02 + 0.5f, a2 = c.k02 - c.fw + 0.5f, b1 = c.k12 + 0.5f, b2 = c.k12 - c.fh + 0.5f;
+        const float d1 = (c.k00 * xc + a1 * zc) / sqrtf(c.k00 * c.k00 + a1 * a1);
+        const float d2 = (c.k00 * xc + a2 * zc) / sqrtf(c.k00 * c.k00 + a2 * a2);
+        const float e1 = (c.k11 * yc + b1 * zc) / sqrtf(c.k11 * c.k11 + b1 * b1);
+        const float e2 = (c.k11 * yc + b2 * zc) / sqrtf(c.k11 * c.k11 + b2 * b2);
+        const bool fx_pos = c.k00 > 0.0f, fy_pos = c.k11 > 0.0f;  // the usual orientation; otherwise no frustum cull
+        dead = dead || (fx_pos && (d1 < -rho || d2 > rho)) || (fy_pos && (e1 < -rho || e2 > rho));
+      }
+    }
+    live = on ? (uint32_t)__ballot(lane < n_f && !dead) : 0u;
+  }
+  const float rtrunc = 1.0f / v.trunc;
+  const bool tsdf_aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
+  unsigned long long nt_done = 0, tsdf_rows_done = 0;
+  uint32_t mk4[4] = {0u, 0u, 0u, 0u};
+  if (live)
+    classify_voxels<4, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, f_begin, live, mk4, nt_done,
+                            tsdf_rows_done);
+  if (on) *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);  // nz % 16 == 0: aligned
+  cls_accumulate(nt_done, tsdf_rows_done, lane, wave, s_acc, stats ? cls_acc : nullptr);
 }
 
 // One hit of a sub-chunk, held by the lane with the hit's index.
@@ -388,7 +541,7 @@ template <int CPL, bool SUM, bool BF16>
 __global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(SAF_WIN_WPE, SAF_WIN_WPE))) void
 fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int img_vecs,
                    unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
-                   const uint32_t* __restrict__ hitmask, uint32_t mask_plane) {
+                   const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc) {
   using Cfg = WinCfg<CPL>;
   constexpr int SR = Cfg::SR;
   // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
@@ -409,6 +562,17 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
   const float** s_lab = s_rgb + kWin;
   Cam* s_cam = reinterpret_cast<Cam*>(s_dyn + Cfg::cam_off);
 
+  if (stats && blockIdx.x == 0 && tid < kClsShards) {  // the classification launches' sharded counters (see cls_accumulate)
+    unsigned long long a = cls_acc[2 * tid], b = cls_acc[2 * tid + 1];
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    if (tid == 0) {
+      if (a) atomicAdd(&stats[1], a);
+      if (b) atomicAdd(&stats[6], b);
+    }
+  }
   if (tid < wa.F) {
     s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
     s_rgb[tid] = wa.rgb[tid];
@@ -729,7 +893,8 @@ WinLayout win_layout(int64_t n_vox, int D, int P) {
   return w;
 }
 
-using WinFn = void (*)(KVol, WinArgs, const float*, int, unsigned long long*, unsigned int*, const uint32_t*, uint32_t);
+using WinFn = void (*)(KVol, WinArgs, const float*, int, unsigned long long*, unsigned int*, const uint32_t*, uint32_t,
+                       const unsigned long long*);
 template <int CPL>
 WinFn pick_win(bool sum, bool bf16) {
   if (bf16) {
@@ -813,6 +978,14 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     while (tile >= 8 && (ppx % tile != 0 || kv.nx % tile != 0)) tile >>= 1;
     if (tile < 8) tile = 0;  // linear order
   }
+  // grids that tile into 4 x 4 x 16 bricks classify brick by brick (SAF_WIN_BRICKS=0: always the linear pieces)
+  static const bool bricks_on = !(getenv("SAF_WIN_BRICKS") && getenv("SAF_WIN_BRICKS")[0] == '0');
+  const bool bricks = bricks_on && kv.nx % kBrickX == 0 && kv.ny % kBrickY == 0 && kv.nz % kBrickZ == 0;
+  const int brick_tiles = (kv.nx / kBrickX) % 8 == 0 && (kv.ny / kBrickY) % 8 == 0 ? 1 : 0;
+  float* dmax = reinterpret_cast<float*>(ws + kDmaxOff);
+  unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(ws + kClsAccOff);
+  static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kDmaxOff + 32 * sizeof(float) <= kClsAccOff,
+                "workspace header layout");
   const int n_win = (n_frames + kWin - 1) / kWin;
   for (int w = 0; w < n_win; ++w) {
     const int f0 = w * kWin;
@@ -825,20 +998,33 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       wa.depth[k] = fr.depth; wa.rgb[k] = fr.rgb; wa.pose[k] = fr.pose; wa.K[k] = fr.K; wa.label_map[k] = fr.label_map;
       pa.feat_map[k] = fr.feat_map;
     }
+    // header: piece counter, dmax, the classification launches' counter shards
+    if (hipMemsetAsync(ws, 0, kHdrBytes, s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
     for (int fb = 0; fb < F; fb += 32) {
       const int fe = fb + 32 < F ? fb + 32 : F;
       uint32_t* plane = masks + (size_t)(fb / 32) * wl.mask_plane;
+      if (bricks) {  // the frames' largest depths feed the bricks' frame cull
+        if (hipMemsetAsync(dmax, 0, 32 * sizeof(float), s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(dmax)");
+        hipLaunchKernelGGL(depth_max_kernel, dim3(32, fe - fb), dim3(256), 0, s, wa, fb, kf0.H * kf0.W,
+                           reinterpret_cast<int*>(dmax));
+      }
       ScopedPair t(prof, 1, f0 + fb, s);
-      if (sum)
+      if (bricks) {
+        if (sum)
+          hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, brick_tiles, dmax,
+                             plane, reinterpret_cast<unsigned long long*>(stats), cls_acc);
+        else
+          hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, brick_tiles, dmax,
+                             plane, reinterpret_cast<unsigned long long*>(stats), cls_acc);
+      } else if (sum) {
         hipLaunchKernelGGL(classify_window_kernel<true>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, tile, plane,
-                           reinterpret_cast<unsigned long long*>(stats));
-      else
+                           reinterpret_cast<unsigned long long*>(stats), cls_acc);
+      } else {
         hipLaunchKernelGGL(classify_window_kernel<false>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, tile, plane,
-                           reinterpret_cast<unsigned long long*>(stats));
+                           reinterpret_cast<unsigned long long*>(stats), cls_acc);
+      }
     }
     if ((rc = check_launch("classify_window_kernel"))) return rc;
-    if (hipMemsetAsync(piece_ctr, 0, sizeof(unsigned int), s) != hipSuccess)
-      return fail(SAF_E_HIP, "hipMemsetAsync(piece counter)");
     {
       ScopedPair t(prof, 0, f0, s);
       hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, pa, maps,
@@ -848,7 +1034,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     {
       ScopedPair t(prof, 2, f0, s);
       hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, maps, img_vecs,
-                         reinterpret_cast<unsigned long long*>(stats), piece_ctr, masks, wl.mask_plane);
+                         reinterpret_cast<unsigned long long*>(stats), piece_ctr, masks, wl.mask_plane, cls_acc);
     }
     if ((rc = check_launch("fuse_window_kernel"))) return rc;
   }
