@@ -89,6 +89,9 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_WIN_P2
 #define SAF_WIN_P2 4
 #endif
+#ifndef SAF_WIN_SPLIT_LOG2
+#define SAF_WIN_SPLIT_LOG2 2  // a piece is handed out in 2^k parts (quarters measured best: halves 6967, quarters 7165, eighths 6049 frames/s on the coherent scene)
+#endif
 #ifndef SAF_WIN_SR2
 #define SAF_WIN_SR2 6
 #endif
@@ -598,11 +601,15 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
   // persistent grid (2 workgroups of 4 waves per CU, 71 KB of LDS each).  Pieces are handed out by an
   // atomic counter: a coherent scene concentrates its hits in few pieces (a wall = whole columns).
   const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
+  // The unit of work is a QUARTER of a piece (the voxels of 16 lanes): a column inside a wall carries
+  // thousands of hits, and whoever draws it last decides when the kernel ends.
   for (;;) {
-    uint32_t piece = 0;
-    if (lane == 0) piece = atomicAdd(piece_ctr, 1u);
-    piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece);
+    uint32_t unit = 0;
+    if (lane == 0) unit = atomicAdd(piece_ctr, 1u);
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    const uint32_t piece = unit >> SAF_WIN_SPLIT_LOG2;
     if (piece >= n_pieces) break;
+    const bool mine = (uint32_t)(lane >> (6 - SAF_WIN_SPLIT_LOG2)) == (unit & ((1u << SAF_WIN_SPLIT_LOG2) - 1u));
     const uint32_t piece_base = piece * (uint32_t)kPiece;
     // ---- the piece's touched voxels: (local id, frame mask) left by classify_window_kernel, compacted into LDS
     uint32_t mk4[4][kMaskWords];
@@ -626,7 +633,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
     int T = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const bool touched = (mk4[k][0] | mk4[k][1]) != 0u;
+      const bool touched = mine && (mk4[k][0] | mk4[k][1]) != 0u;
       const unsigned long long bal = __ballot(touched);
       if (touched) {
         const int slot = T + __popcll(bal & lt_mask);
