@@ -89,6 +89,12 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_WIN_P2
 #define SAF_WIN_P2 4
 #endif
+#ifndef SAF_CLS_WPE
+#define SAF_CLS_WPE 5  // classify_bricks_kernel: waves per SIMD the register budget is set for (78 VGPRs, no spills)
+#endif
+#ifndef SAF_CLS_FU
+#define SAF_CLS_FU 1   // frames classified together: with the frame cull, occupancy hides the depth gathers better than batching does (1: 1.13 ms, 2: 1.17, 4: 1.29, 8: 2.08 per launch)
+#endif
 #ifndef SAF_WIN_SPLIT_LOG2
 #define SAF_WIN_SPLIT_LOG2 2  // a piece is handed out in 2^k parts (quarters measured best: halves 6967, quarters 7165, eighths 6049 frames/s on the coherent scene)
 #endif
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256) void depth_max_kernel(WinArgs wa, int f_begin,
 }
 
 template <bool SUM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_bricks_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE))) void classify_bricks_kernel(
     KVol v, WinArgs wa, int f_begin, int f_end, int tiled, const float* __restrict__ dmax, uint32_t* __restrict__ hitmask,
     unsigned long long* __restrict__ stats, unsigned long long* __restrict__ cls_acc) {
   __shared__ Cam s_cam[kWin];
@@ -418,8 +424,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
   unsigned long long nt_done = 0, tsdf_rows_done = 0;
   uint32_t mk4[4] = {0u, 0u, 0u, 0u};
   if (live)
-    classify_voxels<4, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, f_begin, live, mk4, nt_done,
-                            tsdf_rows_done);
+    classify_voxels<SAF_CLS_FU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, f_begin, live, mk4, nt_done,
+                                     tsdf_rows_done);
   if (on) *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);  // nz % 16 == 0: aligned
   cls_accumulate(nt_done, tsdf_rows_done, lane, wave, s_acc, stats ? cls_acc : nullptr);
 }
