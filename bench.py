@@ -288,6 +288,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if (tj.get("grid") == a.grid and tj.get("dim") == a.dim and tj.get("depth_kind", "A") == a.depth_kind
+                        and tj.get("dtype", "f32") == a.feat_dtype and not a.labels
                         and tj.get("frames_per_launch", 1) == (WIN if windowed else 1)):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:

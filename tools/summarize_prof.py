@@ -33,6 +33,8 @@ if os.path.exists(f"{src}/bench_under_rocprof.json"):
 
 
 def name_of(k):
+    if "classify_bricks_kernel" in k:
+        return "classify_window_kernel"  # the brick-shaped form of the same launch
     for n in ("fuse_window_kernel", "classify_window_kernel", "fuse_rows_kernel", "fuse_kernel", "sweep_kernel",
               "prep_rows_kernel", "prep_kernel", "query_kernel"):
         if n in k:
@@ -57,7 +59,7 @@ if out:
         bj = json.loads(open(f"{src}/pmc_fetch.json").read().strip().splitlines()[-1])
         cfg = bj["config"]
         if "fuse_window_kernel" in out["FETCH_SIZE"]:  # the windowed path ran: per-window launches
-            wt = {"grid": cfg["grid"], "dim": cfg["feat_dim"], "frames_per_launch": 64,
+            wt = {"grid": cfg["grid"], "dim": cfg["feat_dim"], "dtype": bj.get("dtype", "f32"), "frames_per_launch": 64,
                   "depth_kind": "B" if "depth-B" in cfg["workload"] else "A",
                   "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one 512-frame job (8 windows); "
                             "FETCH_SIZE x2 (gfx950 correction), KiB -> bytes"}
