@@ -404,8 +404,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
       const float yc = c.r01 * dx + c.r11 * dy + c.r21 * dz;
       const float zc = c.r02 * dx + c.r12 * dy + c.r22 * dz;
       const float far_z = dmax[lane] + v.trunc * 1.01f + 1e-4f;  // beyond it: sdf < -1 for every pixel (inf: never)
-      dead = zc + rho <= 0.0f || zc - rho > far_z;
-      if (pinhole) {
+      // the sphere argument needs a rigid pose (R orthonormal: distances survive R^T) and z = the camera-space
+      // z (third row of K = 0 0 1); anything else is classified without a cull
+      const float n0 = c.r00 * c.r00 + c.r10 * c.r10 + c.r20 * c.r20, n1 = c.r01 * c.r01 + c.r11 * c.r11 + c.r21 * c.r21;
+      const float n2 = c.r02 * c.r02 + c.r12 * c.r12 + c.r22 * c.r22;
+      const float d01 = c.r00 * c.r01 + c.r10 * c.r11 + c.r20 * c.r21, d02 = c.r00 * c.r02 + c.r10 * c.r12 + c.r20 * c.r22;
+      const float d12 = c.r01 * c.r02 + c.r11 * c.r12 + c.r21 * c.r22;
+      const bool rigid = fabsf(n0 - 1.0f) < 1e-3f && fabsf(n1 - 1.0f) < 1e-3f && fabsf(n2 - 1.0f) < 1e-3f &&
+                         fabsf(d01) < 1e-3f && fabsf(d02) < 1e-3f && fabsf(d12) < 1e-3f;
+      const bool z_is_depth = c.k20 == 0.0f && c.k21 == 0.0f && c.k22 == 1.0f;
+      dead = rigid && z_is_depth && (zc + rho <= 0.0f || zc - rho > far_z);
+      if (pinhole && rigid) {
         // in view <=> -0.5 <= u/z <= W - 0.5 and -0.5 <= v/z <= H - 0.5 with u = k00 x + k02 z, v = k11 y + k12 z:
         // four planes through the camera centre; the brick is outside if its centre is farther than rho behind one
         const float a1 = c.k02 + 0.5f, a2 = c.k02 - c.fw + 0.5f, b1 = c.k12 + 0.5f, b2 = c.k12 - c.fh + 0.5f;

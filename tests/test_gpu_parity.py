@@ -388,6 +388,14 @@ def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_
     d5[0, 20:23, 5:25] = -1.0
     d5[0, 30:33, 5:25] = float("-inf")
     frames[5] = dict(frames[5], depth=d5)
+    # cameras the brick cull of the classification must not reason about: skewed K, a third row of K that is
+    # not (0, 0, 1), a pose whose rotation block is scaled (not rigid)
+    k7 = frames[7]["K"].clone(); k7[0, 0, 1] = 4.0
+    k8 = frames[8]["K"].clone(); k8[0, 2, 0] = 0.02; k8[0, 2, 2] = 0.97
+    p9 = frames[9]["pose"].clone(); p9[0, :3, :3] *= 1.07
+    frames[7] = dict(frames[7], K=k7)
+    frames[8] = dict(frames[8], K=k8)
+    frames[9] = dict(frames[9], pose=p9)
     frames += syn.make_frames(910, 1, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="A", radius=0.6)
 
     def build():
