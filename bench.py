@@ -12,6 +12,14 @@ kernels per frame, one C-ABI call, no host sync), and -- for N > 1 -- the single
 (reduce-scatter of the per-rank SUM volumes + local divide).  Inputs are resident in HBM before
 the timed region.  value = N * frames_per_rank * K / max-over-ranks wall time of the K steps.
 
+N > 1: when WORLD_SIZE is not set, `python bench.py --gpus N` starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches the GPU), forwards
+rank 0's JSON line and exits non-zero if any rank fails.  The headline `value` of an N > 1 run is the SERIAL-merge
+job (fuse, then the RCCL merge, nothing overlapped: BASELINE config 4 is one job); the same K steps are then timed
+again with each job's merge overlapped with the next job's fusion (`overlapped_merge`).  After the timed regions an
+untimed integrity pass proves the merge: weight sums against the kernels' valid counts, and the merged voxel shard
+of a small sharded job against a single-rank fusion of all its frames (`merge_check`).
+
 Extra objects on the JSON line:
   roofline     : the dominant kernel (fuse_kernel): algorithmic bytes per launch (from the Nv
                  counters the kernels emit, SURVEY.md §8d formula) / its average launch duration,
@@ -54,8 +62,9 @@ def parse():
                     help="distinct synthetic frames resident per rank (cycled to --frames)")
     ap.add_argument("--merge", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
     ap.add_argument("--no-overlap-merge", action="store_true",
-                    help="N > 1: run each step's merge on the compute stream instead of overlapping it with the "
-                         "next step's fusion (second volume + side stream)")
+                    help="N > 1: skip the second timed region (merge of job k overlapped with the fusion of job k+1)")
+    ap.add_argument("--check-frames", type=int, default=4,
+                    help="N > 1: frames per rank of the untimed merge-integrity job (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the control flow)")
     ap.add_argument("--feat-dtype", default="f32", choices=["f32", "bf16"],
@@ -69,6 +78,11 @@ def parse():
                          "ViT-B/32-shaped random-weight CLIP image tower in front of the fuse (reported separately)")
     ap.add_argument("--e2e-batch", type=int, default=8, help="frames per integrate() call in the end-to-end pass")
     ap.add_argument("--e2e-dtype", default="f32", choices=["f32", "bf16"], help="backbone compute dtype")
+    ap.add_argument("--api-b1", type=int, default=0, metavar="FRAMES",
+                    help="also time FRAMES frames through integrate_features() ONE FRAME PER CALL (the reference's loop, "
+                         "clipfusion.py:1125-1133) with the deferred window queue behind it; reported as api_b1")
+    ap.add_argument("--query", action="store_true",
+                    help="benchmark the text-query scan instead (BASELINE config 5 and the reference's L = 5 / L = 63 scans)")
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="record HIP events around the kernels of every n-th frame of the timed region")
     return ap.parse_args()
@@ -95,18 +109,58 @@ def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device):
     return depth, rgb, poses, ks, feat
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree
+    (torch.distributed.run) before this process has touched the GPU, forward rank 0's JSON line, and
+    exit with the launcher's code.  (A process that has initialised HIP must never exec or fork ranks.)"""
+    import socket
+    import subprocess
+
+    if os.environ.get("SAF_BENCH_ONE_DEVICE") != "1":
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but this node shows {have} GPU(s) "
+                             "(SAF_BENCH_ONE_DEVICE=1 --backend gloo rehearses the control flow on one GPU)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or f"the {a.gpus}-rank run printed no result line")
+    print(line, flush=True)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return launch_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world > 1 and a.feat_dtype != "f32":
+        raise SystemExit("--gpus > 1 needs --feat-dtype f32: the per-rank volumes hold SUMS until the merge "
+                         "(spatially_aware_ai_amd/distributed.py); bf16 sums would round every addition")
+    if a.query:
+        return bench_query(a, world, rank, local_rank)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     if os.environ.get("SAF_BENCH_ONE_DEVICE") == "1":
         local_rank = 0  # rehearsal: every rank on the one GPU of the box
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -115,6 +169,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(a.backend)
+        assert dist.get_world_size() == world
 
     from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
     from spatially_aware_ai_amd import distributed as sdist
@@ -128,20 +183,19 @@ def main():
 
     fdt = torch.bfloat16 if a.feat_dtype == "bf16" else torch.float32
     esz = 2 if a.feat_dtype == "bf16" else 4
-    # N > 1: consecutive steps are independent jobs, so job k's merge (RCCL, side stream) overlaps
-    # job k+1's fusion into a second volume; all of it is inside the timed region.
-    overlap = world > 1 and not a.no_overlap_merge
-    fusions = []
-    for _ in range(2 if overlap else 1):
+
+    def new_volume():
         if a.labels:
             fz = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, a.height // 3,
                                 a.height // 6, ResidentFeatures(), None, keep_xyz_world=False, feat_dtype=fdt)
         else:
             fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, ResidentFeatures(), None,
                             a.height // 3, a.height // 6, keep_xyz_world=False, feat_dtype=fdt)
-        fz = fz.to(device)
-        fz.accum_mode = _abi.SAF_SUM if world > 1 else _abi.SAF_RUNNING_MEAN
-        fusions.append(fz)
+        return fz.to(device)
+
+    # N > 1 keeps two volumes: the second one lets job k+1 fuse while job k's merge drains (second timed
+    # region) and holds the single-rank reference of the integrity pass
+    fusions = [new_volume() for _ in range(2 if world > 1 else 1)]
     fusion = fusions[0]
 
     uniq = min(a.unique_frames, a.frames)
@@ -156,12 +210,9 @@ def main():
     for i in range(a.frames):
         frames[i] = arr_u[i % uniq]
     ws = fusion._get_workspace(npy, npx)
-    vols = [fz._c_volume() for fz in fusions]
-    vol = vols[0]
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
-    comm_stream = torch.cuda.Stream() if overlap else main_stream
-    merge_done = [None] * len(fusions)
+    comm_stream = torch.cuda.Stream() if world > 1 else main_stream
     merge_state = {"mode": a.merge, "fallback": None}
     L = lib()
     prof = None
@@ -169,78 +220,101 @@ def main():
         prof = L.saf_profiler_create(3 * a.frames * max(1, a.steps))
         L.saf_profiler_set_stride(prof, a.profile_stride)
 
-    def volume_tensors(fz):
-        ts = [fz.clip_feat, fz.rgb, fz.tsdf, fz.weight, fz.tsdf_weight]
-        if a.labels:
-            ts.append(fz.labels_one_hot)
-        return ts
-
-    vol_tensors = [volume_tensors(fz) for fz in fusions]
-    step_no = [0]
+    def fuse_into(fz, frame_arr, n_frames, profiler):
+        vol = fz._c_volume()
+        rc = L.saf_fuse_frames_profiled(C.byref(vol), frame_arr, n_frames, ws.data_ptr(), ws.numel(),
+                                        fusion.fuse_stats.data_ptr(), profiler, stream)
+        check(rc, "saf_fuse_frames_profiled")
 
     def merge(fz):
-        fz.accum_mode = _abi.SAF_SUM
         try:
-            sdist.merge_volumes(fz, mode=merge_state["mode"])
-        except Exception as e:  # e.g. a backend without (in-place) reduce-scatter: fall back, keep measuring
+            return sdist.merge_volumes(fz, mode=merge_state["mode"])
+        except Exception as e:  # e.g. a backend without (in-place) reduce-scatter: fall back, say so on the line
             if merge_state["mode"] == "all_reduce":
                 raise
             merge_state["fallback"] = f"{type(e).__name__}: {e}"[:200]
             merge_state["mode"] = "all_reduce"
-            fz.accum_mode = _abi.SAF_SUM
-            sdist.merge_volumes(fz, mode="all_reduce")
-
-    def step(profiler):
-        slot = step_no[0] % len(fusions)
-        step_no[0] += 1
-        fz = fusions[slot]
-        if merge_done[slot] is not None:  # this volume's previous merge must have drained
-            main_stream.wait_event(merge_done[slot])
-        for t in vol_tensors[slot]:
-            t.zero_()
-        rc = L.saf_fuse_frames_profiled(C.byref(vols[slot]), frames, a.frames, ws.data_ptr(), ws.numel(),
-                                        fusion.fuse_stats.data_ptr(), profiler, stream)
-        check(rc, "saf_fuse_frames_profiled")
-        if world > 1:
-            if overlap:
-                fused = main_stream.record_event()
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(fused)
-                    merge(fz)
-                    merge_done[slot] = comm_stream.record_event()
-            else:
-                merge(fz)
+            fz.accum_mode, fz._shard_range = _abi.SAF_SUM, None
+            return sdist.merge_volumes(fz, mode="all_reduce")
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step(None)
-    barrier()
-    fusion.fuse_stats.zero_()
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(prof)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def run_region(n_steps, overlap, profiler):
+        """n_steps whole jobs; returns the max-over-ranks wall time.  overlap: job k's merge runs on the side
+        stream while job k+1 fuses into the other volume (events order the reuse of a volume behind its merge)."""
+        merge_done = [None] * len(fusions)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            slot = k % len(fusions) if overlap else 0
+            fz = fusions[slot]
+            if merge_done[slot] is not None:  # this volume's previous merge must have drained
+                main_stream.wait_event(merge_done[slot])
+            fz.reset(accum_mode=_abi.SAF_SUM if world > 1 else _abi.SAF_RUNNING_MEAN)
+            fuse_into(fz, frames, a.frames, profiler)
+            if world > 1:
+                if overlap:
+                    fused = main_stream.record_event()
+                    with torch.cuda.stream(comm_stream):
+                        comm_stream.wait_event(fused)
+                        merge(fz)
+                        merge_done[slot] = comm_stream.record_event()
+                else:
+                    merge(fz)
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt_], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax.item())
+        return dt_
 
+    # ---- timed region 1 (the headline): serial merge -- fuse, then the collective, nothing overlapped ----
+    run_region(a.warmup, False, None)
+    fusion.fuse_stats.zero_()
+    dt = run_region(a.steps, False, prof)
     st = fusion.stats()
     total_frames = world * a.frames * a.steps
     value = total_frames / dt
-    # integrity of the timed work (not timed): every frame of every step was fused, and the volume
-    # of the last step holds exactly one observation per valid (voxel, frame) pair
+    # integrity of the timed work (not timed): every frame of every step was fused, and the volume of the last
+    # step holds exactly one observation per valid (voxel, frame) pair -- over all ranks after the merge
     assert st["frames"] == a.frames * a.steps, f"fused {st['frames']} frames, expected {a.frames * a.steps}"
+    merge_check = None
     if world == 1:
-        w_sum = int(fusions[(step_no[0] - 1) % len(fusions)].weight.sum(dtype=torch.int64))
+        w_sum = int(fusion.weight.sum(dtype=torch.int64))
         assert w_sum * a.steps == st["valid"], f"weight sum {w_sum} x {a.steps} steps != valid count {st['valid']}"
+    else:
+        first, count = fusion._shard_range if fusion._shard_range is not None else (0, n_vox)
+        sums = torch.stack([fusion.weight[first:first + count].sum(dtype=torch.int64),
+                            fusion.tsdf_weight[first:first + count].sum(dtype=torch.int64),
+                            torch.tensor(st["valid"], device=device), torch.tensor(st["tsdf_valid"], device=device)])
+        dist.all_reduce(sums)
+        w_sum, tw_sum, valid_all, tsdf_all = (int(v) for v in sums.tolist())
+        if fusion._shard_range is None:  # all_reduce: every rank holds the whole volume
+            w_sum //= world
+            tw_sum //= world
+        assert w_sum * a.steps == valid_all, f"merged weight sum {w_sum} x {a.steps} steps != valid count of all ranks {valid_all}"
+        assert tw_sum * a.steps == tsdf_all, f"merged tsdf_weight sum {tw_sum} x {a.steps} != {tsdf_all}"
+        merge_check = {"weight_sum_all_ranks": w_sum, "valid_hits_all_ranks_per_step": valid_all // a.steps,
+                       "tsdf_weight_sum_all_ranks": tw_sum}
+
+    # ---- timed region 2 (N > 1): the same jobs with each merge overlapped with the next job's fusion ----
+    overlapped = None
+    if world > 1 and not a.no_overlap_merge:
+        run_region(min(2, max(1, a.warmup)), True, None)
+        dt2 = run_region(a.steps, True, None)
+        overlapped = {"value": round(total_frames / dt2, 2), "unit": "frames/s", "ms_per_step": round(dt2 / a.steps * 1e3, 3),
+                      "note": "job k's merge on a side stream beside job k+1's fusion into a second volume: a stream of "
+                              "independent jobs, not BASELINE config 4's single job (that is `value`)"}
+
+    # ---- N > 1: the merged shard of a small sharded job against a single-rank fusion of ALL its frames ----
+    if world > 1 and a.check_frames > 0:
+        merge_check.update(check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, (depth, rgb, poses, ks, feat, label_maps),
+                                       min(a.check_frames, uniq), world, rank, device))
+        merge_check["mode"] = merge_state["mode"]
 
     # ---- roofline of the dominant kernel (fuse_kernel), this rank ----
     roofline = None
@@ -281,21 +355,28 @@ def main():
                            + a.dim * npy * npx * 4)
         avg_fuse_s = ms["fuse"][0] / n_launch * 1e-3
         achieved = fuse_bytes / avg_fuse_s / 1e9
-        traffic = None
+        # HBM traffic of this kernel: PMC counters cannot be read from inside this process, so the figure comes
+        # from the committed rocprofv3 --pmc passes of this same command (tools/profile.sh, newest round first)
+        traffic, traffic_source = None, None
         kname = "fuse_window_kernel" if windowed else "fuse_kernel"
-        tpath = os.path.join(ROOT, "profiles", "r01", "window_traffic.json" if windowed else "fuse_traffic.json")
-        if os.path.exists(tpath):
+        for rnd in ("r02", "r01"):
+            rel = os.path.join("profiles", rnd, "window_traffic.json" if windowed else "fuse_traffic.json")
             try:
-                tj = json.load(open(tpath))
-                if (tj.get("grid") == a.grid and tj.get("dim") == a.dim and tj.get("depth_kind", "A") == a.depth_kind
-                        and tj.get("dtype", "f32") == a.feat_dtype and not a.labels
-                        and tj.get("frames_per_launch", 1) == (WIN if windowed else 1)):
-                    traffic = tj.get("hbm_bytes_per_launch")
+                tj = json.load(open(os.path.join(ROOT, rel)))
             except Exception:
-                traffic = None
+                continue
+            if (tj.get("grid") == a.grid and tj.get("dim") == a.dim and tj.get("depth_kind", "A") == a.depth_kind
+                    and tj.get("dtype", "f32") == a.feat_dtype and not a.labels
+                    and tj.get("frames_per_launch", 1) == (WIN if windowed else 1)):
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = (f"{rel}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an earlier box "
+                                  "(FETCH_SIZE x2, gfx950), not measured in this run")
+                break
         roofline = {
             "kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "volume_state": "fresh (every step starts from a zeroed volume: a row is not read in the window that first "
+                            "touches it, but its bytes are counted as algorithmic)",
             "algorithmic_bytes_per_launch": int(fuse_bytes), "avg_launch_us": round(avg_fuse_s * 1e6, 2),
             "launches": int(n_launch), "valid_voxels_per_frame": round(nv_per, 1),
             "tsdf_voxels_per_frame": round(nt_per, 1),
@@ -317,13 +398,35 @@ def main():
             "frame_hbm_frac": round(frame_bytes / (dt / (a.frames * a.steps)) / 1e9 / HBM_PEAK_GBS, 4),
         }
 
+    # ---- the same launches into a WARM volume (no zeroing: every touched row is read), untimed in `value` ----
+    if roofline is not None and windowed and rank == 0 and world == 1:
+        prof3 = L.saf_profiler_create(3 * a.frames)
+        L.saf_profiler_set_stride(prof3, a.profile_stride)
+        fusion.fuse_stats.zero_()
+        fuse_into(fusion, frames, a.frames, prof3)  # the volume still holds the last step's 512 frames
+        torch.cuda.synchronize()
+        st3 = fusion.stats()
+        tot, n = C.c_double(0), C.c_int64(0)
+        check(L.saf_profiler_read(prof3, 2, C.byref(tot), C.byref(n)), "saf_profiler_read")
+        L.saf_profiler_destroy(prof3)
+        if n.value:
+            nwin = (a.frames + WIN - 1) // WIN
+            wb = (st3["window_rows"] / nwin * (2 * a.dim * esz + 2 * 12 + 2 * 4 + lab)
+                  + a.frames / nwin * (a.height * a.width * (12 + (4 if a.labels else 0)) + a.dim * npy * npx * 4))
+            ws_ = tot.value / n.value * 1e-3
+            roofline["warm_volume"] = {"avg_launch_us": round(ws_ * 1e6, 2), "achieved": round(wb / ws_ / 1e9, 1),
+                                       "frac": round(wb / ws_ / 1e9 / HBM_PEAK_GBS, 4), "launches": int(n.value),
+                                       "algorithmic_bytes_per_launch": int(wb),
+                                       "note": "the same frames fused again without zeroing: every touched row is read and written"}
+
     # ---- the same kernel timed alone (one frame per call = no sweep running beside it) ----
     if roofline is not None and rank == 0 and not windowed:
         n_iso = min(32, a.frames)
         prof2 = L.saf_profiler_create(3 * n_iso)
         torch.cuda.synchronize()
         for i in range(n_iso):
-            check(L.saf_fuse_frames_profiled(C.byref(vol), C.byref(frames[i]), 1, ws.data_ptr(), ws.numel(),
+            vol_i = fusion._c_volume()
+            check(L.saf_fuse_frames_profiled(C.byref(vol_i), C.byref(frames[i]), 1, ws.data_ptr(), ws.numel(),
                                              fusion.fuse_stats.data_ptr(), prof2, stream), "isolated pass")
         torch.cuda.synchronize()
         tot, n = C.c_double(0), C.c_int64(0)
@@ -380,6 +483,11 @@ def main():
                     "kMaX is not part of this pass",
         }
 
+    # ---- the reference's call pattern: one frame per integrate() call (clipfusion.py:1125-1133) ----
+    api_b1 = None
+    if a.api_b1 > 0 and rank == 0 and world == 1:
+        api_b1 = bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, value)
+
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1 only) ----
     cpu = None
     if rank == 0 and world == 1 and a.cpu_frames != 0:
@@ -402,21 +510,107 @@ def main():
             "config": {
                 "workload": f"{a.frames} frames/rank {a.width}x{a.height} depth-{a.depth_kind}, per-rank "
                             f"{a.grid}^3x{a.dim} {a.feat_dtype} grid{' + panoptic label histogram' if a.labels else ''}, frames sharded, "
-                            + (f"one {a.backend} {merge_state['mode']} merge per step"
-                               + (", overlapped with the next step's fusion" if overlap else "")
+                            + (f"one {a.backend} {merge_state['mode']} merge per step, serial (fuse, then merge)"
                                if world > 1 else "single GPU (no merge)"),
                 "frames_per_rank": a.frames, "grid": a.grid, "feat_dim": a.dim, "image": [a.width, a.height],
                 "feature_map": [npy, npx], "unique_frames_resident": uniq, "n_voxels": n_vox,
                 "parallelism": f"frames-dp{world}", "merge_fallback": merge_state["fallback"],
+                "rccl_world": dist.get_world_size() if world > 1 else 1, "backend": a.backend if world > 1 else None,
             },
+            "overlapped_merge": overlapped,
+            "merge_check": merge_check,
             "roofline": roofline,
             "kernel_breakdown": breakdown,
             "cpu_baseline": cpu,
             "end_to_end": e2e,
         }
+        if api_b1 is not None:
+            out["api_b1"] = api_b1
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_query(a, world, rank, local_rank):
+    raise SystemExit("--query: see bench_query.py")
+
+
+def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value):
+    """The reference's own call pattern (clipfusion.py:1125-1133, clip_seem_fusion.py:303-313): ONE frame per
+    integrate() call, here through integrate_features() (backbone outputs resident).  The deferred window queue
+    behind it (clipfusion._FusionVolumeMixin._fuse) copies each call's inputs into a staging ring and fuses 64
+    frames at a time on the windowed path; a job = reset + n calls + the final flush, like a bulk step."""
+    n = min(a.api_b1, depth.shape[0])
+
+    def job():
+        fusion.reset()
+        for i in range(n):
+            labs = None if label_maps is None else [label_maps[i]]
+            fusion.integrate_features(depth[i:i + 1], rgb[i:i + 1], poses[i:i + 1], ks[i:i + 1], feat[i:i + 1], labs)
+        fusion.flush()
+
+    job()
+    torch.cuda.synchronize()
+    fusion.fuse_stats.zero_()
+    t0 = time.perf_counter()
+    job()
+    host_s = time.perf_counter() - t0  # the host has queued everything
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = fusion.stats()
+    assert st["frames"] == n and int(fusion.weight.sum(dtype=torch.int64)) == st["valid"]
+    return {"value": round(n / dt, 2), "unit": "frames/s", "frames": n, "frames_per_call": 1,
+            "vs_bulk": round(n / dt / bulk_value, 4), "host_enqueue_us_per_call": round(host_s / n * 1e6, 1),
+            "windowed": st["window_rows"] > 0,
+            "note": "one frame per integrate_features() call, deferred window queue (64-frame windows), includes the reset "
+                    "of the volume and the final flush; `vs_bulk` = this / the bulk `value` of the same run"}
+
+
+def check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, tensors, c, world, rank, device):
+    """Untimed proof of the merge on the full-size volumes.  Every rank fuses its first c frames in SAF_SUM mode and
+    the ranks merge (the very collective that was timed); every rank then all-gathers the c frames of all ranks and
+    fuses ALL world*c frames, rank after rank, into its second volume as running means -- what a single GPU would
+    have produced.  The two must agree on the voxel range this rank owns: integer weights exactly, means to 1e-4."""
+    v0, v1 = fusions[0], fusions[1]
+    v0.reset(accum_mode=_abi.SAF_SUM)
+    fuse_into(v0, frames, c, None)
+    first, count = merge(v0)
+    # every rank's check frames, gathered (c x ~5 MB per rank)
+    gathered = []
+    for t in tensors:
+        if t is None:
+            gathered.append(None)
+            continue
+        mine = t[:c].contiguous()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        gathered.append(torch.cat(parts))
+    depth, rgb, poses, ks, feat, labs = gathered
+    arr, keep, _, _ = v1._make_frames(depth, rgb, poses, ks, feat, labs, a.labels)
+    v1.reset(accum_mode=_abi.SAF_RUNNING_MEAN)
+    fuse_into(v1, arr, world * c, None)
+    torch.cuda.synchronize()
+    sl = slice(first, first + count)
+    ok_w = bool(torch.equal(v0.weight[sl], v1.weight[sl])) and bool(torch.equal(v0.tsdf_weight[sl], v1.tsdf_weight[sl]))
+    if a.labels:
+        ok_w = ok_w and bool(torch.equal(v0.labels_one_hot[sl], v1.labels_one_hot[sl]))
+    worst = 0.0
+    for name in ("clip_feat", "rgb", "tsdf"):
+        x, y = getattr(v0, name)[sl], getattr(v1, name)[sl]
+        step = max(1, (1 << 22) // max(1, x[0].numel()))  # compare in pieces: no full-size temporaries
+        for s0 in range(0, x.shape[0], step):
+            xs, ys = x[s0:s0 + step].float(), y[s0:s0 + step].float()
+            worst = max(worst, float(((xs - ys).abs() / (ys.abs() * 1e-4 + 1e-6)).max()))
+    touched = int((v1.weight[sl] > 0).sum())
+    res = torch.tensor([int(ok_w), int(worst <= 1.0), touched], device=device, dtype=torch.int64)
+    dist.all_reduce(res, op=dist.ReduceOp.MIN)
+    all_ok_w, all_ok_f, min_touched = (int(v) for v in res.tolist())
+    assert all_ok_w, "merge check: merged integer weights differ from the single-rank fusion of the same frames"
+    assert all_ok_f, f"merge check: merged means differ from the single-rank fusion beyond 1e-4 (worst ratio {worst:.3g})"
+    assert min_touched > 0, "merge check: a rank's voxel shard was not touched by the check frames"
+    return {"check_frames_per_rank": c, "owned_voxel_range": [int(first), int(count)], "weights_exact": True,
+            "means_within_1e-4": True, "worst_error_over_tolerance": round(worst, 4), "touched_voxels_min_over_ranks": min_touched}
 
 
 def host_cores():
@@ -432,33 +626,68 @@ def host_cores():
     return n
 
 
-def cpu_baseline(a, grid, depth, rgb, poses, ks, feat, npy, npx):
-    """Times oracle/saf_oracle.c (test infrastructure, used here only as the reported CPU
-    baseline) on the first few frames of this workload with all host cores of the box."""
+def cpu_model():
     try:
-        from oracle import oracle as O
-    except Exception as e:  # the oracle is optional for the benchmark line
-        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    cores = host_cores()
-    O.set_threads(cores)
-    n = a.cpu_frames if a.cpu_frames > 0 else 17
-    n = min(n, depth.shape[0])
-    vol = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, a.dim)
-    d, r, p, k, f = (t[:n].cpu() for t in (depth, rgb, poses, ks, feat))
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _time_oracle(O, vol, tensors, n, budget_s):
+    d, r, p, k, f = tensors
     vol.integrate(d[:1], r[:1], p[:1], k[:1], f[:1])  # touch pages / warm up
     t0 = time.perf_counter()
     done = 0
     for i in range(1, n):
         vol.integrate(d[i : i + 1], r[i : i + 1], p[i : i + 1], k[i : i + 1], f[i : i + 1])
         done += 1
-        if time.perf_counter() - t0 > 25.0:
+        if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(a, grid, depth, rgb, poses, ks, feat, npy, npx):
+    """Times oracle/saf_oracle.c (test infrastructure, used here only as the reported CPU baseline) on the first
+    few frames of this workload: all host cores of the box's share, then one thread, then BASELINE config 1
+    (32 frames 320x240 into 64^3 x 64) in full -- the plan of BASELINE.md section 3.  ~25 s in all."""
+    try:
+        from oracle import oracle as O
+    except Exception as e:  # the oracle is optional for the benchmark line
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    cores = host_cores()
+    n = a.cpu_frames if a.cpu_frames > 0 else 129
+    n = min(n, depth.shape[0])
+    tensors = tuple(t[:n].cpu() for t in (depth, rgb, poses, ks, feat))
+    O.set_threads(cores)
+    vol = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, a.dim)
+    done, dt = _time_oracle(O, vol, tensors, n, 10.0)
+    O.set_threads(1)
+    vol1 = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, a.dim)
+    done1, dt1 = _time_oracle(O, vol1, tensors, min(n, 9), 8.0)
+    del vol, vol1
+    # BASELINE config 1 in full: 32 synthetic 320x240 frames, 64^3 grid, 64-dim features (the reference's own
+    # CPU-runnable case; its genuine Python path measured 39-49 frames/s on 8 threads and 13 on one, BASELINE.md)
+    c1 = {}
+    g1 = syn.make_grid(64)
+    y1, x1 = syn.feature_map_shape(320, 240)
+    fr1 = syn.make_frames(2024, 32, width=320, height=240, feat_dim=64, npy=y1, npx=x1, depth_kind="A")
+    t1 = tuple(torch.cat([f[k] for f in fr1]) for k in ("depth", "rgb", "pose", "K", "feat"))
+    for threads in (cores, 1):
+        O.set_threads(threads)
+        v = O.OracleVolume(g1.origin, g1.voxel_size, g1.nvox, g1.trunc, 64)
+        dn, dtt = _time_oracle(O, v, t1, 32, 10.0)
+        c1[f"threads_{threads}"] = round(dn / dtt, 2) if dn else None
     O.set_threads(1)
     return {
         "value": round(done / dt, 3) if done else None, "unit": "frames/s", "cores": cores, "kind": "port",
         "sample": f"{done} frames of the same workload ({a.grid}^3x{a.dim}, {a.width}x{a.height}), "
                   f"oracle/saf_oracle.c with OpenMP over {cores} host threads",
+        "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
+        "one_thread": {"value": round(done1 / dt1, 3) if done1 else None, "frames": done1},
+        "config1_full": {"frames_per_s": c1, "sample": "BASELINE config 1 in full: 32 frames 320x240 into 64^3 x 64 (31 timed after one warm-up frame)"},
     }
 
 

@@ -11,8 +11,9 @@
  *   - all data pointers are DEVICE pointers (HIP, gfx950) unless a parameter says "host";
  *   - nothing here owns volume memory: the caller (torch) allocates and keeps it alive;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream), re-entrant, and keeps no global mutable state besides the thread-local error
- *     string;
+ *     stream) and re-entrant.  Process-wide state is limited to: the thread-local error string, a
+ *     per-device pool of the auxiliary stream / events of the per-frame pipeline, and a per-device
+ *     asynchronous error latch (saf_poll_async_error);
  *   - return value: 0 = ok, <0 = error (SAF_E_*), text via saf_last_error();
  *   - voxel flat index n = (x*ny + y)*nz + z, the C-order flattening of meshgrid(ij)
  *     (clipfusion.py:617-622); 64-bit offsets are used wherever n*D can exceed 2^31.
@@ -130,6 +131,12 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
                     void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
 
+/* The per-frame pipeline hands sweep(i) to fuse(i) on the device; a fuse workgroup that waited ~2 s without
+ * seeing its sweep gives up (stats[4]) and sets a host-visible latch.  Once set, saf_fuse_frame(s) on that
+ * device return SAF_E_HIP (the volume of the earlier call is incomplete); this polls the latch without
+ * launching anything. */
+int saf_poll_async_error(void);
+
 /*
  * Optional per-kernel timing: a pool of HIP event pairs recorded on the launch stream around each
  * kernel of saf_fuse_frames_profiled (class 0 = prep, 1 = sweep / window classification, 2 = fuse /
@@ -174,12 +181,20 @@ enum saf_query_epilogue {
                         out[n,l] = S[n,l]*w[l] - mean_l(S[n,l]*w[l]), w from row 0 of feats */
 };
 
+/* Row normalisation applied to the features before the dot products. */
+enum saf_query_normalize {
+  SAF_NORM_NONE = 0,
+  SAF_NORM_L2 = 1,       /* f / |f|, NaN -> 0 (clip_seem_fusion.py:507-511; query_mesh.py:24-25) */
+  SAF_NORM_L2_CLAMP = 2  /* f / max(|f|, 0.1) (eval_scannet_segmentation.py:549-551, hypersim_eval.py:50-51) */
+};
+
 /*
  * Scan n_rows feature rows against n_text text embeddings.
  *   feats      [n_rows, feat_stride] feat_dtype (row-major; first D columns used)
  *   text       [n_text, text_stride] f32 (first D columns used: run_query truncates, :901)
- *   normalize  1: divide each row by its L2 norm first and map NaN -> 0
- *              (clip_seem_fusion.py:507-511; query_mesh.py:24-25 without the nan_to_num)
+ *   normalize  a saf_query_normalize: SAF_NORM_L2 divides each row by its L2 norm first and maps NaN -> 0
+ *              (clip_seem_fusion.py:507-511; query_mesh.py:24-25 without the nan_to_num); SAF_NORM_L2_CLAMP
+ *              divides by max(norm, 0.1) as the eval scripts do
  *   out        [n_rows, n_text] f32
  *   out_last   optional [n_rows] f32: only the last column (query_mesh.py:38); out may be NULL then
  *   workspace  device scratch of saf_query_workspace_bytes(n_text, epilogue) bytes (may be NULL if 0)

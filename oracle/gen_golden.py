@@ -12,6 +12,7 @@ detectron2, ... -- the recipe verified in SURVEY.md §8c), drives
   * Clip.clip_feature_surgery       (clipfusion.py:906-934)
   * the clip_text_query post-processing arithmetic (clip_seem_fusion.py:507-548)
   * flood_fill_3d, first scan         (handy_utils.py:295-480)
+  * Clip.get_patches / img_inference_tiled with a stub encode_image (clipfusion.py:789-839)
 
 on small seeded inputs and writes inputs + outputs as .npz fixtures under tests/golden/.
 The backbones (CLIP ViT, kMaX-DeepLab) are replaced by seeded feature / label maps: they
@@ -465,6 +466,44 @@ def gen_label_components(out_dir):
     print("label_components:", [int(out[f"c{i}_count"].size) for i in range(len(cases))], "objects per case")
 
 
+def stub_encode_image(x):
+    """Deterministic stand-in for open_clip's encode_image used to pin the tiling front-end (a12): 12 numbers per
+    224x224 tile that depend on the tile's content and position-sensitive samples of it."""
+    return torch.cat([x.mean(dim=(2, 3)), x[:, :, 5::50, 7::50].flatten(1)[:, :9]], dim=1)
+
+
+def gen_tiled_clip(ref_cf, out_dir):
+    """Clip.get_patches / Clip.img_inference_tiled (clipfusion.py:789-839) with the ViT replaced by
+    stub_encode_image: pins the tile order, the normalisation and the 224^2 bilinear resize."""
+    g = torch.Generator().manual_seed(1357)
+    clip = ref_cf.Clip("stub", "stub")
+    clip.feature_dim = 12
+    seen = []
+
+    def _encode_image(x):
+        seen.append(x.clone())
+        return stub_encode_image(x)
+
+    clip.clip.encode_image = _encode_image
+    out = {}
+    for ci, (b, h, w, ps, st) in enumerate([(2, 48, 64, 16, 8), (1, 30, 40, 10, 10), (3, 96, 128, 32, 16)]):
+        rgb = torch.rand(b, 3, h, w, generator=g)
+        seen.clear()
+        patches = clip.get_patches(rgb, ps, st)
+        feats = clip.img_inference_tiled(rgb, ps, st)
+        resized = torch.cat(seen)
+        out[f"c{ci}_rgb"] = rgb.numpy()
+        out[f"c{ci}_patch"] = np.array([ps, st])
+        out[f"c{ci}_patches_shape"] = np.array(patches.shape)
+        out[f"c{ci}_patches_sample"] = patches[:, :, :, :, ::3, ::3].numpy().copy()
+        out[f"c{ci}_resized_sample"] = resized[:, :, ::13, ::11].numpy().copy()
+        out[f"c{ci}_resized_sum"] = resized.double().sum(dim=(1, 2, 3)).numpy()
+        out[f"c{ci}_feats"] = feats.numpy().copy()
+    out["n_cases"] = np.array(3)
+    np.savez_compressed(os.path.join(out_dir, "tiled_clip.npz"), **out)
+    print("tiled clip front-end:", [tuple(out[f"c{i}_feats"].shape) for i in range(3)])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -481,6 +520,7 @@ def main():
     gen_fusion_c1(ref_cf, args.out)
     gen_extract_mesh(ref_cf, ref_csf, args.out)
     gen_label_components(args.out)
+    gen_tiled_clip(ref_cf, args.out)
     with open(os.path.join(args.out, "README.md"), "w") as f:
         f.write(
             "Golden vectors produced by `oracle/gen_golden.py` from the reference's own Python\n"

@@ -335,10 +335,14 @@ int saf_oracle_query_scan(const float* feats, int64_t n_rows, int64_t feat_strid
       double nn = 0;
       for (int c = 0; c < D; ++c) nn += (double)f[c] * f[c];
       float norm = (float)sqrt(nn);
+      /* normalize == 2: feat_norm.clamp_min_(0.1), eval_scannet_segmentation.py:549-551, hypersim_eval.py:50-51 */
+      if (normalize == 2 && norm < 0.1f) norm = 0.1f;
       for (int c = 0; c < D; ++c) {
         float q = f[c] / norm;
-        if (isnan(q)) q = 0.0f;
-        if (isinf(q)) q = q > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+        if (normalize == 1) {
+          if (isnan(q)) q = 0.0f;
+          if (isinf(q)) q = q > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+        }
         row[c] = q;
       }
     } else {

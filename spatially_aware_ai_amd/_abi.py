@@ -17,6 +17,7 @@ SAF_E_UNSUPPORTED = -4
 SAF_F32, SAF_BF16, SAF_F16 = 0, 1, 2
 SAF_RUNNING_MEAN, SAF_SUM = 0, 1
 SAF_Q_SCORES, SAF_Q_SOFTMAX, SAF_Q_SURGERY = 0, 1, 2
+SAF_NORM_NONE, SAF_NORM_L2, SAF_NORM_L2_CLAMP = 0, 1, 2
 SAF_STATS_WORDS = 8
 SAF_WINDOW_FRAMES = 64
 
@@ -74,6 +75,7 @@ PROTOTYPES = {
         C.c_int,
         [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp, _fp],
     ),
+    "saf_poll_async_error": (C.c_int, []),
     "saf_profiler_create": (_fp, [C.c_int32]),
     "saf_profiler_destroy": (None, [_fp]),
     "saf_profiler_reset": (None, [_fp]),

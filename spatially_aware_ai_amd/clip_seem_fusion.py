@@ -35,8 +35,9 @@ class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
     _rgb_bilinear = True  # clip_seem_fusion.py:793-798
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_patch_size, clip_patch_stride,
-                 clip_model, seg_model, keep_xyz_world=True, feat_dtype=torch.float32):
+                 clip_model, seg_model, keep_xyz_world=True, feat_dtype=torch.float32, defer_frames=True):
         super().__init__()
+        self.__dict__["defer_frames"] = bool(defer_frames)
         self.clip = clip_model
         self.clip_patch_size = clip_patch_size
         self.clip_patch_stride = clip_patch_stride

@@ -37,6 +37,9 @@ def _axis_tables(origin, voxel_size, nvox):
     return [(torch.arange(int(nvox[a])) * voxel_size + origin[a]).to(torch.float32).contiguous() for a in range(3)]
 
 
+_VOLUME_BUFFERS = frozenset(("tsdf", "rgb", "clip_feat", "weight", "tsdf_weight", "labels_one_hot", "fuse_stats"))
+
+
 class _FusionVolumeMixin:
     """Buffers, workspace and the C-ABI call shared by both fusion modules."""
 
@@ -77,6 +80,10 @@ class _FusionVolumeMixin:
             ).reshape(-1, 3)
             self.register_buffer("xyz_world", xyz_world)
         self._workspace = None
+        self._shard_range = None  # (first, count) while the volume holds only a reduce-scattered shard
+        self.__dict__.setdefault("defer_frames", True)  # queue small integrate() calls into 64-frame windows
+        self.__dict__["_pending_n"] = 0
+        self.__dict__["_stage"] = None
 
     # -- C structs -------------------------------------------------------------------------
     def _c_volume(self):
@@ -141,19 +148,155 @@ class _FusionVolumeMixin:
             )
         return arr, (depth_imgs, rgb_imgs, poses, K, feat, labs), npy, npx
 
+    # -- the deferred window queue ---------------------------------------------------------------
+    # The reference calls integrate() with ONE frame per DataLoader batch (clip_seem_fusion.py:303-313,
+    # clipfusion.py:1120-1133).  One frame per C call would run the per-frame pipeline; the windowed path
+    # (saf_fuse_frames with 16+ frames: every touched feature row travels to HBM once per 64-frame window)
+    # needs many frames in one call.  Small calls are therefore queued -- their inputs copied into a staging ring
+    # of SAF_WINDOW_FRAMES slots -- and fused when the window is full or when anything reads or replaces the
+    # volume: the registered buffers (attribute access, state_dict, .to()), stats(), extract_mesh, the merge.
+    # The two device paths are bit-identical, so a caller cannot tell -- except by speed.
+    _DEFER_MAX_BATCH = 15  # calls of 16+ frames take the windowed path by themselves
+
+    def _defer_ok(self, bsz, feat):
+        if not self.__dict__.get("defer_frames", True) or bsz > self._DEFER_MAX_BATCH:
+            return False
+        d = int(self.n_clip_feats)
+        bf16 = self._buffers["clip_feat"].dtype == torch.bfloat16
+        # the shapes saf_fuse_frames takes on the windowed path (include/saf.h); others gain nothing from a queue
+        return d <= 1024 and d % (512 if bf16 else 256) == 0 and feat.shape[2] + 3 <= 255 and feat.shape[3] + 3 <= 255
+
     def _fuse(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False):
+        bsz = int(depth_imgs.shape[0])
+        if clip_feat_img.dim() != 4 or not self._defer_ok(bsz, clip_feat_img):
+            self.flush()
+            return self._fuse_now(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
+        h, w = int(depth_imgs.shape[1]), int(depth_imgs.shape[2])
+        if tuple(rgb_imgs.shape) != (bsz, h, w, 3):
+            raise ValueError(f"rgb_imgs must be [B,H,W,3], got {tuple(rgb_imgs.shape)}")
+        if tuple(poses.shape) != (bsz, 4, 4) or tuple(K.shape) != (bsz, 3, 3):
+            raise ValueError("poses must be [B,4,4] and K [B,3,3]")
+        if clip_feat_img.shape[0] != bsz or clip_feat_img.shape[1] < self.n_clip_feats:
+            raise ValueError(f"feature map must be [B,D>={self.n_clip_feats},npy,npx], got {tuple(clip_feat_img.shape)}")
+        for t, name in ((depth_imgs, "depth_imgs"), (rgb_imgs, "rgb_imgs"), (poses, "poses"), (K, "K"),
+                        (clip_feat_img, "clip feature map")):
+            require_cuda(t, name)
+        if label_maps is not None:
+            for m in label_maps:
+                require_cuda(m, "label map")
+                if tuple(m.shape) != (h, w):
+                    raise ValueError("label map must be [H,W]")
+        key = (h, w, tuple(int(v) for v in clip_feat_img.shape[1:]), label_maps is not None, bool(rgb_bilinear))
+        st = self.__dict__.get("_stage")
+        if st is None or st["key"] != key:
+            self.flush()
+            dev = self._buffers["tsdf"].device
+            n = _abi.SAF_WINDOW_FRAMES
+            mk = lambda *shape: torch.empty((n,) + shape, dtype=torch.float32, device=dev)
+            st = {"key": key, "depth": mk(h, w), "rgb": mk(h, w, 3), "pose": mk(4, 4), "K": mk(3, 3),
+                  "feat": mk(*key[2]), "labels": mk(h, w) if label_maps is not None else None, "event": None,
+                  "stream": None}
+            self.__dict__["_stage"] = st
+        with torch.cuda.device(self._buffers["tsdf"].device):
+            stream = torch.cuda.current_stream()
+            if st["event"] is not None and st["stream"] != stream.cuda_stream:
+                stream.wait_event(st["event"])  # the last flush may still be reading the staging ring on its stream
+            for i in range(bsz):
+                k = self.__dict__["_pending_n"]
+                st["depth"][k].copy_(depth_imgs[i], non_blocking=True)
+                st["rgb"][k].copy_(rgb_imgs[i], non_blocking=True)
+                st["pose"][k].copy_(poses[i], non_blocking=True)
+                st["K"][k].copy_(K[i], non_blocking=True)
+                st["feat"][k].copy_(clip_feat_img[i], non_blocking=True)
+                if label_maps is not None:
+                    st["labels"][k].copy_(label_maps[i], non_blocking=True)
+                self.__dict__["_pending_n"] = k + 1
+                if k + 1 == _abi.SAF_WINDOW_FRAMES:
+                    self.flush()
+
+    def flush(self):
+        """Fuse the frames queued behind integrate() (no-op when nothing is pending).  Readers of the volume never
+        need to call it -- every access to a registered buffer flushes -- it exists for callers that hold raw
+        pointers or tensors obtained earlier."""
+        n = self.__dict__.get("_pending_n", 0)
+        if not n:
+            return
+        self.__dict__["_pending_n"] = 0  # first: the buffer accesses below must not re-enter
+        st = self.__dict__["_stage"]
+        labs = None if st["labels"] is None else [st["labels"][i] for i in range(n)]
+        self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], st["feat"][:n], labs, st["key"][4])
+        with torch.cuda.device(self._buffers["tsdf"].device):
+            stream = torch.cuda.current_stream()
+            st["event"], st["stream"] = stream.record_event(), stream.cuda_stream
+
+    @property
+    def pending_frames(self):
+        """Frames queued behind integrate() and not yet fused."""
+        return self.__dict__.get("_pending_n", 0)
+
+    def __getattr__(self, name):
+        # registered buffers live in _buffers, so every read of one comes through here
+        if name in _VOLUME_BUFFERS and self.__dict__.get("_pending_n", 0):
+            self.flush()
+        return super().__getattr__(name)
+
+    def __setattr__(self, name, value):
+        if (name in _VOLUME_BUFFERS or name == "accum_mode") and self.__dict__.get("_pending_n", 0):
+            self.flush()  # queued frames belong to the buffers / mode that were current when they were queued
+        super().__setattr__(name, value)
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .cpu() / .float()
+        self.flush()
+        self.__dict__["_stage"] = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _save_to_state_dict(self, *args, **kwargs):
+        self.flush()
+        return super()._save_to_state_dict(*args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.flush()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def named_buffers(self, *args, **kwargs):
+        self.flush()
+        return super().named_buffers(*args, **kwargs)
+
+    def _fuse_now(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False):
+        if getattr(self, "_shard_range", None) is not None:
+            raise SafError(
+                "this volume holds only its reduce-scattered voxel shard "
+                f"{self._shard_range} of a merged job; all_gather it (merge_volumes(..., gather=True)) before fusing more frames"
+            )
         arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
         vol = self._c_volume()
         ws = self._get_workspace(npy, npx)
-        rc = lib().saf_fuse_frames(
-            C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self.fuse_stats.data_ptr(), current_stream_ptr()
-        )
-        check(rc, "saf_fuse_frames")
-        # the launches are asynchronous: keep inputs alive until the stream has consumed them
-        for t in keep[:5]:
-            t.record_stream(torch.cuda.current_stream())
+        # the module's device, not the caller's current one, owns the launch (and its current stream)
+        with torch.cuda.device(self.tsdf.device):
+            stream = torch.cuda.current_stream()
+            rc = lib().saf_fuse_frames(
+                C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self.fuse_stats.data_ptr(), stream.cuda_stream
+            )
+            check(rc, "saf_fuse_frames")
+            # the launches are asynchronous: keep inputs alive until the stream has consumed them
+            for t in keep[:5]:
+                t.record_stream(stream)
+            for t in keep[5] or ():
+                t.record_stream(stream)
 
     # -- extensions (not in the reference) ---------------------------------------------------
+    def reset(self, accum_mode=_abi.SAF_RUNNING_MEAN):
+        """Back to the freshly constructed state: every volume buffer zero (the reference builds a new module per
+        scan, clip_seem_fusion.py:291-302)."""
+        self.__dict__["_pending_n"] = 0  # frames still queued would be fused into a volume that is being discarded
+        for name in ("clip_feat", "rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot"):
+            t = self._buffers.get(name)
+            if t is not None:
+                t.zero_()
+        self.accum_mode = accum_mode
+        self._shard_range = None
+
+
     def integrate_features(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None):
         """``integrate`` with the backbone outputs supplied by the caller (fuse-only entry used by
         the benchmark and the parity tests)."""
@@ -233,6 +376,19 @@ class _FusionVolumeMixin:
 # --------------------------------------------------------------------------------------------
 
 
+def _norm_mode(normalize):
+    """False/0 -> none; True/1 -> L2 + nan_to_num (clip_seem_fusion.py:507-511); 2 / "clamp" -> divide by
+    max(norm, 0.1) as eval_scannet_segmentation.py:549-551 and hypersim_eval.py:50-51 do."""
+    if normalize in ("clamp", "clamp_min"):
+        return _abi.SAF_NORM_L2_CLAMP
+    if isinstance(normalize, bool):
+        return int(normalize)
+    mode = int(normalize)
+    if mode not in (_abi.SAF_NORM_NONE, _abi.SAF_NORM_L2, _abi.SAF_NORM_L2_CLAMP):
+        raise ValueError(f"bad normalize mode {normalize!r}")
+    return mode
+
+
 def _query_scan(feats, text, epilogue, scale=1.0, normalize=False, last_only=False):
     """Run saf_query_scan on [N,D] f32 features and [L,>=D] f32 text embeddings (both moved to the
     HIP device if needed); returns [N,L] (or [N] when last_only) on the device of ``feats``."""
@@ -262,7 +418,7 @@ def _query_scan(feats, text, epilogue, scale=1.0, normalize=False, last_only=Fal
     with torch.cuda.device(dev):
         rc = lib().saf_query_scan(
             f.data_ptr(), ft, n, f.stride(0), d, t.data_ptr(), nl, t.stride(0), epilogue, float(scale),
-            int(bool(normalize)), _abi.ptr(out), _abi.ptr(last), _abi.ptr(ws), wsb, current_stream_ptr(),
+            _norm_mode(normalize), _abi.ptr(out), _abi.ptr(last), _abi.ptr(ws), wsb, current_stream_ptr(),
         )
     check(rc, "saf_query_scan")
     res = last if last_only else out
@@ -295,7 +451,7 @@ def query_scores_wide(feats, text, scale=1.0, normalize=True, out_dtype=None):
     with torch.cuda.device(feats.device):
         rc = lib().saf_query_scan_wide(
             feats.data_ptr(), _DT[feats.dtype], n, feats.stride(0), d, t.data_ptr(), q, t.stride(0), float(scale),
-            int(bool(normalize)), out.data_ptr(), _DT[out_dtype], out.stride(0), ws.data_ptr(), wsb, current_stream_ptr(),
+            _norm_mode(normalize), out.data_ptr(), _DT[out_dtype], out.stride(0), ws.data_ptr(), wsb, current_stream_ptr(),
         )
     check(rc, "saf_query_scan_wide")
     return out
@@ -455,8 +611,9 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
     _rgb_bilinear = False  # nearest rgb sampling (clipfusion.py:701-706)
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_model, clip_pretraining,
-                 clip_patch_size, clip_patch_stride, keep_xyz_world=True, feat_dtype=torch.float32):
+                 clip_patch_size, clip_patch_stride, keep_xyz_world=True, feat_dtype=torch.float32, defer_frames=True):
         super().__init__()
+        self.__dict__["defer_frames"] = bool(defer_frames)
         if isinstance(clip_model, str):
             self.clip = Clip(clip_model, clip_pretraining)
             self.clip.requires_grad_(False)

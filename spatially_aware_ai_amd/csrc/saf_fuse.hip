@@ -20,6 +20,8 @@
 // (bit-identical).  All arithmetic that selects voxels is shared with the oracle's restatement in
 // spirit and checked bit-for-bit against it (saf_common.h); the device building blocks shared with the
 // windowed path live in saf_fuse_dev.h.
+#include <mutex>
+
 #include "saf_fuse_dev.h"
 
 namespace saf {
@@ -307,6 +309,11 @@ __device__ __forceinline__ unsigned long long sweep_blocks_done(const unsigned l
   for (int k = 0; k < kDoneShards; ++k) n += __hip_atomic_load(&sweep_done[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return n;
 }
+// Asynchronous error latch (host-mapped pinned word, one per device): a fuse workgroup that gives up waiting
+// for its frame's sweep sets it; every later saf_fuse_* / saf_poll_async_error call on the host then fails with
+// SAF_E_HIP instead of leaving a silently incomplete volume behind (stats[4] counts the workgroups as before).
+__device__ int* g_async_latch = nullptr;
+
 __device__ __forceinline__ bool wait_for_sweep(const unsigned long long* __restrict__ sweep_done,
                                                unsigned long long target, unsigned long long* __restrict__ stats) {
   __shared__ int s_ok;
@@ -319,6 +326,7 @@ __device__ __forceinline__ bool wait_for_sweep(const unsigned long long* __restr
         if (wall_clock64() - t0 > 200000000ull) {
           ok = 0;
           if (stats) atomicAdd(&stats[4], 1ull);
+          if (g_async_latch) __hip_atomic_store(g_async_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
       }
@@ -832,6 +840,84 @@ int launch_rows(const KVol& kv, const FrameJob& job, unsigned char* ws, unsigned
                      reinterpret_cast<unsigned long long*>(stats), sweep_done_ptr(ws), target, shared_cus, s);
 }
 
+// The auxiliary stream and events of the two-stream pipeline are pooled per device (creating and destroying
+// a stream and six events per call cost tens of microseconds on every short integrate()).  A call takes a set
+// from the pool and returns it when it has queued its work: the next user queues behind it on the same stream,
+// and an event re-recorded later does not disturb a wait that was queued earlier.
+constexpr int kEvRing = 4;
+struct PipeRes {
+  int device;
+  hipStream_t aux;
+  hipEvent_t fork, join, fused[kEvRing];
+  PipeRes* next;
+};
+std::mutex g_pipe_mu;
+PipeRes* g_pipe_free = nullptr;
+
+PipeRes* pipe_acquire() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pipe_mu);
+    for (PipeRes** pp = &g_pipe_free; *pp; pp = &(*pp)->next) {
+      if ((*pp)->device == dev) {
+        PipeRes* r = *pp;
+        *pp = r->next;
+        return r;
+      }
+    }
+  }
+  PipeRes* r = new PipeRes();
+  r->device = dev;
+  r->next = nullptr;
+  bool ok = hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&r->join, hipEventDisableTiming) == hipSuccess;
+  for (int b = 0; ok && b < kEvRing; ++b) ok = hipEventCreateWithFlags(&r->fused[b], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    delete r;  // (handles created so far are leaked: this only happens when the runtime is out of resources)
+    return nullptr;
+  }
+  return r;
+}
+void pipe_release(PipeRes* r) {
+  std::lock_guard<std::mutex> lk(g_pipe_mu);
+  r->next = g_pipe_free;
+  g_pipe_free = r;
+}
+
+// Host side of the asynchronous error latch (see g_async_latch): one mapped pinned word per device.
+constexpr int kMaxDevices = 64;
+int* g_latch_host[kMaxDevices] = {};
+std::mutex g_latch_mu;
+
+int ensure_latch() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return SAF_OK;  // no latch: stats[4] still counts
+  std::lock_guard<std::mutex> lk(g_latch_mu);
+  if (g_latch_host[dev]) return SAF_OK;
+  int* h = nullptr;
+  int* d = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(int), hipHostMallocMapped) != hipSuccess) return SAF_OK;
+  *h = 0;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(g_async_latch), &d, sizeof(d)) != hipSuccess) {
+    (void)hipHostFree(h);
+    return SAF_OK;
+  }
+  g_latch_host[dev] = h;
+  return SAF_OK;
+}
+int poll_latch() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return SAF_OK;
+  const int* h = g_latch_host[dev];
+  if (h && *reinterpret_cast<const volatile int*>(h) != 0)
+    return fail(SAF_E_HIP, "an earlier saf_fuse_frames call on this device dropped frames: fuse workgroups timed out "
+                           "waiting for their frame's sweep (stats[4]); the volume is incomplete");
+  return SAF_OK;
+}
+
 #define SAF_HIP_TRY(call)                                                                  \
   do {                                                                                     \
     hipError_t e_ = (call);                                                                \
@@ -868,14 +954,11 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
     }
     return SAF_OK;
   }
-  constexpr int kEvRing = 4;
-  hipStream_t aux = nullptr;
-  hipEvent_t fork = nullptr, fused[kEvRing] = {nullptr, nullptr, nullptr, nullptr};
-  SAF_HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-  SAF_HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-  for (int b = 0; b < kEvRing; ++b) SAF_HIP_TRY(hipEventCreateWithFlags(&fused[b], hipEventDisableTiming));
-  SAF_HIP_TRY(hipEventRecord(fork, s));
-  SAF_HIP_TRY(hipStreamWaitEvent(aux, fork, 0));
+  PipeRes* pr = pipe_acquire();
+  if (!pr) return fail(SAF_E_HIP, "could not create the sweep stream / events of the per-frame pipeline");
+  hipStream_t aux = pr->aux;
+  SAF_HIP_TRY(hipEventRecord(pr->fork, s));
+  SAF_HIP_TRY(hipStreamWaitEvent(aux, pr->fork, 0));
   for (int32_t i = 0; i < n_frames; ++i) {
     FrameJob job;
     if ((rc = make_job(kv, &frames[i], workspace, workspace_bytes, &job))) goto done;
@@ -884,18 +967,18 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
       // buffer i & 3 was last read by fuse(i - 4); events exist after the odd-numbered fuse kernels:
       // the first one at or after i - 4 is j = (i - 4) | 1  (<= i - 3, already recorded)
       const int32_t j = (i - kListBuffers) | 1;
-      SAF_HIP_TRY(hipStreamWaitEvent(aux, fused[(j >> 1) % kEvRing], 0));
+      SAF_HIP_TRY(hipStreamWaitEvent(aux, pr->fused[(j >> 1) % kEvRing], 0));
     }
     if ((rc = launch_classify(kv, job, ws, buf, i, prof, aux))) goto done;
     if ((rc = launch_rows(kv, job, ws, buf, i, stats, true, prof, s))) goto done;
-    if (i & 1) SAF_HIP_TRY(hipEventRecord(fused[(i >> 1) % kEvRing], s));
+    if (i & 1) SAF_HIP_TRY(hipEventRecord(pr->fused[(i >> 1) % kEvRing], s));
   }
 done:
-  // destroying a stream / event with work in flight is deferred by the runtime until it drains
-  if (fork) (void)hipEventDestroy(fork);
-  for (int b = 0; b < kEvRing; ++b)
-    if (fused[b]) (void)hipEventDestroy(fused[b]);
-  if (aux) (void)hipStreamDestroy(aux);
+  // join: the sweeps' TSDF stores become visible to later work on `s` only at the end of the sweep
+  // kernels, which the last fuse kernel does not order -- the caller's stream waits for the aux stream
+  // (also on the error paths: whatever was queued on aux must not outlive the call unordered)
+  if (hipEventRecord(pr->join, aux) == hipSuccess) (void)hipStreamWaitEvent(s, pr->join, 0);
+  pipe_release(pr);
   return rc;
 }
 
@@ -922,6 +1005,8 @@ int saf_fuse_frames_profiled(const saf_volume* vol, const saf_frame* frames, int
   if (rc) return rc;
   if (n_frames < 0 || (n_frames > 0 && !frames)) return fail(SAF_E_INVALID, "bad frame array");
   if (n_frames == 0) return SAF_OK;
+  if ((rc = poll_latch())) return rc;
+  ensure_latch();
   return fuse_many(kv, frames, n_frames, workspace, workspace_bytes, stats, profiler, static_cast<hipStream_t>(stream));
 }
 
@@ -935,6 +1020,8 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
   if (!frame) return fail(SAF_E_INVALID, "frame is NULL");
   return saf_fuse_frames_profiled(vol, frame, 1, workspace, workspace_bytes, stats, nullptr, stream);
 }
+
+int saf_poll_async_error(void) { return poll_latch(); }
 
 saf_profiler* saf_profiler_create(int32_t capacity_pairs) {
   if (capacity_pairs <= 0) return nullptr;

@@ -64,11 +64,15 @@ __global__ __launch_bounds__(kQThreads) void query_kernel(const void* __restrict
       }
       if (normalize) {
         // clip_feat /= clip_feat.norm(dim=-1, keepdim=True); nan_to_num   clip_seem_fusion.py:508-511
-        const float norm = sqrtf(wave_sum(ss));
+        float norm = sqrtf(wave_sum(ss));
+        // SAF_NORM_L2_CLAMP: feat_norm.clamp_min_(0.1)   eval_scannet_segmentation.py:549-551, hypersim_eval.py:50-51
+        if (normalize == SAF_NORM_L2_CLAMP) norm = norm < 0.1f ? 0.1f : norm;
         for (int c = lane; c < D; c += 64) {
           float q = row[c] / norm;
-          if (q != q) q = 0.f;
-          if (__builtin_isinf(q)) q = q > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+          if (normalize == SAF_NORM_L2) {
+            if (q != q) q = 0.f;
+            if (__builtin_isinf(q)) q = q > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+          }
           row[c] = q;
         }
       }
@@ -266,7 +270,9 @@ __global__ __launch_bounds__(kQThreads) void query_mfma_kernel(const void* __res
     // ---- epilogue on the accumulator layout: this lane holds column n = m (+32 t) of 16 rows
     ss += __shfl_xor(ss, 32);  // both halves of row m
     // clip_feat /= norm ; nan_to_num: an all-zero row gives zeros       clip_seem_fusion.py:508-511
-    const float inv = normalize ? (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f) : 1.0f;
+    // SAF_NORM_L2_CLAMP: norm.clamp_min(0.1)                            eval_scannet_segmentation.py:549-551
+    const float inv = normalize == SAF_NORM_L2_CLAMP ? 1.0f / fmaxf(sqrtf(ss), 0.1f)
+                                                     : (normalize ? (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f) : 1.0f);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int mi = (i & 3) + 8 * (i >> 2) + 4 * h;  // row of accumulator register i in this half

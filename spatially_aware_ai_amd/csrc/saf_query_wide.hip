@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
       }
       ss += __shfl_xor(ss, 32);                              // both halves of row r
-      inv = ss > 0.0f ? scale / sqrtf(ss) : 0.0f;            // nan_to_num: an all-zero row scores 0
+      // SAF_NORM_L2: nan_to_num, an all-zero row scores 0; SAF_NORM_L2_CLAMP: norm.clamp_min(0.1)
+      inv = normalize == SAF_NORM_L2_CLAMP ? scale / fmaxf(sqrtf(ss), 0.1f) : (ss > 0.0f ? scale / sqrtf(ss) : 0.0f);
     }
 
     __syncthreads();  // the previous row block is done with both LDS buffers

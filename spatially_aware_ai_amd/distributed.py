@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import _abi
-from ._lib import check, current_stream_ptr, lib
+from ._lib import SafError, check, current_stream_ptr, lib
 
 _CHUNK_ELEMS = 1 << 28  # collectives are issued in <= 1 GiB (fp32) pieces
 
@@ -80,8 +80,12 @@ def _all_gather_rows(t, group, rank, world):
     per = n // world
     if per > 0:
         main = t[: per * world]
-        outs = [main[k * per : (k + 1) * per] for k in range(world)]
-        dist.all_gather(outs, main[rank * per : (rank + 1) * per].clone(), group=group)
+        if dist.get_backend(group) == "nccl":
+            # RCCL in-place form (sendbuff == recvbuff + rank * sendcount): no full-volume temporary
+            dist.all_gather_into_tensor(main, main[rank * per : (rank + 1) * per], group=group)
+        else:
+            outs = [main[k * per : (k + 1) * per] for k in range(world)]
+            dist.all_gather(outs, main[rank * per : (rank + 1) * per].clone(), group=group)
     if n > per * world:
         src = world - 1
         dist.broadcast(t[per * world :], src=dist.get_global_rank(group, src) if group else src, group=group)
@@ -143,15 +147,44 @@ def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool
     the local divide.  ``fusion`` must have been fused with ``accum_mode = SAF_SUM`` (call
     ``means_to_sums`` first otherwise).  Returns the (first, count) voxel range that holds final
     means on this rank."""
+    if fusion.clip_feat.dtype != torch.float32:
+        raise SafError(
+            f"merge_volumes needs an f32 feature volume (got {fusion.clip_feat.dtype}): per-rank SUMS kept in bf16 would "
+            "round every addition to 8 bits; fuse the per-rank shards in f32 and convert after the merge"
+        )
+    if getattr(fusion, "_shard_range", None) is not None:
+        raise SafError("this volume was already merged and holds only its voxel shard")
+    flush = getattr(fusion, "flush", None)
+    if flush is not None:
+        flush()  # frames still queued behind integrate() belong to this job
     if fusion.accum_mode != _abi.SAF_SUM:
         means_to_sums(fusion)
     tensors = _volume_tensors(fusion)
+    n = fusion.tsdf.numel()
     first, count = merge_sums(tensors, group=group, mode=mode, gather=False)
     finalize_sums(fusion, first, count)
-    if gather and mode == "reduce_scatter" and dist.get_world_size(group) > 1:
+    if (first, count) == (0, n):
+        return first, count
+    if gather:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         for t in tensors.values():
             _all_gather_rows(t, group, rank, world)
         fusion.accum_mode = _abi.SAF_RUNNING_MEAN
-        return 0, fusion.tsdf.numel()
+        return 0, n
+    # voxel-sharded result: only [first, first+count) holds the job's means; the other rows hold this rank's
+    # partial sums.  integrate() refuses to fuse into it (clipfusion._fuse) until gather_shards() is called.
+    fusion.accum_mode = _abi.SAF_RUNNING_MEAN
+    fusion._shard_range = (first, count)
     return first, count
+
+
+def gather_shards(fusion, group=None):
+    """All-gather a voxel-sharded merged volume (merge_volumes(..., gather=False)) so that every rank holds
+    the whole merged volume and may fuse further frames."""
+    if getattr(fusion, "_shard_range", None) is None:
+        return 0, fusion.tsdf.numel()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    for t in _volume_tensors(fusion).values():
+        _all_gather_rows(t, group, rank, world)
+    fusion._shard_range = None
+    return 0, fusion.tsdf.numel()

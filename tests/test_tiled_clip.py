@@ -1,0 +1,62 @@
+"""Pins the tiled CLIP front-end (Clip.get_patches / Clip.img_inference_tiled,
+reference clipfusion.py:789-839) against goldens produced by the reference's own code with the ViT replaced
+by a stub encode_image (oracle/gen_golden.py::gen_tiled_clip).  The PyTorch restatement runs on the CPU; the
+fused HIP front-end (saf_clip_tiles) is checked against the same goldens in tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from spatially_aware_ai_amd.clipfusion import Clip
+
+
+def stub_encode_image(x):
+    """Same function as oracle/gen_golden.py::stub_encode_image (test code on both sides, not reference code)."""
+    x = x.float()
+    return torch.cat([x.mean(dim=(2, 3)), x[:, :, 5::50, 7::50].flatten(1)[:, :9]], dim=1)
+
+
+class StubBackbone(torch.nn.Module):
+    class visual:
+        output_dim = 12
+
+    def __init__(self):
+        super().__init__()
+        self.seen = []
+
+    def encode_image(self, x):
+        self.seen.append(x.clone())
+        return stub_encode_image(x)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "tiled_clip.npz"))
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_get_patches_and_tiled_inference_match_reference(golden, case):
+    g = golden
+    rgb = torch.from_numpy(g[f"c{case}_rgb"])
+    ps, st = (int(v) for v in g[f"c{case}_patch"])
+    bb = StubBackbone()
+    clip = Clip("stub", None, backbone=bb, tokenizer=None)
+    patches = clip.get_patches(rgb, ps, st)
+    assert tuple(patches.shape) == tuple(int(v) for v in g[f"c{case}_patches_shape"])
+    assert np.array_equal(patches[:, :, :, :, ::3, ::3].numpy(), g[f"c{case}_patches_sample"]), "tile order / content"
+    for cap in (8, 64, 5):  # the reference's cap, ours, and one that does not divide the tile count
+        bb.seen.clear()
+        clip.max_patch_batch_size = cap
+        feats = clip.img_inference_tiled(rgb, ps, st)
+        resized = torch.cat(bb.seen)
+        np.testing.assert_allclose(resized[:, :, ::13, ::11].numpy(), g[f"c{case}_resized_sample"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(resized.double().sum(dim=(1, 2, 3)).numpy(), g[f"c{case}_resized_sum"], rtol=1e-6)
+        assert feats.shape == g[f"c{case}_feats"].shape
+        np.testing.assert_allclose(feats.numpy(), g[f"c{case}_feats"], rtol=1e-5, atol=1e-6)
+
+
+def test_tile_shape_asserts_like_the_reference():
+    clip = Clip("stub", None, backbone=StubBackbone(), tokenizer=None)
+    with pytest.raises(AssertionError):  # (H - p) % s != 0, clipfusion.py:792-793
+        clip.get_patches(torch.zeros(1, 3, 50, 64), 16, 8)
