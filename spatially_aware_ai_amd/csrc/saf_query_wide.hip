@@ -218,6 +218,344 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// v2: 64 feature rows per wave at ONE wave per SIMD (the whole 512-register file), fused epilogues.
+//
+// v1 above spends one ds_read_b128 of text per MFMA and two waves per SIMD share the matrix pipe, meeting at a
+// barrier every 32 MFMAs.  Here a wave keeps TWO 32-row fragments of the volume in registers (256 VGPRs at
+// D = 512), so every text fragment read from LDS feeds two MFMAs and a tile of 32 queries is 64 back-to-back
+// MFMAs per wave between barriers; the query tiles run as one continuous double-buffered sequence across row
+// blocks (the next block's first tile is already in flight during the last tile of this one).
+//
+// Epilogues (saf_wide_epilogue): SCORES writes the N x Q scores (16-bit outputs as 16-byte stores after a
+// half-wave exchange); VS_BACKGROUND turns every target column into softmax([backgrounds..., target])[-1]
+// (query_mesh.py:36-39, hypersim_eval.py:76-81) from a per-row log-sum-exp of the background scores; ROW_ARGMAX
+// keeps only the best query and its score per row (eval_scannet_segmentation.py:553-560, first label of the
+// argsort); QUERY_MAX keeps only the best row and its score per query.  The last two write no N x Q output.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kW2Threads = 256;
+constexpr int kW2Waves = 4;
+constexpr int kW2Rows = 64;  // feature rows per wave
+
+// float -> u32 that orders like the float (for integer atomic max)
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t o) {
+  return __builtin_bit_cast(float, (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// 8 consecutive 16-bit scores per lane from the two half-waves' groups g (even) and g + 1: after the exchange
+// lanes 0-31 hold queries 8 g .. 8 g + 7 and lanes 32-63 queries 8 g + 8 .. 8 g + 15 of their row (T21).
+template <int OT>
+__device__ __forceinline__ uint2 pack4_16(float v0, float v1, float v2, float v3) {
+  if (OT == SAF_BF16) return make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 a, b;
+  a.x = (_Float16)v0; a.y = (_Float16)v1; b.x = (_Float16)v2; b.y = (_Float16)v3;
+  return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+}
+
+struct Wide2Args {
+  const uint16_t* feats;
+  int64_t n_rows, fstride;
+  const uint16_t* text16;  // [Qpad][D]; VS_BACKGROUND: tile 0 = backgrounds (zero padded), targets from tile 1
+  int Q, Qpad;             // Q = columns that exist (VS_BACKGROUND: 32 + number of targets)
+  float scale;
+  int normalize, n_bg, flags;
+  void* out;               // SCORES / VS_BACKGROUND
+  int64_t ostride;
+  int32_t* out_index;      // ROW_ARGMAX [n_rows]
+  float* out_value;        // ROW_ARGMAX [n_rows]
+  unsigned long long* qkeys;  // QUERY_MAX [Qpad]: ordered(score) << 32 | low 32 bits of ~row (smaller row wins ties)
+  int64_t row_offset;
+};
+
+template <int FT, int OT, int KS, int EPI>
+__global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1))) void query_wide2_kernel(Wide2Args wa) {
+  constexpr int D = KS * 16;
+  constexpr int ROWB = D * 2 + 16;  // padded LDS row in bytes: the 16 lanes of a ds_read_b128 group hit distinct bank quads
+  constexpr bool kDma = (D == 512);  // a text row is exactly one 1 KiB LDS-DMA piece
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_tiles[];  // 2 x [32][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n_qt = wa.Qpad / kWTile;
+  const int64_t rows_per_wg = (int64_t)kW2Waves * kW2Rows;
+  const int64_t n_blocks = (wa.n_rows + rows_per_wg - 1) / rows_per_wg;
+  const int64_t my_blocks = blockIdx.x < n_blocks ? (n_blocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t n_steps = my_blocks * n_qt;  // (row block, query tile) pairs of this workgroup, in order
+  if (n_steps == 0) return;
+  constexpr int PIECES = kWTile * (D / 8);
+  constexpr int PPT = (PIECES + kW2Threads - 1) / kW2Threads;
+
+  auto issue_tile = [&](int qt, unsigned char* dst) {  // LDS-DMA form: lands later, covered by vmcnt before the barrier
+#pragma unroll
+    for (int k = 0; k < kWTile / kW2Waves; ++k) {
+      const int q = wave * (kWTile / kW2Waves) + k;
+      const uint16_t* src = wa.text16 + (int64_t)(qt * kWTile + q) * D + lane * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + q * ROWB), 16, 0, 0);
+    }
+  };
+  auto copy_tile = [&](int qt, unsigned char* dst) {  // register-staged form (narrower rows, and the very first tile)
+    for (int p = tid; p < PIECES; p += kW2Threads) {
+      const int q = p / (D / 8), c = p - q * (D / 8);
+      *reinterpret_cast<uint4*>(dst + q * ROWB + c * 16) =
+          *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)(qt * kWTile + q) * D + c * 8);
+    }
+  };
+
+  copy_tile(0, s_tiles);
+  __syncthreads();
+
+  uint4 a0[KS], a1[KS];
+  float inv0 = 0.f, inv1 = 0.f;
+  int64_t row_a = 0, row_b = 0;  // this lane's two feature rows (true indices, may be >= n_rows)
+  // per-row-block epilogue state
+  float best_v0 = -INFINITY, best_v1 = -INFINITY, lse0 = 0.f, lse1 = 0.f;
+  int best_q0 = 0, best_q1 = 0;
+  const bool vec_ok = (wa.ostride % 8 == 0) && (((uintptr_t)wa.out & 15) == 0);
+
+  int64_t step = 0;
+  for (int64_t bi = 0; bi < my_blocks; ++bi) {
+    const int64_t blk = blockIdx.x + bi * gridDim.x;
+    const int64_t row0 = (blk * kW2Waves + wave) * kW2Rows;
+    row_a = row0 + r;
+    row_b = row0 + 32 + r;
+    {
+      const int64_t ra = row_a < wa.n_rows ? row_a : wa.n_rows - 1, rb = row_b < wa.n_rows ? row_b : wa.n_rows - 1;
+      const uint16_t* pa = wa.feats + ra * wa.fstride + 8 * h;
+      const uint16_t* pb = wa.feats + rb * wa.fstride + 8 * h;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        a0[s] = __builtin_nontemporal_load(reinterpret_cast<const uint4*>(pa + 16 * s));
+        a1[s] = __builtin_nontemporal_load(reinterpret_cast<const uint4*>(pb + 16 * s));
+      }
+    }
+    inv0 = inv1 = wa.scale;
+    if (wa.normalize) {
+      float ss0 = 0.f, ss1 = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint32_t w0[4] = {a0[s].x, a0[s].y, a0[s].z, a0[s].w};
+        const uint32_t w1[4] = {a1[s].x, a1[s].y, a1[s].z, a1[s].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lo = elem16_to_f32<FT>((uint16_t)(w0[j] & 0xffffu)), hi = elem16_to_f32<FT>((uint16_t)(w0[j] >> 16));
+          ss0 = __builtin_fmaf(lo, lo, ss0);
+          ss0 = __builtin_fmaf(hi, hi, ss0);
+          lo = elem16_to_f32<FT>((uint16_t)(w1[j] & 0xffffu)); hi = elem16_to_f32<FT>((uint16_t)(w1[j] >> 16));
+          ss1 = __builtin_fmaf(lo, lo, ss1);
+          ss1 = __builtin_fmaf(hi, hi, ss1);
+        }
+      }
+      ss0 += __shfl_xor(ss0, 32);
+      ss1 += __shfl_xor(ss1, 32);
+      if (wa.normalize == SAF_NORM_L2_CLAMP) {
+        inv0 = wa.scale / fmaxf(sqrtf(ss0), 0.1f);
+        inv1 = wa.scale / fmaxf(sqrtf(ss1), 0.1f);
+      } else {  // SAF_NORM_L2 with nan_to_num: an all-zero row scores 0
+        inv0 = ss0 > 0.0f ? wa.scale / sqrtf(ss0) : 0.0f;
+        inv1 = ss1 > 0.0f ? wa.scale / sqrtf(ss1) : 0.0f;
+      }
+    }
+    best_v0 = best_v1 = -INFINITY;
+    best_q0 = best_q1 = 0;
+
+    for (int qt = 0; qt < n_qt; ++qt, ++step) {
+      const unsigned char* cur = s_tiles + (size_t)(step & 1) * kWTile * ROWB;
+      unsigned char* nxt = s_tiles + (size_t)((step + 1) & 1) * kWTile * ROWB;
+      const bool more = step + 1 < n_steps;
+      const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
+      uint4 stage[kDma ? 1 : PPT];
+      if (more) {
+        if (kDma) {
+          issue_tile(qt_next, nxt);
+        } else {
+#pragma unroll
+          for (int k = 0; k < PPT; ++k) {
+            const int p = tid + k * kW2Threads;
+            if (p < PIECES) {
+              const int q = p / (D / 8), c = p - q * (D / 8);
+              stage[k] = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)(qt_next * kWTile + q) * D + c * 8);
+            }
+          }
+        }
+      }
+      f32x16_t c0, c1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
+      const unsigned char* trow = cur + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4 t = *reinterpret_cast<const uint4*>(trow + 32 * s);
+        c0 = mfma16<FT>(t, a0[s], c0);  // C[query][feature row]
+        c1 = mfma16<FT>(t, a1[s], c1);
+      }
+      if (more && !kDma) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const int p = tid + k * kW2Threads;
+          if (p < PIECES) {
+            const int q = p / (D / 8), c = p - q * (D / 8);
+            *reinterpret_cast<uint4*>(nxt + q * ROWB + c * 16) = stage[k];
+          }
+        }
+      }
+      // the barrier before this tile's epilogue: what it waits for is the next tile's LDS-DMA (issued a whole MFMA
+      // phase ago) and the previous tile's output stores
+      if (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+
+      // ---------------- epilogue of tile qt on the accumulator layout ----------------
+      // lane (r, h): feature rows row_a (c0) / row_b (c1); register 4 g + i holds query qt*32 + 8 g + 4 h + i
+      const int qbase = qt * kWTile + 4 * h;
+      if (EPI == SAF_QW_SCORES || EPI == SAF_QW_VS_BACKGROUND) {
+        float v0[16], v1[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v0[i] = c0[i] * inv0; v1[i] = c1[i] * inv1; }
+        int col0 = qbase;  // output column of register 0
+        bool write = true;
+        if (EPI == SAF_QW_VS_BACKGROUND) {
+          if (qt == 0) {  // tile 0 holds the backgrounds: per-row log-sum-exp of their scaled scores, no output
+            float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const bool bg = 8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg;
+              m0 = bg ? fmaxf(m0, v0[i]) : m0;
+              m1 = bg ? fmaxf(m1, v1[i]) : m1;
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 32));
+            m1 = fmaxf(m1, __shfl_xor(m1, 32));
+            float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const bool bg = 8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg;
+              e0 += bg ? __expf(v0[i] - m0) : 0.f;
+              e1 += bg ? __expf(v1[i] - m1) : 0.f;
+            }
+            e0 += __shfl_xor(e0, 32);
+            e1 += __shfl_xor(e1, 32);
+            lse0 = m0 + __logf(e0);
+            lse1 = m1 + __logf(e1);
+            write = false;
+          } else {
+            // softmax([bg..., target])[-1] = 1 / (1 + exp(lse_bg - z_target))
+            const bool rescale = (wa.flags & 1) != 0;  // query_mesh.py:39: ((r - 0.5) * 2).clamp(0, 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              float p0 = __builtin_amdgcn_rcpf(1.0f + __expf(lse0 - v0[i])), p1 = __builtin_amdgcn_rcpf(1.0f + __expf(lse1 - v1[i]));
+              if (rescale) {
+                p0 = fminf(fmaxf((p0 - 0.5f) * 2.0f, 0.0f), 1.0f);
+                p1 = fminf(fmaxf((p1 - 0.5f) * 2.0f, 0.0f), 1.0f);
+              }
+              v0[i] = p0; v1[i] = p1;
+            }
+            col0 = qbase - kWTile;
+          }
+        }
+        if (write) {
+          const int ncols = EPI == SAF_QW_VS_BACKGROUND ? wa.Q - kWTile : wa.Q;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const float* v = f ? v1 : v0;
+            const int64_t row = f ? row_b : row_a;
+            if (OT == SAF_F32) {
+              if (row < wa.n_rows) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  const int q0 = col0 + 8 * g;
+                  float* o = static_cast<float*>(wa.out) + row * wa.ostride + q0;
+                  if (vec_ok && q0 + 3 < ncols) {
+                    *reinterpret_cast<float4*>(o) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                  } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                      if (q0 + i < ncols) o[i] = v[4 * g + i];
+                  }
+                }
+              }
+            } else {
+              // pairs of groups (g, g + 1): after the half-wave exchange lanes 0-31 hold columns 16 gp .. + 7 and
+              // lanes 32-63 columns 16 gp + 8 .. + 15 of their row: one 16-byte store each
+#pragma unroll
+              for (int gp = 0; gp < 2; ++gp) {
+                uint2 lo = pack4_16<OT>(v[8 * gp], v[8 * gp + 1], v[8 * gp + 2], v[8 * gp + 3]);       // group 2 gp
+                uint2 hi = pack4_16<OT>(v[8 * gp + 4], v[8 * gp + 5], v[8 * gp + 6], v[8 * gp + 7]);   // group 2 gp + 1
+                auto rx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+                auto ry = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+                // lanes 0-31: [own group 2gp | upper half's group 2gp]; lanes 32-63: [lower half's group 2gp+1 | own]
+                const uint4 w = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                const int qv = (col0 - 4 * h) + 16 * gp + 8 * h;  // first of this lane's 8 columns
+                if (row < wa.n_rows) {
+                  uint16_t* o = static_cast<uint16_t*>(wa.out) + row * wa.ostride + qv;
+                  if (vec_ok && qv + 7 < ncols) {
+                    *reinterpret_cast<uint4*>(o) = w;
+                  } else {
+                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                      if (qv + i < ncols) o[i] = (uint16_t)(ww[i >> 1] >> (16 * (i & 1)));
+                  }
+                }
+              }
+            }
+          }
+        }
+      } else if (EPI == SAF_QW_ROW_ARGMAX) {
+        const bool last = qt == n_qt - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int q = qbase + 8 * (i >> 2) + (i & 3);
+          float x0 = c0[i] * inv0, x1 = c1[i] * inv1;
+          if (last && q >= wa.Q) { x0 = -INFINITY; x1 = -INFINITY; }  // zero-padded text rows are no candidates
+          if (x0 > best_v0) { best_v0 = x0; best_q0 = q; }  // queries ascend: the first maximum stays
+          if (x1 > best_v1) { best_v1 = x1; best_q1 = q; }
+        }
+      } else {  // SAF_QW_QUERY_MAX: best row per query -- reduce over the wave's 64 rows, one atomic per query
+        const bool last = qt == n_qt - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int q = qbase + 8 * (i >> 2) + (i & 3);
+          const float x0 = row_a < wa.n_rows ? c0[i] * inv0 : -INFINITY, x1 = row_b < wa.n_rows ? c1[i] * inv1 : -INFINITY;
+          // key: ordered score in the high word, ~row in the low word (equal scores: the smaller row wins)
+          const unsigned long long k0 = ((unsigned long long)ordered_bits(x0) << 32) | (uint32_t)~(uint32_t)(row_a + wa.row_offset);
+          const unsigned long long k1 = ((unsigned long long)ordered_bits(x1) << 32) | (uint32_t)~(uint32_t)(row_b + wa.row_offset);
+          unsigned long long k = k0 > k1 ? k0 : k1;
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            const unsigned long long t = __shfl_xor(k, o);
+            k = t > k ? t : k;
+          }
+          if (r == 0 && !(last && q >= wa.Q)) atomicMax(&wa.qkeys[q], k);
+        }
+      }
+    }
+    if (EPI == SAF_QW_ROW_ARGMAX) {
+      // both halves of a row: the larger score, the smaller query on ties
+      const float ov0 = __shfl_xor(best_v0, 32), ov1 = __shfl_xor(best_v1, 32);
+      const int oq0 = __shfl_xor(best_q0, 32), oq1 = __shfl_xor(best_q1, 32);
+      if (ov0 > best_v0 || (ov0 == best_v0 && oq0 < best_q0)) { best_v0 = ov0; best_q0 = oq0; }
+      if (ov1 > best_v1 || (ov1 == best_v1 && oq1 < best_q1)) { best_v1 = ov1; best_q1 = oq1; }
+      if (h == 0) {
+        if (row_a < wa.n_rows) { wa.out_index[row_a] = best_q0; wa.out_value[row_a] = best_v0; }
+        if (row_b < wa.n_rows) { wa.out_index[row_b] = best_q1; wa.out_value[row_b] = best_v1; }
+      }
+    }
+  }
+}
+
+__global__ void qkeys_decode_kernel(const unsigned long long* __restrict__ keys, int Q, float* __restrict__ out_value,
+                                    int64_t* __restrict__ out_row, int64_t row_hi) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Q) return;
+  const unsigned long long k = keys[q];
+  out_value[q] = k ? from_ordered_bits((uint32_t)(k >> 32)) : -INFINITY;
+  // the low word is ~(row + offset) mod 2^32; row_hi restores the bits above 32 (volumes here have < 2^32 rows)
+  out_row[q] = k ? (int64_t)(uint32_t)~(uint32_t)k + row_hi : -1;
+}
+
 template <int FT, int OT, int KS>
 int launch_wide(const uint16_t* feats, int64_t n_rows, int64_t fstride, const uint16_t* text16, int Q, int Qpad,
                 float scale, int normalize, void* out, int64_t ostride, hipStream_t s) {
