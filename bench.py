@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--api-b1", type=int, default=0, metavar="FRAMES",
                     help="also time FRAMES frames through integrate_features() ONE FRAME PER CALL (the reference's loop, "
                          "clipfusion.py:1125-1133) with the deferred window queue behind it; reported as api_b1")
+    ap.add_argument("--queries", type=int, default=1000, help="--query: number of target text queries")
+    ap.add_argument("--query-wide-only", action="store_true", help="--query: skip the fp32 L=5 / L=63 cases")
     ap.add_argument("--query", action="store_true",
                     help="benchmark the text-query scan instead (BASELINE config 5 and the reference's L = 5 / L = 63 scans)")
     ap.add_argument("--profile-stride", type=int, default=4,
@@ -532,8 +534,167 @@ def main():
         dist.destroy_process_group()
 
 
+MFMA16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak of MI355X (guides/MI355X_MICROARCH.md)
+MFMA32_PEAK_TFLOPS = 157.3   # exact-fp32 matrix peak (= the fp32 vector rate)
+
+
 def bench_query(a, world, rank, local_rank):
-    raise SystemExit("--query: see bench_query.py")
+    """`bench.py --query`: the text-query scans over a volume resident in HBM, one JSON line in the same schema.
+
+    The headline is BASELINE config 5 -- 1000 text queries over a 256^3 x 512 fp16 volume, the query_mesh.py path (4
+    shared background prompts + one target per query, softmax(100 * cos)[-1] per voxel and target), voxel-sharded
+    over the ranks: `value` = queries/s for the whole volume, writing the N x 1000 fp16 heat maps.  `cases` adds the
+    fused reductions that write no N x Q matrix (per-voxel best query, per-query best voxel), the raw scores, and the
+    reference's own small scans over the fp32 volume (L = 5 softmax: query_mesh.py:36-39; L = 63 surgery:
+    query_mesh.py:52-83), each with its roofline from HIP events around the launch."""
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    if os.environ.get("SAF_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
+    from spatially_aware_ai_amd import distributed as sdist
+    from spatially_aware_ai_amd.clipfusion import _query_scan, query_scan_wide
+
+    n_all = a.grid ** 3
+    first, n = sdist.voxel_shard(n_all, rank, world)
+    d, q, n_bg = a.dim, a.queries, 4
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    feats16 = torch.empty((n, d), dtype=torch.float16, device=device)
+    for s0 in range(0, n, 1 << 20):
+        feats16[s0:s0 + (1 << 20)] = torch.randn((min(1 << 20, n - s0), d), generator=g, device=device).half()
+    tg = torch.Generator().manual_seed(9)
+    text = torch.randn((n_bg + q, d), generator=tg)
+    text = (text / text.norm(dim=-1, keepdim=True)).to(device)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for e0, e1 in ev:
+            e0.record()
+            fn()
+            e1.record()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax.item())
+        return wall / steps, sum(e0.elapsed_time(e1) for e0, e1 in ev) / steps * 1e-3
+
+    def mfma_case(name, fn, n_queries, out_bytes, steps, warmup):
+        wall, kern = timed(fn, steps, warmup)
+        flop = 2.0 * n * d * n_queries
+        return {"case": name, "ms": round(wall * 1e3, 3), "rows_this_rank": n, "queries": n_queries,
+                "roofline": {"bound": "mfma", "achieved": round(flop / kern / 1e12, 1), "peak": MFMA16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(flop / kern / 1e12 / MFMA16_PEAK_TFLOPS, 4), "traffic": None,
+                             "avg_launch_us": round(kern * 1e6, 1),
+                             "algorithmic_bytes_per_launch": int(n * d * 2 + n_queries * d * 2 + out_bytes),
+                             "hbm_GBps_of_algorithmic_bytes": round((n * d * 2 + out_bytes) / kern / 1e9, 1)}}
+
+    keep = {}
+
+    def heat_maps():
+        keep["hm"] = query_scan_wide(feats16, text, "vs_background", scale=100.0, n_background=n_bg, rescale=True)
+
+    def query_max():
+        val, row = query_scan_wide(feats16, text[n_bg:], "query_max", row_offset=first)
+        if world > 1:  # the only exchange of the sharded scan: Q (score, voxel) pairs per rank
+            vals = [torch.empty_like(val) for _ in range(world)]
+            rows = [torch.empty_like(row) for _ in range(world)]
+            dist.all_gather(vals, val)
+            dist.all_gather(rows, row)
+            keep["qm"] = torch.stack(vals).max(dim=0)
+        else:
+            keep["qm"] = (val, row)
+
+    cases = []
+    head = mfma_case("query_mesh path: softmax([4 backgrounds, target])[-1] heat maps for every target, fp16 out",
+                     heat_maps, q + n_bg, n * q * 2, a.steps, a.warmup)
+    cases.append(head)
+    del keep["hm"]
+    torch.cuda.empty_cache()
+    cases.append(mfma_case("per-voxel best query (row_argmax), no N x Q output",
+                           lambda: query_scan_wide(feats16, text[n_bg:], "row_argmax"), q, n * 8, a.steps, 1))
+    cases.append(mfma_case("per-query best voxel (query_max), no N x Q output", query_max, q, q * 12, a.steps, 1))
+    cases.append(mfma_case("raw scores, fp16 out",
+                           lambda: keep.__setitem__("sc", query_scan_wide(feats16, text[n_bg:], "scores")), q, n * q * 2,
+                           a.steps, 1))
+    keep.clear()
+    torch.cuda.empty_cache()
+    # the reference's own scans over the fp32 volume (single GPU only: they are HBM-bound and tiny next to the above)
+    if world == 1 and not a.query_wide_only:
+        del feats16
+        torch.cuda.empty_cache()
+        f32 = torch.empty((n, d), dtype=torch.float32, device=device)
+        for s0 in range(0, n, 1 << 20):
+            f32[s0:s0 + (1 << 20)] = torch.randn((min(1 << 20, n - s0), d), generator=g, device=device)
+        for name, nl, epi, scale, peak_note in (
+                ("L=5 softmax over the fp32 volume (query_mesh.py:36-39), last column", 5, _abi.SAF_Q_SOFTMAX, 100.0, None),
+                ("L=63 surgery over the fp32 volume (query_mesh.py:52-83)", 63, _abi.SAF_Q_SURGERY, 1.0, None)):
+            t = text[:nl] if nl <= text.shape[0] else torch.nn.functional.normalize(torch.randn((nl, d), device=device), dim=-1)
+            last = epi == _abi.SAF_Q_SOFTMAX
+            wall, kern = timed(lambda: keep.__setitem__("o", _query_scan(f32, t, epi, scale=scale, normalize=True, last_only=last)),
+                               a.steps, 1)
+            nbytes = n * d * 4 + nl * d * 4 + n * (1 if last else nl) * 4
+            flop = 2.0 * n * d * nl
+            cases.append({"case": name, "ms": round(wall * 1e3, 3), "rows_this_rank": n, "queries": nl,
+                          "roofline": {"bound": "hbm", "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                       "avg_launch_us": round(kern * 1e6, 1), "algorithmic_bytes_per_launch": int(nbytes),
+                                       "exact_fp32_mfma_TFLOPs": round(flop / kern / 1e12, 1),
+                                       "exact_fp32_mfma_frac": round(flop / kern / 1e12 / MFMA32_PEAK_TFLOPS, 4)}})
+            keep.clear()
+    if rank == 0:
+        out = {
+            "metric": f"text queries/s over a {a.grid}^3x{d} fp16 volume (BASELINE config 5: 1000-query CLIP-text scan, query_mesh path)",
+            "value": round(q / (head["ms"] * 1e-3), 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": head["ms"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"{q} target queries + {n_bg} shared background prompts over {n_all} voxel rows x {d} fp16, "
+                                   f"voxel-sharded over {world} rank(s); a step = one scan of the whole volume writing the "
+                                   f"[N, {q}] fp16 heat maps", "grid": a.grid, "feat_dim": d, "queries": q, "n_voxels": n_all,
+                       "parallelism": f"voxels-shard{world}", "rccl_world": world, "backend": a.backend if world > 1 else None},
+            "roofline": dict(head["roofline"], kernel="query_wide2_kernel"),
+            "cases": cases,
+            "cpu_baseline": query_cpu_baseline(a, feats_shape=(n_all, d), q=q + n_bg) if world == 1 and a.cpu_frames != 0 else None,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def query_cpu_baseline(a, feats_shape, q):
+    """The CPU oracle's scan (saf_oracle_query_scan: scores in double, the checker of the parity tests) on a bounded
+    sample of rows of the same shape, one thread (the restatement is scalar C)."""
+    try:
+        from oracle import oracle as O
+    except Exception as e:
+        return {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    rows = 2048
+    g = torch.Generator().manual_seed(3)
+    f = torch.randn(rows, feats_shape[1], generator=g).half().float()
+    t = torch.nn.functional.normalize(torch.randn(q, feats_shape[1], generator=g), dim=-1)
+    t0 = time.perf_counter()
+    O.wide_scan(f, t, "vs_background", scale=100.0, n_background=4)
+    dt = time.perf_counter() - t0
+    # queries/s for the whole volume at this rate
+    return {"value": round((q - 4) / (dt * feats_shape[0] / rows), 4), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"{rows} of the {feats_shape[0]} rows x {q} text rows in {dt:.2f} s on one host thread, "
+                      "extrapolated to the whole volume", "cpu_model": cpu_model()}
 
 
 def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value):

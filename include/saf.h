@@ -222,6 +222,30 @@ int saf_query_scan_wide(const void* feats, int32_t feat_dtype, int64_t n_rows, i
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Wide scan with fused epilogues (64 feature rows per wave at one wave per SIMD; feat_dim 256 or 512).  BASELINE
+ * config 5's N x Q score matrix (33 GB at 256^3 x 1000 fp16) is twice the volume it is computed from; the
+ * reductions the reference's callers apply to it are fused here:
+ *   SAF_QW_SCORES         out[n, q] = scale * <f_n, t_q>                         (as saf_query_scan_wide)
+ *   SAF_QW_VS_BACKGROUND  the first n_background text rows are shared background prompts, the others targets:
+ *                         out[n, t] = softmax(scale * [<f_n, bg_0..>, <f_n, target_t>])[-1] -- query_mesh.py:36-39 and
+ *                         hypersim_eval.py:76-81 for every target at once; flags & 1 adds query_mesh.py:39's
+ *                         ((r - 0.5) * 2).clamp(0, 1).  out is [n_rows, n_text - n_background].
+ *   SAF_QW_ROW_ARGMAX     per row the best query and its score: out_index[n] i32, out_value[n] f32
+ *                         (eval_scannet_segmentation.py:553-560: the first label of the argsort); nothing N x Q is written.
+ *   SAF_QW_QUERY_MAX      per query the best row and its score: out_value[q] f32, out_row[q] i64 = row_offset + local
+ *                         row (equal scores: the smaller row), -1 / -inf when n_rows = 0; row_offset lets ranks that
+ *                         scan voxel shards report global voxel indices.
+ * Unused outputs may be NULL.  workspace: saf_query_wide_ex_workspace_bytes(...) bytes, 256-byte aligned.
+ */
+enum saf_wide_epilogue { SAF_QW_SCORES = 0, SAF_QW_VS_BACKGROUND = 1, SAF_QW_ROW_ARGMAX = 2, SAF_QW_QUERY_MAX = 3 };
+size_t saf_query_wide_ex_workspace_bytes(int32_t n_text, int32_t feat_dim, int32_t epilogue, int32_t n_background);
+int saf_query_scan_wide_ex(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_t feat_stride,
+                           int32_t feat_dim, const float* text, int32_t n_text, int64_t text_stride, float scale,
+                           int32_t normalize, int32_t epilogue, int32_t n_background, int32_t flags, void* out,
+                           int32_t out_dtype, int64_t out_stride, int32_t* out_index, float* out_value,
+                           int64_t* out_row, int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * After the cross-rank SUM of SAF_SUM-mode volumes: clip_feat <- F/w,
  * rgb <- C/w, tsdf <- T/wt over voxels [first, first+count); rows with zero weight stay zero.
  */

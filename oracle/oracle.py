@@ -212,3 +212,39 @@ def label_components(labels_grid, null_class=133, min_voxels=3, max_objects=None
     assert rc == 0
     k = min(int(nobj[0]), mo)
     return ids.view(nx, ny, nz), first[:k], cls[:k], cnt[:k]
+
+
+def wide_scan(feats, text, epilogue="scores", scale=1.0, normalize=True, n_background=0, rescale=False, row_offset=0,
+              round_to=None):
+    """CPU truth of saf_query_scan_wide_ex's epilogues on top of the oracle's scores (saf_oracle_query_scan with
+    SAF_Q_SCORES): the reductions restate, in torch on the CPU, what the reference's callers do with the score matrix --
+    vs_background: softmax(scale * [bg..., target])[-1] per target (query_mesh.py:36-39, hypersim_eval.py:76-81);
+    row_argmax: first maximum per row (eval_scannet_segmentation.py:553-560); query_max: best row per query.
+    ``round_to``: a 16-bit dtype the inputs are rounded to first, as the HIP scan reads them."""
+    feats = torch.as_tensor(feats)
+    text = torch.as_tensor(text, dtype=torch.float32)[:, : feats.shape[1]]
+    if round_to is not None:
+        feats, text = feats.to(round_to), text.to(round_to)
+    mode = {False: 0, True: 1}.get(normalize, normalize)
+    mode = 2 if mode in ("clamp", "clamp_min") else int(mode)
+    s = query_scan(feats.float(), text.float(), _abi.SAF_Q_SCORES, scale=scale, normalize=mode)
+    if epilogue == "scores":
+        return s
+    if epilogue == "vs_background":
+        bg, tg = s[:, :n_background].double(), s[:, n_background:].double()
+        lse = torch.logsumexp(bg, dim=1, keepdim=True)
+        p = torch.sigmoid(tg - lse)  # = softmax([bg..., target])[-1]
+        if rescale:
+            p = ((p - 0.5) * 2).clamp(0, 1)
+        return p.float()
+    if epilogue == "row_argmax":
+        val, idx = s.max(dim=1)
+        idx = torch.argmax((s == val[:, None]).int(), dim=1)  # the first maximum
+        return idx.int(), val
+    if epilogue == "query_max":
+        if s.shape[0] == 0:
+            return torch.full((s.shape[1],), -float("inf")), torch.full((s.shape[1],), -1, dtype=torch.int64)
+        val = s.max(dim=0).values
+        row = torch.argmax((s == val[None]).int(), dim=0)
+        return val, row.long() + row_offset
+    raise ValueError(epilogue)

@@ -18,6 +18,7 @@ SAF_F32, SAF_BF16, SAF_F16 = 0, 1, 2
 SAF_RUNNING_MEAN, SAF_SUM = 0, 1
 SAF_Q_SCORES, SAF_Q_SOFTMAX, SAF_Q_SURGERY = 0, 1, 2
 SAF_NORM_NONE, SAF_NORM_L2, SAF_NORM_L2_CLAMP = 0, 1, 2
+SAF_QW_SCORES, SAF_QW_VS_BACKGROUND, SAF_QW_ROW_ARGMAX, SAF_QW_QUERY_MAX = 0, 1, 2, 3
 SAF_STATS_WORDS = 8
 SAF_WINDOW_FRAMES = 64
 
@@ -105,6 +106,16 @@ PROTOTYPES = {
             _fp, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
             _fp, C.c_int32, C.c_int64,
             C.c_float, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_size_t, _fp,
+        ],
+    ),
+    "saf_query_wide_ex_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "saf_query_scan_wide_ex": (
+        C.c_int,
+        [
+            _fp, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+            _fp, C.c_int32, C.c_int64, C.c_float, C.c_int32,
+            C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, _fp, _fp, C.c_int64,
+            _fp, C.c_size_t, _fp,
         ],
     ),
     "saf_merge_finalize": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),

@@ -428,33 +428,84 @@ def _query_scan(feats, text, epilogue, scale=1.0, normalize=False, last_only=Fal
 _DT = {torch.float32: _abi.SAF_F32, torch.bfloat16: _abi.SAF_BF16, torch.float16: _abi.SAF_F16}
 
 
-def query_scores_wide(feats, text, scale=1.0, normalize=True, out_dtype=None):
-    """Cosine scores of many text queries over a 16-bit feature volume (BASELINE config 5: the
-    query_mesh.py scan with ~1000 queries): ``out[n, q] = scale * <f_n / |f_n|, t_q>`` on the 16-bit matrix
-    cores (saf_query_scan_wide).  ``feats`` [N, D] float16 / bfloat16 on the HIP device, D in {128, 256, 512};
-    ``text`` [Q, >=D] fp32 (rounded to the feature dtype); returns [N, Q] of ``out_dtype`` (default: feats.dtype).
+_WIDE_EPILOGUES = {"scores": _abi.SAF_QW_SCORES, "vs_background": _abi.SAF_QW_VS_BACKGROUND,
+                   "row_argmax": _abi.SAF_QW_ROW_ARGMAX, "query_max": _abi.SAF_QW_QUERY_MAX}
+
+
+def query_scan_wide(feats, text, epilogue="scores", scale=1.0, normalize=True, n_background=0, rescale=False,
+                    out_dtype=None, row_offset=0):
+    """Many text queries over a 16-bit feature volume on the 16-bit matrix cores (BASELINE config 5: the
+    query_mesh.py / hypersim_eval.py scan with ~1000 targets), with the callers' reductions fused into the scan
+    (saf_query_scan_wide_ex) so that the N x Q score matrix -- twice the size of the volume -- need not exist.
+
+    ``feats`` [N, D] float16 / bfloat16 on the HIP device, D in {256, 512} (128: scores only); ``text`` [Q, >=D] fp32
+    (rounded to the feature dtype).  ``epilogue``:
+
+    * ``"scores"``         -> [N, Q]: ``scale * <f_n / |f_n|, t_q>``
+    * ``"vs_background"``  -> [N, Q - n_background]: ``softmax(scale * [<f, bg_0..>, <f, target>])[-1]`` for every target,
+      the first ``n_background`` text rows being the shared background prompts (query_mesh.py:36-39 with
+      ``scale=100``; hypersim_eval.py:76-81); ``rescale=True`` adds ``((r - 0.5) * 2).clamp(0, 1)`` (query_mesh.py:39)
+    * ``"row_argmax"``     -> (index int32 [N], value f32 [N]): best query per row
+      (eval_scannet_segmentation.py:553-560, the first label of the argsort)
+    * ``"query_max"``      -> (value f32 [Q], row int64 [Q]): best row per query, rows numbered from ``row_offset``
     """
     require_cuda(feats, "features")
     if feats.dtype not in (torch.float16, torch.bfloat16) or feats.dim() != 2:
-        raise ValueError("query_scores_wide needs a [N, D] float16 / bfloat16 feature tensor")
+        raise ValueError("query_scan_wide needs a [N, D] float16 / bfloat16 feature tensor")
     if feats.stride(1) != 1:
         feats = feats.contiguous()
+    epi = _WIDE_EPILOGUES[epilogue] if isinstance(epilogue, str) else int(epilogue)
     out_dtype = out_dtype or feats.dtype
-    t = text.detach().to(device=feats.device, dtype=torch.float32)
+    dev = feats.device
+    t = text.detach().to(device=dev, dtype=torch.float32)
     if t.stride(1) != 1:
         t = t.contiguous()
     n, d = feats.shape
     q = t.shape[0]
-    out = torch.empty((n, q), dtype=out_dtype, device=feats.device)
-    wsb = lib().saf_query_wide_workspace_bytes(q, d)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=feats.device)
-    with torch.cuda.device(feats.device):
-        rc = lib().saf_query_scan_wide(
-            feats.data_ptr(), _DT[feats.dtype], n, feats.stride(0), d, t.data_ptr(), q, t.stride(0), float(scale),
-            _norm_mode(normalize), out.data_ptr(), _DT[out_dtype], out.stride(0), ws.data_ptr(), wsb, current_stream_ptr(),
+    if t.shape[1] < d:
+        raise RuntimeError(f"text features have {t.shape[1]} dims, image features {d}")
+    L = lib()
+    norm = _norm_mode(normalize)
+    if d == 128 and epi == _abi.SAF_QW_SCORES:  # the narrow shape keeps the first kernel
+        out = torch.empty((n, q), dtype=out_dtype, device=dev)
+        wsb = L.saf_query_wide_workspace_bytes(q, d)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.saf_query_scan_wide(feats.data_ptr(), _DT[feats.dtype], n, feats.stride(0), d, t.data_ptr(), q,
+                                       t.stride(0), float(scale), norm, out.data_ptr(), _DT[out_dtype], out.stride(0),
+                                       ws.data_ptr(), wsb, current_stream_ptr())
+        check(rc, "saf_query_scan_wide")
+        return out
+    out = idx = val = row = None
+    if epi in (_abi.SAF_QW_SCORES, _abi.SAF_QW_VS_BACKGROUND):
+        cols = q - (int(n_background) if epi == _abi.SAF_QW_VS_BACKGROUND else 0)
+        # rows padded to a multiple of 8 columns keep every 16-byte store of the epilogue aligned
+        stride = (cols + 7) // 8 * 8
+        out = torch.empty((n, stride), dtype=out_dtype, device=dev)[:, :cols]
+    elif epi == _abi.SAF_QW_ROW_ARGMAX:
+        idx = torch.empty(n, dtype=torch.int32, device=dev)
+        val = torch.empty(n, dtype=torch.float32, device=dev)
+    else:
+        val = torch.empty(q, dtype=torch.float32, device=dev)
+        row = torch.empty(q, dtype=torch.int64, device=dev)
+    wsb = L.saf_query_wide_ex_workspace_bytes(q, d, epi, int(n_background))
+    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.saf_query_scan_wide_ex(
+            feats.data_ptr(), _DT[feats.dtype], n, feats.stride(0), d, t.data_ptr(), q, t.stride(0), float(scale), norm,
+            epi, int(n_background), int(bool(rescale)), _abi.ptr(out), _DT[out_dtype], 0 if out is None else out.stride(0),
+            _abi.ptr(idx), _abi.ptr(val), _abi.ptr(row), int(row_offset), ws.data_ptr(), ws.numel(), current_stream_ptr(),
         )
-    check(rc, "saf_query_scan_wide")
-    return out
+    check(rc, "saf_query_scan_wide_ex")
+    if out is not None:
+        return out
+    return (idx, val) if idx is not None else (val, row)
+
+
+def query_scores_wide(feats, text, scale=1.0, normalize=True, out_dtype=None):
+    """Cosine scores of many text queries over a 16-bit feature volume: ``out[n, q] = scale * <f_n / |f_n|, t_q>``
+    ([N, Q] of ``out_dtype``, default feats.dtype).  See query_scan_wide for the fused reductions."""
+    return query_scan_wide(feats, text, "scores", scale=scale, normalize=normalize, out_dtype=out_dtype)
 
 
 class Clip(torch.nn.Module):

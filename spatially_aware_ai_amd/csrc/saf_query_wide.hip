@@ -237,6 +237,12 @@ constexpr int kW2Threads = 256;
 constexpr int kW2Waves = 4;
 constexpr int kW2Rows = 64;  // feature rows per wave
 
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream_u4(const uint16_t* p) {  // the volume is read once: keep it out of the caches' way
+  const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // float -> u32 that orders like the float (for integer atomic max)
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
   const uint32_t b = __builtin_bit_cast(uint32_t, f);
@@ -329,8 +335,8 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
       const uint16_t* pb = wa.feats + rb * wa.fstride + 8 * h;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        a0[s] = __builtin_nontemporal_load(reinterpret_cast<const uint4*>(pa + 16 * s));
-        a1[s] = __builtin_nontemporal_load(reinterpret_cast<const uint4*>(pb + 16 * s));
+        a0[s] = ld_stream_u4(pa + 16 * s);
+        a1[s] = ld_stream_u4(pb + 16 * s);
       }
     }
     inv0 = inv1 = wa.scale;
@@ -596,6 +602,73 @@ int launch_wide_ot(int ot, int D, const uint16_t* feats, int64_t n_rows, int64_t
   }
 }
 
+template <int FT, int OT, int KS, int EPI>
+int launch_wide2(const Wide2Args& wa, hipStream_t s) {
+  constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16);
+  auto fn = query_wide2_kernel<FT, OT, KS, EPI>;
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)shmem);
+    if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const int64_t rows_per_wg = (int64_t)kW2Waves * kW2Rows;
+  int64_t blocks = (wa.n_rows + rows_per_wg - 1) / rows_per_wg;
+  const int64_t cap = device_cus();  // persistent: one workgroup (4 waves, one per SIMD) per CU
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kW2Threads), shmem, s, wa);
+  return check_launch("query_wide2_kernel");
+}
+
+template <int FT, int KS>
+int launch_wide2_epi(int epi, int ot, const Wide2Args& wa, hipStream_t s) {
+  switch (epi) {
+    case SAF_QW_SCORES:
+      switch (ot) {
+        case SAF_F32: return launch_wide2<FT, SAF_F32, KS, SAF_QW_SCORES>(wa, s);
+        case SAF_F16: return launch_wide2<FT, SAF_F16, KS, SAF_QW_SCORES>(wa, s);
+        case SAF_BF16: return launch_wide2<FT, SAF_BF16, KS, SAF_QW_SCORES>(wa, s);
+      }
+      break;
+    case SAF_QW_VS_BACKGROUND:
+      switch (ot) {
+        case SAF_F32: return launch_wide2<FT, SAF_F32, KS, SAF_QW_VS_BACKGROUND>(wa, s);
+        case SAF_F16: return launch_wide2<FT, SAF_F16, KS, SAF_QW_VS_BACKGROUND>(wa, s);
+        case SAF_BF16: return launch_wide2<FT, SAF_BF16, KS, SAF_QW_VS_BACKGROUND>(wa, s);
+      }
+      break;
+    case SAF_QW_ROW_ARGMAX: return launch_wide2<FT, SAF_F32, KS, SAF_QW_ROW_ARGMAX>(wa, s);
+    case SAF_QW_QUERY_MAX: return launch_wide2<FT, SAF_F32, KS, SAF_QW_QUERY_MAX>(wa, s);
+  }
+  return fail(SAF_E_INVALID, "wide scan: bad epilogue %d / out_dtype %d", epi, ot);
+}
+
+// fp32 text -> 16-bit tiles.  SCORES / ROW_ARGMAX / QUERY_MAX: row q of the text is row q.  VS_BACKGROUND: the
+// first n_bg rows (the shared background prompts) fill tile 0, zero padded to 32 rows; target t is row 32 + t.
+template <int FT>
+__global__ void text_tiles_kernel(const float* __restrict__ text, int Q, int64_t tstride, int D, int Qpad, int n_bg,
+                                  uint16_t* __restrict__ out, unsigned long long* __restrict__ qkeys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qkeys && i < Qpad) qkeys[i] = 0ull;
+  if (i >= Qpad * D) return;
+  const int q = i / D, k = i - q * D;
+  int src = q;
+  if (n_bg > 0) src = q < kWTile ? (q < n_bg ? q : -1) : q - kWTile + n_bg;
+  const float v = (src >= 0 && src < Q) ? text[(int64_t)src * tstride + k] : 0.0f;
+  if (FT == SAF_BF16) {
+    out[i] = (uint16_t)f32_to_bf16_bits(v);
+  } else {
+    const _Float16 hv = (_Float16)v;
+    out[i] = __builtin_bit_cast(uint16_t, hv);
+  }
+}
+
+// columns the kernel sees (Q of Wide2Args) and their padding to whole tiles
+inline int wide2_cols(int n_text, int epi, int n_bg) { return epi == SAF_QW_VS_BACKGROUND ? kWTile + (n_text - n_bg) : n_text; }
+inline size_t wide2_ws_bytes(int n_text, int D, int epi, int n_bg) {
+  const size_t qpad = ((size_t)wide2_cols(n_text, epi, n_bg) + kWTile - 1) / kWTile * kWTile;
+  return ((qpad * D * 2 + 255) & ~(size_t)255) + qpad * sizeof(unsigned long long);
+}
+
 }  // namespace
 }  // namespace saf
 
@@ -640,6 +713,83 @@ int saf_query_scan_wide(const void* feats, int32_t feat_dtype, int64_t n_rows, i
                                         out, out_stride, s)
              : launch_wide_ot<SAF_F16>(out_dtype, feat_dim, f, n_rows, feat_stride, text16, n_text, Qpad, scale, normalize,
                                        out, out_stride, s);
+}
+
+size_t saf_query_wide_ex_workspace_bytes(int32_t n_text, int32_t feat_dim, int32_t epilogue, int32_t n_background) {
+  if (n_text <= 0 || feat_dim <= 0 || n_background < 0 || n_background > n_text) return 0;
+  return wide2_ws_bytes(n_text, feat_dim, epilogue, n_background);
+}
+
+int saf_query_scan_wide_ex(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_t feat_stride, int32_t feat_dim,
+                           const float* text, int32_t n_text, int64_t text_stride, float scale, int32_t normalize,
+                           int32_t epilogue, int32_t n_background, int32_t flags, void* out, int32_t out_dtype,
+                           int64_t out_stride, int32_t* out_index, float* out_value, int64_t* out_row, int64_t row_offset,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (feat_dtype != SAF_F16 && feat_dtype != SAF_BF16)
+    return fail(SAF_E_UNSUPPORTED, "wide scan: features must be SAF_F16 or SAF_BF16");
+  if (feat_dim != 256 && feat_dim != 512)
+    return fail(SAF_E_UNSUPPORTED, "wide scan (fused epilogues): feat_dim must be 256 or 512 (got %d)", feat_dim);
+  if (!feats || !text || n_rows < 0 || n_text <= 0 || feat_stride < feat_dim || text_stride < feat_dim)
+    return fail(SAF_E_INVALID, "wide scan: bad arguments");
+  if (((uintptr_t)feats & 15) || (feat_stride % 8) != 0) return fail(SAF_E_INVALID, "wide scan: feature rows must be 16-byte aligned");
+  int n_bg = 0, n_out_cols = n_text;
+  switch (epilogue) {
+    case SAF_QW_SCORES:
+      if (!out || out_stride < n_text) return fail(SAF_E_INVALID, "wide scan: SCORES needs out [n_rows, >= n_text]");
+      break;
+    case SAF_QW_VS_BACKGROUND:
+      n_bg = n_background;
+      n_out_cols = n_text - n_bg;
+      if (n_bg < 1 || n_bg > kWTile || n_out_cols < 1)
+        return fail(SAF_E_INVALID, "wide scan: VS_BACKGROUND needs 1..32 background rows followed by at least one target");
+      if (!out || out_stride < n_out_cols) return fail(SAF_E_INVALID, "wide scan: VS_BACKGROUND needs out [n_rows, >= n_text - n_background]");
+      if (!(scale > 0.0f)) return fail(SAF_E_INVALID, "wide scan: VS_BACKGROUND needs a positive scale");
+      break;
+    case SAF_QW_ROW_ARGMAX:
+      if (!out_index || !out_value) return fail(SAF_E_INVALID, "wide scan: ROW_ARGMAX needs out_index and out_value [n_rows]");
+      break;
+    case SAF_QW_QUERY_MAX:
+      if (!out_value || !out_row) return fail(SAF_E_INVALID, "wide scan: QUERY_MAX needs out_value and out_row [n_text]");
+      if (row_offset < 0 || row_offset + n_rows > (int64_t)0xffffffffll) return fail(SAF_E_UNSUPPORTED, "wide scan: QUERY_MAX rows must index below 2^32");
+      break;
+    default: return fail(SAF_E_INVALID, "wide scan: bad epilogue %d", epilogue);
+  }
+  const size_t need = wide2_ws_bytes(n_text, feat_dim, epilogue, n_bg);
+  if (!workspace || ((uintptr_t)workspace & 255) || workspace_bytes < need)
+    return fail(SAF_E_WORKSPACE, "wide scan: workspace needs %zu bytes, 256-byte aligned", need);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int cols = wide2_cols(n_text, epilogue, n_bg);
+  const int Qpad = (cols + kWTile - 1) / kWTile * kWTile;
+  uint16_t* text16 = static_cast<uint16_t*>(workspace);
+  unsigned long long* qkeys = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(workspace) +
+                                                                   (((size_t)Qpad * feat_dim * 2 + 255) & ~(size_t)255));
+  const int items = Qpad * feat_dim;
+  if (feat_dtype == SAF_BF16)
+    hipLaunchKernelGGL(text_tiles_kernel<SAF_BF16>, dim3((items + 255) / 256), dim3(256), 0, s, text, n_text, text_stride,
+                       feat_dim, Qpad, n_bg, text16, epilogue == SAF_QW_QUERY_MAX ? qkeys : nullptr);
+  else
+    hipLaunchKernelGGL(text_tiles_kernel<SAF_F16>, dim3((items + 255) / 256), dim3(256), 0, s, text, n_text, text_stride,
+                       feat_dim, Qpad, n_bg, text16, epilogue == SAF_QW_QUERY_MAX ? qkeys : nullptr);
+  int rc = check_launch("text_tiles_kernel");
+  if (rc) return rc;
+  if (n_rows > 0) {
+    Wide2Args wa;
+    wa.feats = static_cast<const uint16_t*>(feats);
+    wa.n_rows = n_rows; wa.fstride = feat_stride; wa.text16 = text16; wa.Q = cols; wa.Qpad = Qpad; wa.scale = scale;
+    wa.normalize = normalize; wa.n_bg = n_bg; wa.flags = flags; wa.out = out; wa.ostride = out_stride;
+    wa.out_index = out_index; wa.out_value = out_value; wa.qkeys = qkeys; wa.row_offset = row_offset;
+    if (feat_dtype == SAF_BF16)
+      rc = feat_dim == 512 ? launch_wide2_epi<SAF_BF16, 32>(epilogue, out_dtype, wa, s) : launch_wide2_epi<SAF_BF16, 16>(epilogue, out_dtype, wa, s);
+    else
+      rc = feat_dim == 512 ? launch_wide2_epi<SAF_F16, 32>(epilogue, out_dtype, wa, s) : launch_wide2_epi<SAF_F16, 16>(epilogue, out_dtype, wa, s);
+    if (rc) return rc;
+  }
+  if (epilogue == SAF_QW_QUERY_MAX) {
+    hipLaunchKernelGGL(qkeys_decode_kernel, dim3((n_text + 255) / 256), dim3(256), 0, s, qkeys, n_text, out_value, out_row,
+                       (int64_t)0);
+    return check_launch("qkeys_decode_kernel");
+  }
+  return SAF_OK;
 }
 
 }  // extern "C"

@@ -188,3 +188,89 @@ def gather_shards(fusion, group=None):
         _all_gather_rows(t, group, rank, world)
     fusion._shard_range = None
     return 0, fusion.tsdf.numel()
+
+
+# --------------------------------------------------------------------------------------------
+# voxel-sharded text-query scan (BASELINE config 5)
+# --------------------------------------------------------------------------------------------
+
+
+def shard_features_16(fusion, first, count, dtype=torch.float16):
+    """The 16-bit copy of a volume's voxel shard that the wide scan reads (cached on the module until the volume
+    is fused into or reset again).  One pass over count * D * 4 bytes."""
+    key = (first, count, dtype, fusion.clip_feat.data_ptr(), int(fusion.fuse_stats[2]))
+    cached = fusion.__dict__.get("_shard16")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    feats = fusion.clip_feat[first:first + count]
+    if feats.dtype != dtype:
+        out = torch.empty(feats.shape, dtype=dtype, device=feats.device)
+        step = max(1, (1 << 26) // max(1, feats.shape[1]))  # in pieces: no second full-size temporary
+        for s0 in range(0, feats.shape[0], step):
+            out[s0:s0 + step].copy_(feats[s0:s0 + step])
+        feats = out
+    fusion.__dict__["_shard16"] = (key, feats)
+    return feats
+
+
+def query_sharded(fusion, text, epilogue="row_argmax", group=None, gather=True, dtype=torch.float16, scan_fn=None, **kw):
+    """BASELINE config 5: many text queries over the merged volume, voxel-sharded over the ranks.
+
+    After ``merge_volumes(..., gather=False)`` rank k holds the means of voxel range k (its ``_shard_range``); a
+    volume that is whole on every rank is split by ``voxel_shard``.  Each rank scans ONLY its range with
+    ``query_scan_wide`` (no data-path collective: the volume never moves) and the small results are combined:
+
+    * ``"query_max"``   -> (value [Q], voxel [Q]) identical on every rank: an all-gather of Q (score, voxel) pairs and a
+      max -- equal scores resolve to the smaller voxel index, as a single-rank scan would;
+    * ``"row_argmax"``  -> (index, value) of this rank's voxel range, or of all N voxels when ``gather`` (all-gather of
+      4 + 4 bytes per voxel);
+    * ``"scores"`` / ``"vs_background"`` -> this rank's [count, Q] block (33 GB in all at config 5: it stays sharded).
+
+    ``scan_fn(feats, text, epilogue, row_offset=..., **kw)`` defaults to the HIP scan; the CPU tests inject an
+    oracle-backed one to exercise the sharding and the reductions under gloo."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = fusion.tsdf.numel()
+    rng = getattr(fusion, "_shard_range", None)
+    first, count = rng if rng is not None else voxel_shard(n, rank, world)
+    if scan_fn is None:
+        from .clipfusion import query_scan_wide
+
+        scan_fn = query_scan_wide
+        feats = shard_features_16(fusion, first, count, dtype)
+    else:
+        feats = fusion.clip_feat[first:first + count]
+    res = scan_fn(feats, text, epilogue, row_offset=first, **kw)
+    if world == 1:
+        return res
+    if epilogue == "query_max":
+        val, row = res
+        vals = [torch.empty_like(val) for _ in range(world)]
+        rows = [torch.empty_like(row) for _ in range(world)]
+        dist.all_gather(vals, val.contiguous(), group=group)
+        dist.all_gather(rows, row.contiguous(), group=group)
+        vals, rows = torch.stack(vals), torch.stack(rows)
+        best = vals.max(dim=0).values
+        # among the ranks that reach the maximum, the smallest voxel index (ranks own ascending ranges)
+        big = torch.iinfo(torch.int64).max
+        cand = torch.where((vals == best[None]) & (rows >= 0), rows, torch.full_like(rows, big))
+        pick = cand.min(dim=0).values
+        return best, torch.where(pick == big, torch.full_like(pick, -1), pick)
+    if epilogue == "row_argmax" and gather:
+        idx, val = res
+        counts = [voxel_shard(n, k, world)[1] for k in range(world)] if rng is None else None
+        if counts is None:  # ranges came from the merge: exchange their sizes
+            c = torch.tensor([count], dtype=torch.int64, device=idx.device)
+            cs = [torch.empty_like(c) for _ in range(world)]
+            dist.all_gather(cs, c, group=group)
+            counts = [int(x) for x in cs]
+        pad = max(counts)
+        out = []
+        for t in (idx, val):
+            mine = torch.zeros(pad, dtype=t.dtype, device=t.device)
+            mine[:count] = t
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            out.append(torch.cat([p[:c] for p, c in zip(parts, counts)]))
+        return tuple(out)
+    return res

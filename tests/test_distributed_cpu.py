@@ -114,3 +114,55 @@ def test_two_rank_merge_equals_single_process(tmp_path, oracle, mode):
     expect = world if mode == "all_reduce" else 1
     assert (covered == expect).all(), "every voxel must be finalised by exactly the ranks that own it"
     assert int(ref.weight.sum()) > 0
+
+
+# ---- BASELINE config 5: the voxel-sharded query scan (sharding + reductions; the scan itself is injected) ----
+Q_TEXT = 21
+
+
+def _query_worker(rank, world, port, out_dir, from_merge):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+
+        grid = syn.make_grid(NVOX, side=1.2)
+        frames, _ = _frames()
+        vol = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM)
+        _fuse(vol, frames, seem=False)
+        vol._shard_range = sdist.voxel_shard(vol.n, rank, world) if from_merge else None
+        text = torch.randn(Q_TEXT, DIM, generator=torch.Generator().manual_seed(5))
+        text[3] = text[11]  # two queries with identical scores everywhere
+        res = {}
+        for epi, kw in (("query_max", {}), ("row_argmax", {}), ("vs_background", {"n_background": 4, "scale": 100.0})):
+            out = sdist.query_sharded(vol, text, epi, scan_fn=O.wide_scan, **kw)
+            out = out if isinstance(out, tuple) else (out,)
+            for i, t in enumerate(out):
+                res[f"{epi}_{i}"] = t.numpy()
+        np.savez(os.path.join(out_dir, f"q{rank}.npz"), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("from_merge", [False, True])
+def test_two_rank_sharded_query_equals_single_process(tmp_path, oracle, from_merge):
+    world = 2
+    mp.spawn(_query_worker, args=(world, _free_port(), str(tmp_path), from_merge), nprocs=world, join=True)
+    grid = syn.make_grid(NVOX, side=1.2)
+    frames, _ = _frames()
+    ref = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM)
+    _fuse(ref, frames, seem=False)
+    text = torch.randn(Q_TEXT, DIM, generator=torch.Generator().manual_seed(5))
+    text[3] = text[11]
+    qv, qr = oracle.wide_scan(ref.clip_feat, text, "query_max")
+    ri, rv = oracle.wide_scan(ref.clip_feat, text, "row_argmax")
+    vb = oracle.wide_scan(ref.clip_feat, text, "vs_background", n_background=4, scale=100.0)
+    assert int((ref.weight > 0).sum()) > 20
+    for r in range(world):
+        g = np.load(os.path.join(tmp_path, f"q{r}.npz"))
+        # every rank ends with the same per-query answer as one scan over the whole volume (ties -> smaller voxel)
+        assert np.array_equal(g["query_max_0"], qv.numpy()) and np.array_equal(g["query_max_1"], qr.numpy())
+        assert np.array_equal(g["row_argmax_0"], ri.numpy()) and np.array_equal(g["row_argmax_1"], rv.numpy())
+        first, count = sdist.voxel_shard(ref.n, r, world)
+        np.testing.assert_allclose(g["vs_background_0"], vb.numpy()[first:first + count], rtol=1e-6, atol=1e-7)
