@@ -605,9 +605,11 @@ def bench_query(a, world, rank, local_rank):
                              "hbm_GBps_of_algorithmic_bytes": round((n * d * 2 + out_bytes) / kern / 1e9, 1)}}
 
     keep = {}
+    qs = (q + 7) // 8 * 8
+    big = torch.empty((n, qs), dtype=torch.float16, device=device)[:, :q]  # the N x Q output, allocated once
 
     def heat_maps():
-        keep["hm"] = query_scan_wide(feats16, text, "vs_background", scale=100.0, n_background=n_bg, rescale=True)
+        query_scan_wide(feats16, text, "vs_background", scale=100.0, n_background=n_bg, rescale=True, out=big)
 
     def query_max():
         val, row = query_scan_wide(feats16, text[n_bg:], "query_max", row_offset=first)
@@ -624,15 +626,13 @@ def bench_query(a, world, rank, local_rank):
     head = mfma_case("query_mesh path: softmax([4 backgrounds, target])[-1] heat maps for every target, fp16 out",
                      heat_maps, q + n_bg, n * q * 2, a.steps, a.warmup)
     cases.append(head)
-    del keep["hm"]
-    torch.cuda.empty_cache()
     cases.append(mfma_case("per-voxel best query (row_argmax), no N x Q output",
                            lambda: query_scan_wide(feats16, text[n_bg:], "row_argmax"), q, n * 8, a.steps, 1))
     cases.append(mfma_case("per-query best voxel (query_max), no N x Q output", query_max, q, q * 12, a.steps, 1))
-    cases.append(mfma_case("raw scores, fp16 out",
-                           lambda: keep.__setitem__("sc", query_scan_wide(feats16, text[n_bg:], "scores")), q, n * q * 2,
-                           a.steps, 1))
+    cases.append(mfma_case("raw scores, fp16 out", lambda: query_scan_wide(feats16, text[n_bg:], "scores", out=big), q,
+                           n * q * 2, a.steps, 1))
     keep.clear()
+    del big
     torch.cuda.empty_cache()
     # the reference's own scans over the fp32 volume (single GPU only: they are HBM-bound and tiny next to the above)
     if world == 1 and not a.query_wide_only:

@@ -433,7 +433,7 @@ _WIDE_EPILOGUES = {"scores": _abi.SAF_QW_SCORES, "vs_background": _abi.SAF_QW_VS
 
 
 def query_scan_wide(feats, text, epilogue="scores", scale=1.0, normalize=True, n_background=0, rescale=False,
-                    out_dtype=None, row_offset=0):
+                    out_dtype=None, row_offset=0, out=None):
     """Many text queries over a 16-bit feature volume on the 16-bit matrix cores (BASELINE config 5: the
     query_mesh.py / hypersim_eval.py scan with ~1000 targets), with the callers' reductions fused into the scan
     (saf_query_scan_wide_ex) so that the N x Q score matrix -- twice the size of the volume -- need not exist.
@@ -448,6 +448,9 @@ def query_scan_wide(feats, text, epilogue="scores", scale=1.0, normalize=True, n
     * ``"row_argmax"``     -> (index int32 [N], value f32 [N]): best query per row
       (eval_scannet_segmentation.py:553-560, the first label of the argsort)
     * ``"query_max"``      -> (value f32 [Q], row int64 [Q]): best row per query, rows numbered from ``row_offset``
+
+    ``out``: an optional preallocated [N, columns] tensor for the two matrix-valued epilogues (row stride a multiple
+    of 8 elements keeps the 16-byte stores of the epilogue aligned).
     """
     require_cuda(feats, "features")
     if feats.dtype not in (torch.float16, torch.bfloat16) or feats.dim() != 2:
@@ -476,16 +479,24 @@ def query_scan_wide(feats, text, epilogue="scores", scale=1.0, normalize=True, n
                                        ws.data_ptr(), wsb, current_stream_ptr())
         check(rc, "saf_query_scan_wide")
         return out
-    out = idx = val = row = None
+    idx = val = row = None
     if epi in (_abi.SAF_QW_SCORES, _abi.SAF_QW_VS_BACKGROUND):
         cols = q - (int(n_background) if epi == _abi.SAF_QW_VS_BACKGROUND else 0)
-        # rows padded to a multiple of 8 columns keep every 16-byte store of the epilogue aligned
-        stride = (cols + 7) // 8 * 8
-        out = torch.empty((n, stride), dtype=out_dtype, device=dev)[:, :cols]
+        if out is None:
+            # rows padded to a multiple of 8 columns keep every 16-byte store of the epilogue aligned
+            stride = (cols + 7) // 8 * 8
+            out = torch.empty((n, stride), dtype=out_dtype, device=dev)[:, :cols]
+        else:
+            require_cuda(out, "out")
+            if tuple(out.shape) != (n, cols) or out.stride(1) != 1:
+                raise ValueError(f"out must be [{n}, {cols}] with unit column stride")
+            out_dtype = out.dtype
     elif epi == _abi.SAF_QW_ROW_ARGMAX:
+        out = None
         idx = torch.empty(n, dtype=torch.int32, device=dev)
         val = torch.empty(n, dtype=torch.float32, device=dev)
     else:
+        out = None
         val = torch.empty(q, dtype=torch.float32, device=dev)
         row = torch.empty(q, dtype=torch.int64, device=dev)
     wsb = L.saf_query_wide_ex_workspace_bytes(q, d, epi, int(n_background))

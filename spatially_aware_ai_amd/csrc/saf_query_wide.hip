@@ -278,6 +278,163 @@ struct Wide2Args {
   int64_t row_offset;
 };
 
+// What the epilogue of a tile needs to know about the tile (it runs one step later, beside the next tile's MFMAs,
+// possibly after the workgroup has moved on to its next row block).
+struct W2Tile {
+  float inv0, inv1;     // scale / row norm of the lane's two feature rows
+  int64_t row_a, row_b; // their true indices (may be >= n_rows on the last block)
+  int qt;               // query tile
+};
+// per-row-block epilogue state (ROW_ARGMAX: running best; VS_BACKGROUND: log-sum-exp of the backgrounds)
+struct W2State {
+  float best_v0, best_v1, lse0, lse1;
+  int best_q0, best_q1;
+};
+
+template <int OT, int EPI>
+__device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t& c0, const f32x16_t& c1, const W2Tile& t,
+                                            W2State& st, int r, int h, int n_qt, bool vec_ok) {
+  // lane (r, h): feature rows row_a (c0) / row_b (c1); register 4 g + i holds query qt*32 + 8 g + 4 h + i
+  const int qbase = t.qt * kWTile + 4 * h;
+  if (EPI == SAF_QW_SCORES || EPI == SAF_QW_VS_BACKGROUND) {
+    float v0[16], v1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v0[i] = c0[i] * t.inv0; v1[i] = c1[i] * t.inv1; }
+    int col0 = qbase;  // output column of register 0
+    bool write = true;
+    if (EPI == SAF_QW_VS_BACKGROUND) {
+      if (t.qt == 0) {  // tile 0 holds the backgrounds: per-row log-sum-exp of their scaled scores, no output
+        float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool bg = 8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg;
+          m0 = bg ? fmaxf(m0, v0[i]) : m0;
+          m1 = bg ? fmaxf(m1, v1[i]) : m1;
+        }
+        m0 = fmaxf(m0, __shfl_xor(m0, 32));
+        m1 = fmaxf(m1, __shfl_xor(m1, 32));
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool bg = 8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg;
+          e0 += bg ? __expf(v0[i] - m0) : 0.f;
+          e1 += bg ? __expf(v1[i] - m1) : 0.f;
+        }
+        e0 += __shfl_xor(e0, 32);
+        e1 += __shfl_xor(e1, 32);
+        st.lse0 = m0 + __logf(e0);
+        st.lse1 = m1 + __logf(e1);
+        write = false;
+      } else {
+        // softmax([bg..., target])[-1] = 1 / (1 + exp(lse_bg - z_target))
+        const bool rescale = (wa.flags & 1) != 0;  // query_mesh.py:39: ((r - 0.5) * 2).clamp(0, 1)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p0 = __builtin_amdgcn_rcpf(1.0f + __expf(st.lse0 - v0[i])), p1 = __builtin_amdgcn_rcpf(1.0f + __expf(st.lse1 - v1[i]));
+          if (rescale) {
+            p0 = fminf(fmaxf((p0 - 0.5f) * 2.0f, 0.0f), 1.0f);
+            p1 = fminf(fmaxf((p1 - 0.5f) * 2.0f, 0.0f), 1.0f);
+          }
+          v0[i] = p0; v1[i] = p1;
+        }
+        col0 = qbase - kWTile;
+      }
+    }
+    if (write) {
+      const int ncols = EPI == SAF_QW_VS_BACKGROUND ? wa.Q - kWTile : wa.Q;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float* v = f ? v1 : v0;
+        const int64_t row = f ? t.row_b : t.row_a;
+        if (OT == SAF_F32) {
+          if (row < wa.n_rows) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int q0 = col0 + 8 * g;
+              float* o = static_cast<float*>(wa.out) + row * wa.ostride + q0;
+              if (vec_ok && q0 + 3 < ncols) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+              } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (q0 + i < ncols) o[i] = v[4 * g + i];
+              }
+            }
+          }
+        } else {
+          // pairs of groups (g, g + 1): after the half-wave exchange lanes 0-31 hold columns 16 gp .. + 7 and
+          // lanes 32-63 columns 16 gp + 8 .. + 15 of their row: one 16-byte store each
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            uint2 lo = pack4_16<OT>(v[8 * gp], v[8 * gp + 1], v[8 * gp + 2], v[8 * gp + 3]);       // group 2 gp
+            uint2 hi = pack4_16<OT>(v[8 * gp + 4], v[8 * gp + 5], v[8 * gp + 6], v[8 * gp + 7]);   // group 2 gp + 1
+            auto rx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+            auto ry = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+            // lanes 0-31: [own group 2gp | upper half's group 2gp]; lanes 32-63: [lower half's group 2gp+1 | own]
+            const uint4 w = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            const int qv = (col0 - 4 * h) + 16 * gp + 8 * h;  // first of this lane's 8 columns
+            if (row < wa.n_rows) {
+              uint16_t* o = static_cast<uint16_t*>(wa.out) + row * wa.ostride + qv;
+              if (vec_ok && qv + 7 < ncols) {
+                *reinterpret_cast<uint4*>(o) = w;
+              } else {
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                  if (qv + i < ncols) o[i] = (uint16_t)(ww[i >> 1] >> (16 * (i & 1)));
+              }
+            }
+          }
+        }
+      }
+    }
+  } else if (EPI == SAF_QW_ROW_ARGMAX) {
+    if (t.qt == 0) {
+      st.best_v0 = st.best_v1 = -INFINITY;
+      st.best_q0 = st.best_q1 = 0;
+    }
+    const bool last = t.qt == n_qt - 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = qbase + 8 * (i >> 2) + (i & 3);
+      float x0 = c0[i] * t.inv0, x1 = c1[i] * t.inv1;
+      if (last && q >= wa.Q) { x0 = -INFINITY; x1 = -INFINITY; }  // zero-padded text rows are no candidates
+      if (x0 > st.best_v0) { st.best_v0 = x0; st.best_q0 = q; }  // queries ascend: the first maximum stays
+      if (x1 > st.best_v1) { st.best_v1 = x1; st.best_q1 = q; }
+    }
+    if (last) {
+      // both halves of a row: the larger score, the smaller query on ties
+      const float ov0 = __shfl_xor(st.best_v0, 32), ov1 = __shfl_xor(st.best_v1, 32);
+      const int oq0 = __shfl_xor(st.best_q0, 32), oq1 = __shfl_xor(st.best_q1, 32);
+      if (ov0 > st.best_v0 || (ov0 == st.best_v0 && oq0 < st.best_q0)) { st.best_v0 = ov0; st.best_q0 = oq0; }
+      if (ov1 > st.best_v1 || (ov1 == st.best_v1 && oq1 < st.best_q1)) { st.best_v1 = ov1; st.best_q1 = oq1; }
+      if (h == 0) {
+        if (t.row_a < wa.n_rows) { wa.out_index[t.row_a] = st.best_q0; wa.out_value[t.row_a] = st.best_v0; }
+        if (t.row_b < wa.n_rows) { wa.out_index[t.row_b] = st.best_q1; wa.out_value[t.row_b] = st.best_v1; }
+      }
+    }
+  } else {  // SAF_QW_QUERY_MAX: the best of the wave's 64 rows per query, one atomic per query and wave
+    const bool last = t.qt == n_qt - 1;
+    const bool ok_a = t.row_a < wa.n_rows, ok_b = t.row_b < wa.n_rows;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = qbase + 8 * (i >> 2) + (i & 3);
+      const float x0 = ok_a ? c0[i] * t.inv0 : -INFINITY, x1 = ok_b ? c1[i] * t.inv1 : -INFINITY;
+      float m = fmaxf(x0, x1);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));  // every lane of the half: the 64 rows' maximum
+      // the smallest row that reaches it: fragment a (rows row0 + r) before fragment b (rows row0 + 32 + r)
+      const unsigned long long ba = __ballot(x0 == m), bb = __ballot(x1 == m);
+      const uint32_t ha = (uint32_t)(ba >> (32 * h)), hb = (uint32_t)(bb >> (32 * h));
+      const uint32_t slot = ha ? (uint32_t)__ffs((int)ha) - 1u : 32u + (uint32_t)__ffs((int)hb) - 1u;
+      if (r == 0 && !(last && q >= wa.Q) && m > -INFINITY) {
+        const uint32_t row = (uint32_t)(t.row_a + wa.row_offset) + slot;  // row_a of lane r = 0 is the wave's first row
+        atomicMax(&wa.qkeys[q], ((unsigned long long)ordered_bits(m) << 32) | (uint32_t)~row);
+      }
+    }
+  }
+}
+
 template <int FT, int OT, int KS, int EPI>
 __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1))) void query_wide2_kernel(Wide2Args wa) {
   constexpr int D = KS * 16;
@@ -294,43 +451,33 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
   if (n_steps == 0) return;
   constexpr int PIECES = kWTile * (D / 8);
   constexpr int PPT = (PIECES + kW2Threads - 1) / kW2Threads;
-
-  auto issue_tile = [&](int qt, unsigned char* dst) {  // LDS-DMA form: lands later, covered by vmcnt before the barrier
-#pragma unroll
-    for (int k = 0; k < kWTile / kW2Waves; ++k) {
-      const int q = wave * (kWTile / kW2Waves) + k;
-      const uint16_t* src = wa.text16 + (int64_t)(qt * kWTile + q) * D + lane * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + q * ROWB), 16, 0, 0);
-    }
-  };
-  auto copy_tile = [&](int qt, unsigned char* dst) {  // register-staged form (narrower rows, and the very first tile)
-    for (int p = tid; p < PIECES; p += kW2Threads) {
-      const int q = p / (D / 8), c = p - q * (D / 8);
-      *reinterpret_cast<uint4*>(dst + q * ROWB + c * 16) =
-          *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)(qt * kWTile + q) * D + c * 8);
-    }
-  };
-
-  copy_tile(0, s_tiles);
-  __syncthreads();
-
-  uint4 a0[KS], a1[KS];
-  float inv0 = 0.f, inv1 = 0.f;
-  int64_t row_a = 0, row_b = 0;  // this lane's two feature rows (true indices, may be >= n_rows)
-  // per-row-block epilogue state
-  float best_v0 = -INFINITY, best_v1 = -INFINITY, lse0 = 0.f, lse1 = 0.f;
-  int best_q0 = 0, best_q1 = 0;
   const bool vec_ok = (wa.ostride % 8 == 0) && (((uintptr_t)wa.out & 15) == 0);
 
-  int64_t step = 0;
-  for (int64_t bi = 0; bi < my_blocks; ++bi) {
-    const int64_t blk = blockIdx.x + bi * gridDim.x;
-    const int64_t row0 = (blk * kW2Waves + wave) * kW2Rows;
-    row_a = row0 + r;
-    row_b = row0 + 32 + r;
-    {
-      const int64_t ra = row_a < wa.n_rows ? row_a : wa.n_rows - 1, rb = row_b < wa.n_rows ? row_b : wa.n_rows - 1;
+  for (int p = tid; p < PIECES; p += kW2Threads) {  // tile 0 of the first block
+    const int q = p / (D / 8), c = p - q * (D / 8);
+    *reinterpret_cast<uint4*>(s_tiles + q * ROWB + c * 16) = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)q * D + c * 8);
+  }
+
+  uint4 a0[KS], a1[KS];
+  W2Tile cur, prev;
+  W2State st;
+  st.best_v0 = st.best_v1 = -INFINITY; st.best_q0 = st.best_q1 = 0; st.lse0 = st.lse1 = 0.f;
+  cur.inv0 = cur.inv1 = 0.f; cur.row_a = cur.row_b = 0; cur.qt = 0;
+  prev = cur;
+  f32x16_t acc[2][2];  // [step parity][fragment]: the tile being accumulated and the previous one awaiting its epilogue
+
+  // One step = one (row block, query tile) pair.  In program order: barrier (tile in LDS) -> LDS-DMA of the next
+  // tile -> all of this tile's text fragments into registers -> the PREVIOUS tile's epilogue -> 64 MFMAs.  The
+  // epilogue's vector work and stores have no dependence on the MFMAs that follow them, so the scheduler may
+  // interleave the two; the fragments arrive while the epilogue runs.
+  auto step_body = [&](int64_t step, f32x16_t& c0, f32x16_t& c1, const f32x16_t& p0, const f32x16_t& p1) {
+    const int qt = (int)(step % n_qt);
+    if (qt == 0) {  // a new row block: its 64 rows per wave, register resident for every query tile
+      const int64_t blk = blockIdx.x + (step / n_qt) * gridDim.x;
+      const int64_t row0 = (blk * kW2Waves + wave) * kW2Rows;
+      cur.row_a = row0 + r;
+      cur.row_b = row0 + 32 + r;
+      const int64_t ra = cur.row_a < wa.n_rows ? cur.row_a : wa.n_rows - 1, rb = cur.row_b < wa.n_rows ? cur.row_b : wa.n_rows - 1;
       const uint16_t* pa = wa.feats + ra * wa.fstride + 8 * h;
       const uint16_t* pb = wa.feats + rb * wa.fstride + 8 * h;
 #pragma unroll
@@ -338,217 +485,99 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         a0[s] = ld_stream_u4(pa + 16 * s);
         a1[s] = ld_stream_u4(pb + 16 * s);
       }
-    }
-    inv0 = inv1 = wa.scale;
-    if (wa.normalize) {
-      float ss0 = 0.f, ss1 = 0.f;
+      cur.inv0 = cur.inv1 = wa.scale;
+      if (wa.normalize) {
+        float ss0 = 0.f, ss1 = 0.f;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const uint32_t w0[4] = {a0[s].x, a0[s].y, a0[s].z, a0[s].w};
-        const uint32_t w1[4] = {a1[s].x, a1[s].y, a1[s].z, a1[s].w};
+        for (int s = 0; s < KS; ++s) {
+          const uint32_t w0[4] = {a0[s].x, a0[s].y, a0[s].z, a0[s].w};
+          const uint32_t w1[4] = {a1[s].x, a1[s].y, a1[s].z, a1[s].w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float lo = elem16_to_f32<FT>((uint16_t)(w0[j] & 0xffffu)), hi = elem16_to_f32<FT>((uint16_t)(w0[j] >> 16));
-          ss0 = __builtin_fmaf(lo, lo, ss0);
-          ss0 = __builtin_fmaf(hi, hi, ss0);
-          lo = elem16_to_f32<FT>((uint16_t)(w1[j] & 0xffffu)); hi = elem16_to_f32<FT>((uint16_t)(w1[j] >> 16));
-          ss1 = __builtin_fmaf(lo, lo, ss1);
-          ss1 = __builtin_fmaf(hi, hi, ss1);
-        }
-      }
-      ss0 += __shfl_xor(ss0, 32);
-      ss1 += __shfl_xor(ss1, 32);
-      if (wa.normalize == SAF_NORM_L2_CLAMP) {
-        inv0 = wa.scale / fmaxf(sqrtf(ss0), 0.1f);
-        inv1 = wa.scale / fmaxf(sqrtf(ss1), 0.1f);
-      } else {  // SAF_NORM_L2 with nan_to_num: an all-zero row scores 0
-        inv0 = ss0 > 0.0f ? wa.scale / sqrtf(ss0) : 0.0f;
-        inv1 = ss1 > 0.0f ? wa.scale / sqrtf(ss1) : 0.0f;
-      }
-    }
-    best_v0 = best_v1 = -INFINITY;
-    best_q0 = best_q1 = 0;
-
-    for (int qt = 0; qt < n_qt; ++qt, ++step) {
-      const unsigned char* cur = s_tiles + (size_t)(step & 1) * kWTile * ROWB;
-      unsigned char* nxt = s_tiles + (size_t)((step + 1) & 1) * kWTile * ROWB;
-      const bool more = step + 1 < n_steps;
-      const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
-      uint4 stage[kDma ? 1 : PPT];
-      if (more) {
-        if (kDma) {
-          issue_tile(qt_next, nxt);
-        } else {
-#pragma unroll
-          for (int k = 0; k < PPT; ++k) {
-            const int p = tid + k * kW2Threads;
-            if (p < PIECES) {
-              const int q = p / (D / 8), c = p - q * (D / 8);
-              stage[k] = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)(qt_next * kWTile + q) * D + c * 8);
-            }
+          for (int j = 0; j < 4; ++j) {
+            float lo = elem16_to_f32<FT>((uint16_t)(w0[j] & 0xffffu)), hi = elem16_to_f32<FT>((uint16_t)(w0[j] >> 16));
+            ss0 = __builtin_fmaf(lo, lo, ss0);
+            ss0 = __builtin_fmaf(hi, hi, ss0);
+            lo = elem16_to_f32<FT>((uint16_t)(w1[j] & 0xffffu)); hi = elem16_to_f32<FT>((uint16_t)(w1[j] >> 16));
+            ss1 = __builtin_fmaf(lo, lo, ss1);
+            ss1 = __builtin_fmaf(hi, hi, ss1);
           }
         }
+        ss0 += __shfl_xor(ss0, 32);
+        ss1 += __shfl_xor(ss1, 32);
+        if (wa.normalize == SAF_NORM_L2_CLAMP) {
+          cur.inv0 = wa.scale / fmaxf(sqrtf(ss0), 0.1f);
+          cur.inv1 = wa.scale / fmaxf(sqrtf(ss1), 0.1f);
+        } else {  // SAF_NORM_L2 with nan_to_num: an all-zero row scores 0
+          cur.inv0 = ss0 > 0.0f ? wa.scale / sqrtf(ss0) : 0.0f;
+          cur.inv1 = ss1 > 0.0f ? wa.scale / sqrtf(ss1) : 0.0f;
+        }
       }
-      f32x16_t c0, c1;
+    }
+    cur.qt = qt;
+    const unsigned char* curb = s_tiles + (size_t)(step & 1) * kWTile * ROWB;
+    unsigned char* nxt = s_tiles + (size_t)((step + 1) & 1) * kWTile * ROWB;
+    // this tile's text is in LDS (its DMA / copy was issued a step ago) and every wave is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool more = step + 1 < n_steps;
+    const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
+    uint4 stage[kDma ? 1 : PPT];
+    if (more) {
+      if (kDma) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
-      const unsigned char* trow = cur + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const uint4 t = *reinterpret_cast<const uint4*>(trow + 32 * s);
-        c0 = mfma16<FT>(t, a0[s], c0);  // C[query][feature row]
-        c1 = mfma16<FT>(t, a1[s], c1);
-      }
-      if (more && !kDma) {
+        for (int k = 0; k < kWTile / kW2Waves; ++k) {
+          const int q = wave * (kWTile / kW2Waves) + k;
+          const uint16_t* src = wa.text16 + (int64_t)(qt_next * kWTile + q) * D + lane * 8;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(nxt + q * ROWB), 16, 0, 0);
+        }
+      } else {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
           const int p = tid + k * kW2Threads;
           if (p < PIECES) {
             const int q = p / (D / 8), c = p - q * (D / 8);
-            *reinterpret_cast<uint4*>(nxt + q * ROWB + c * 16) = stage[k];
+            stage[k] = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)(qt_next * kWTile + q) * D + c * 8);
           }
         }
       }
-      // the barrier before this tile's epilogue: what it waits for is the next tile's LDS-DMA (issued a whole MFMA
-      // phase ago) and the previous tile's output stores
-      if (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+    }
+    // every text fragment of the tile into registers: the reads stream while the previous tile's epilogue runs
+    uint4 t[KS];
+    const unsigned char* trow = curb + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h
+#pragma unroll
+    for (int s = 0; s < KS; ++s) t[s] = *reinterpret_cast<const uint4*>(trow + 32 * s);
+    if (step > 0) w2_epilogue<OT, EPI>(wa, p0, p1, prev, st, r, h, n_qt, vec_ok);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      c0 = mfma16<FT>(t[s], a0[s], c0);  // C[query][feature row]
+      c1 = mfma16<FT>(t[s], a1[s], c1);
+    }
+    if (more && !kDma) {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int p = tid + k * kW2Threads;
+        if (p < PIECES) {
+          const int q = p / (D / 8), c = p - q * (D / 8);
+          *reinterpret_cast<uint4*>(nxt + q * ROWB + c * 16) = stage[k];
+        }
+      }
+    }
+    prev = cur;
+  };
 
-      // ---------------- epilogue of tile qt on the accumulator layout ----------------
-      // lane (r, h): feature rows row_a (c0) / row_b (c1); register 4 g + i holds query qt*32 + 8 g + 4 h + i
-      const int qbase = qt * kWTile + 4 * h;
-      if (EPI == SAF_QW_SCORES || EPI == SAF_QW_VS_BACKGROUND) {
-        float v0[16], v1[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { v0[i] = c0[i] * inv0; v1[i] = c1[i] * inv1; }
-        int col0 = qbase;  // output column of register 0
-        bool write = true;
-        if (EPI == SAF_QW_VS_BACKGROUND) {
-          if (qt == 0) {  // tile 0 holds the backgrounds: per-row log-sum-exp of their scaled scores, no output
-            float m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const bool bg = 8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg;
-              m0 = bg ? fmaxf(m0, v0[i]) : m0;
-              m1 = bg ? fmaxf(m1, v1[i]) : m1;
-            }
-            m0 = fmaxf(m0, __shfl_xor(m0, 32));
-            m1 = fmaxf(m1, __shfl_xor(m1, 32));
-            float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const bool bg = 8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg;
-              e0 += bg ? __expf(v0[i] - m0) : 0.f;
-              e1 += bg ? __expf(v1[i] - m1) : 0.f;
-            }
-            e0 += __shfl_xor(e0, 32);
-            e1 += __shfl_xor(e1, 32);
-            lse0 = m0 + __logf(e0);
-            lse1 = m1 + __logf(e1);
-            write = false;
-          } else {
-            // softmax([bg..., target])[-1] = 1 / (1 + exp(lse_bg - z_target))
-            const bool rescale = (wa.flags & 1) != 0;  // query_mesh.py:39: ((r - 0.5) * 2).clamp(0, 1)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              float p0 = __builtin_amdgcn_rcpf(1.0f + __expf(lse0 - v0[i])), p1 = __builtin_amdgcn_rcpf(1.0f + __expf(lse1 - v1[i]));
-              if (rescale) {
-                p0 = fminf(fmaxf((p0 - 0.5f) * 2.0f, 0.0f), 1.0f);
-                p1 = fminf(fmaxf((p1 - 0.5f) * 2.0f, 0.0f), 1.0f);
-              }
-              v0[i] = p0; v1[i] = p1;
-            }
-            col0 = qbase - kWTile;
-          }
-        }
-        if (write) {
-          const int ncols = EPI == SAF_QW_VS_BACKGROUND ? wa.Q - kWTile : wa.Q;
-#pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            const float* v = f ? v1 : v0;
-            const int64_t row = f ? row_b : row_a;
-            if (OT == SAF_F32) {
-              if (row < wa.n_rows) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  const int q0 = col0 + 8 * g;
-                  float* o = static_cast<float*>(wa.out) + row * wa.ostride + q0;
-                  if (vec_ok && q0 + 3 < ncols) {
-                    *reinterpret_cast<float4*>(o) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-                  } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                      if (q0 + i < ncols) o[i] = v[4 * g + i];
-                  }
-                }
-              }
-            } else {
-              // pairs of groups (g, g + 1): after the half-wave exchange lanes 0-31 hold columns 16 gp .. + 7 and
-              // lanes 32-63 columns 16 gp + 8 .. + 15 of their row: one 16-byte store each
-#pragma unroll
-              for (int gp = 0; gp < 2; ++gp) {
-                uint2 lo = pack4_16<OT>(v[8 * gp], v[8 * gp + 1], v[8 * gp + 2], v[8 * gp + 3]);       // group 2 gp
-                uint2 hi = pack4_16<OT>(v[8 * gp + 4], v[8 * gp + 5], v[8 * gp + 6], v[8 * gp + 7]);   // group 2 gp + 1
-                auto rx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
-                auto ry = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
-                // lanes 0-31: [own group 2gp | upper half's group 2gp]; lanes 32-63: [lower half's group 2gp+1 | own]
-                const uint4 w = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-                const int qv = (col0 - 4 * h) + 16 * gp + 8 * h;  // first of this lane's 8 columns
-                if (row < wa.n_rows) {
-                  uint16_t* o = static_cast<uint16_t*>(wa.out) + row * wa.ostride + qv;
-                  if (vec_ok && qv + 7 < ncols) {
-                    *reinterpret_cast<uint4*>(o) = w;
-                  } else {
-                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                      if (qv + i < ncols) o[i] = (uint16_t)(ww[i >> 1] >> (16 * (i & 1)));
-                  }
-                }
-              }
-            }
-          }
-        }
-      } else if (EPI == SAF_QW_ROW_ARGMAX) {
-        const bool last = qt == n_qt - 1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int q = qbase + 8 * (i >> 2) + (i & 3);
-          float x0 = c0[i] * inv0, x1 = c1[i] * inv1;
-          if (last && q >= wa.Q) { x0 = -INFINITY; x1 = -INFINITY; }  // zero-padded text rows are no candidates
-          if (x0 > best_v0) { best_v0 = x0; best_q0 = q; }  // queries ascend: the first maximum stays
-          if (x1 > best_v1) { best_v1 = x1; best_q1 = q; }
-        }
-      } else {  // SAF_QW_QUERY_MAX: best row per query -- reduce over the wave's 64 rows, one atomic per query
-        const bool last = qt == n_qt - 1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int q = qbase + 8 * (i >> 2) + (i & 3);
-          const float x0 = row_a < wa.n_rows ? c0[i] * inv0 : -INFINITY, x1 = row_b < wa.n_rows ? c1[i] * inv1 : -INFINITY;
-          // key: ordered score in the high word, ~row in the low word (equal scores: the smaller row wins)
-          const unsigned long long k0 = ((unsigned long long)ordered_bits(x0) << 32) | (uint32_t)~(uint32_t)(row_a + wa.row_offset);
-          const unsigned long long k1 = ((unsigned long long)ordered_bits(x1) << 32) | (uint32_t)~(uint32_t)(row_b + wa.row_offset);
-          unsigned long long k = k0 > k1 ? k0 : k1;
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            const unsigned long long t = __shfl_xor(k, o);
-            k = t > k ? t : k;
-          }
-          if (r == 0 && !(last && q >= wa.Q)) atomicMax(&wa.qkeys[q], k);
-        }
-      }
-    }
-    if (EPI == SAF_QW_ROW_ARGMAX) {
-      // both halves of a row: the larger score, the smaller query on ties
-      const float ov0 = __shfl_xor(best_v0, 32), ov1 = __shfl_xor(best_v1, 32);
-      const int oq0 = __shfl_xor(best_q0, 32), oq1 = __shfl_xor(best_q1, 32);
-      if (ov0 > best_v0 || (ov0 == best_v0 && oq0 < best_q0)) { best_v0 = ov0; best_q0 = oq0; }
-      if (ov1 > best_v1 || (ov1 == best_v1 && oq1 < best_q1)) { best_v1 = ov1; best_q1 = oq1; }
-      if (h == 0) {
-        if (row_a < wa.n_rows) { wa.out_index[row_a] = best_q0; wa.out_value[row_a] = best_v0; }
-        if (row_b < wa.n_rows) { wa.out_index[row_b] = best_q1; wa.out_value[row_b] = best_v1; }
-      }
-    }
+  int64_t step = 0;
+  for (; step + 1 < n_steps; step += 2) {
+    step_body(step, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+    step_body(step + 1, acc[1][0], acc[1][1], acc[0][0], acc[0][1]);
+  }
+  if (step < n_steps) {
+    step_body(step, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+    w2_epilogue<OT, EPI>(wa, acc[0][0], acc[0][1], prev, st, r, h, n_qt, vec_ok);
+  } else {
+    w2_epilogue<OT, EPI>(wa, acc[1][0], acc[1][1], prev, st, r, h, n_qt, vec_ok);
   }
 }
 
@@ -729,24 +758,24 @@ int saf_query_scan_wide_ex(const void* feats, int32_t feat_dtype, int64_t n_rows
     return fail(SAF_E_UNSUPPORTED, "wide scan: features must be SAF_F16 or SAF_BF16");
   if (feat_dim != 256 && feat_dim != 512)
     return fail(SAF_E_UNSUPPORTED, "wide scan (fused epilogues): feat_dim must be 256 or 512 (got %d)", feat_dim);
-  if (!feats || !text || n_rows < 0 || n_text <= 0 || feat_stride < feat_dim || text_stride < feat_dim)
+  if ((!feats && n_rows > 0) || !text || n_rows < 0 || n_text <= 0 || feat_stride < feat_dim || text_stride < feat_dim)
     return fail(SAF_E_INVALID, "wide scan: bad arguments");
   if (((uintptr_t)feats & 15) || (feat_stride % 8) != 0) return fail(SAF_E_INVALID, "wide scan: feature rows must be 16-byte aligned");
   int n_bg = 0, n_out_cols = n_text;
   switch (epilogue) {
     case SAF_QW_SCORES:
-      if (!out || out_stride < n_text) return fail(SAF_E_INVALID, "wide scan: SCORES needs out [n_rows, >= n_text]");
+      if ((!out && n_rows > 0) || out_stride < n_text) return fail(SAF_E_INVALID, "wide scan: SCORES needs out [n_rows, >= n_text]");
       break;
     case SAF_QW_VS_BACKGROUND:
       n_bg = n_background;
       n_out_cols = n_text - n_bg;
       if (n_bg < 1 || n_bg > kWTile || n_out_cols < 1)
         return fail(SAF_E_INVALID, "wide scan: VS_BACKGROUND needs 1..32 background rows followed by at least one target");
-      if (!out || out_stride < n_out_cols) return fail(SAF_E_INVALID, "wide scan: VS_BACKGROUND needs out [n_rows, >= n_text - n_background]");
+      if ((!out && n_rows > 0) || out_stride < n_out_cols) return fail(SAF_E_INVALID, "wide scan: VS_BACKGROUND needs out [n_rows, >= n_text - n_background]");
       if (!(scale > 0.0f)) return fail(SAF_E_INVALID, "wide scan: VS_BACKGROUND needs a positive scale");
       break;
     case SAF_QW_ROW_ARGMAX:
-      if (!out_index || !out_value) return fail(SAF_E_INVALID, "wide scan: ROW_ARGMAX needs out_index and out_value [n_rows]");
+      if ((!out_index || !out_value) && n_rows > 0) return fail(SAF_E_INVALID, "wide scan: ROW_ARGMAX needs out_index and out_value [n_rows]");
       break;
     case SAF_QW_QUERY_MAX:
       if (!out_value || !out_row) return fail(SAF_E_INVALID, "wide scan: QUERY_MAX needs out_value and out_row [n_text]");
