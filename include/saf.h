@@ -268,6 +268,39 @@ int saf_sample_vertices(const saf_volume* vol, const float* verts_index, int64_t
                         float* out_rgb, const int32_t* obj_idx, float* out_obj, const float* seg_color,
                         float* out_seg, void* stream);
 
+/*
+ * The tiled CLIP front-end in one pass (Clip.img_inference_tiled before the ViT,
+ * clipfusion.py:808-823): normalize_img, Unfold into overlapping patch x patch tiles at `stride`, bilinear resize of
+ * every tile to out_size x out_size (align_corners = False).
+ *   rgb    [batch, 3, H, W] f32 in 0..1 addressed through element strides (channel-last frames as the loaders yield
+ *          them: stride_c = 1, stride_x = 3, stride_y = 3 W)
+ *   mean3 / std3  HOST pointers to the three channel means / standard deviations (clipfusion.py:774-779)
+ *   out    [batch * npy * npx, 3, out_size, out_size] of out_dtype, tile index (b * npy + py) * npx + px as
+ *          get_patches orders them (clipfusion.py:800-804)
+ */
+int saf_clip_tiles(const float* rgb, int32_t batch, int32_t height, int32_t width, int64_t stride_b, int64_t stride_c,
+                   int64_t stride_y, int64_t stride_x, int32_t patch, int32_t stride, int32_t out_size,
+                   const float* mean3, const float* std3, void* out, int32_t out_dtype, void* stream);
+
+/*
+ * Marching cubes on the TSDF, on the device: the mesh half of extract_mesh (clipfusion.py:723-739,
+ * clip_seem_fusion.py:824-842) -- un-fused voxels (weight == 0) act as the reference's NaN mask, faces with a vertex on
+ * an edge to an un-fused voxel are dropped, unused vertices never exist.  Two calls, because the sizes are results:
+ *   count: classifies every cube; counts[0] = vertices, counts[1] = faces (device i64[2]; read them back to allocate);
+ *   emit : verts [n_verts, 3] f32 in voxel-index coordinates (x, y, z) -- what skimage returns and the reference feeds
+ *          to grid_sample / scales by voxel_size -- ordered by (owner voxel in raster order, axis); faces [n_faces, 3]
+ *          i32 ordered by cube in raster order, normals toward positive tsdf.  Both calls take the same workspace
+ *          (saf_marching_cubes_workspace_bytes, 256-byte aligned), untouched in between.
+ * The triangulation of ambiguous cubes and the vertex order differ from scikit-image's Lewiner variant (not in the
+ * build image: parity with it is unpinned); the vertex SET is one vertex per level-crossing grid edge in both.
+ */
+size_t saf_marching_cubes_workspace_bytes(int64_t n_voxels);
+int saf_marching_cubes_count(const float* tsdf, const int32_t* weight, int32_t nx, int32_t ny, int32_t nz, float level,
+                             void* workspace, size_t workspace_bytes, int64_t* counts, void* stream);
+int saf_marching_cubes_emit(const float* tsdf, const int32_t* weight, int32_t nx, int32_t ny, int32_t nz, float level,
+                            void* workspace, size_t workspace_bytes, float* verts, int64_t verts_capacity,
+                            int32_t* faces, int64_t faces_capacity, void* stream);
+
 /* Per-voxel argmax of the label histogram with the all-zero row -> -1 rule
  * (clip_seem_fusion.py:315-325).  out[N] i32. */
 int saf_label_argmax(const int32_t* labels_one_hot, int64_t n_voxels, int32_t n_classes,

@@ -122,6 +122,15 @@ PROTOTYPES = {
     "saf_mean_to_sum": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_label_argmax": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, _fp]),
     "saf_sample_vertices": (C.c_int, [C.POINTER(SafVolume), _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "saf_clip_tiles": (
+        C.c_int,
+        [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+         C.POINTER(C.c_float), C.POINTER(C.c_float), _fp, C.c_int32, _fp],
+    ),
+    "saf_marching_cubes_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "saf_marching_cubes_count": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, _fp, C.c_size_t, _fp, _fp]),
+    "saf_marching_cubes_emit": (
+        C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, _fp, C.c_size_t, _fp, C.c_int64, _fp, C.c_int64, _fp]),
     "saf_label_components_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "saf_label_components": (
         C.c_int,

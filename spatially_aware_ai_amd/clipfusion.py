@@ -340,18 +340,14 @@ class _FusionVolumeMixin:
         return tuple(out)
 
     def _marching_cubes_vertices(self, marching_cubes=None):
-        """TSDF -> (verts in index space, faces) as the reference does on the CPU (clipfusion.py:724-739):
-        un-fused voxels become NaN, faces touching NaN vertices are dropped, vertices re-indexed."""
+        """TSDF -> (verts in index space, faces) (clipfusion.py:724-739): un-fused voxels act as NaN, faces touching
+        a NaN vertex are dropped, vertices re-indexed.  Default: on the device (saf_marching_cubes_*), nothing but the
+        mesh leaves it.  ``marching_cubes=`` takes a callable with scikit-image's signature (e.g.
+        ``skimage.measure.marching_cubes``) to run the reference's own CPU route instead."""
         if marching_cubes is None:
-            try:
-                import skimage.measure
-
-                marching_cubes = skimage.measure.marching_cubes
-            except ImportError as e:
-                raise ImportError(
-                    "extract_mesh needs scikit-image's marching_cubes (the reference's dependency) or a "
-                    "marching_cubes= callable with the same signature"
-                ) from e
+            nx, ny, nz = (int(v) for v in self.nvox)
+            verts, faces = marching_cubes_gpu(self.tsdf.view(nx, ny, nz), self.weight.view(nx, ny, nz), level=0.0)
+            return verts.cpu().numpy(), faces.cpu().numpy().astype(np.int64)
         tsdf = self.tsdf.masked_fill(self.weight == 0, torch.nan).cpu()
         verts, faces = marching_cubes(tsdf.view(*[int(v) for v in self.nvox]).numpy(), level=0)[:2]
         faces = faces[~np.isnan(verts[faces]).any(axis=(1, 2))]
@@ -364,8 +360,8 @@ class _FusionVolumeMixin:
         return verts * self.voxel_size + torch.as_tensor(self.origin).cpu().numpy()
 
     def extract_mesh(self, marching_cubes=None):
-        """Reference clipfusion.py:723-763: (verts_world, faces, vertex_colors, vertex_clip_feats).  Marching
-        cubes stays on the CPU as in the reference; the vertex sampling of the D-channel volume runs in HIP."""
+        """Reference clipfusion.py:723-763: (verts_world, faces, vertex_colors, vertex_clip_feats).  Marching cubes
+        and the vertex sampling of the D-channel volume both run in HIP; the volume never leaves the device."""
         verts, faces = self._marching_cubes_vertices(marching_cubes)
         colors, feats = self.sample_mesh_vertices(verts)[:2]
         return self._verts_world(verts), faces, colors, feats
@@ -426,6 +422,39 @@ def _query_scan(feats, text, epilogue, scale=1.0, normalize=False, last_only=Fal
 
 
 _DT = {torch.float32: _abi.SAF_F32, torch.bfloat16: _abi.SAF_BF16, torch.float16: _abi.SAF_F16}
+
+
+def marching_cubes_gpu(tsdf, weight, level=0.0):
+    """Marching cubes on the device (saf_marching_cubes_count / _emit): ``tsdf`` [nx,ny,nz] f32 and ``weight`` [nx,ny,nz]
+    i32 on the HIP device -> (verts [V,3] f32 in voxel-index coordinates, faces [F,3] i32), both on the device.
+    Voxels with weight 0 are the reference's NaN mask (clipfusion.py:724); faces with a vertex on an edge to such a
+    voxel do not exist, nor do unused vertices (clipfusion.py:730-739)."""
+    require_cuda(tsdf, "tsdf")
+    require_cuda(weight, "weight")
+    if tsdf.dim() != 3 or tuple(weight.shape) != tuple(tsdf.shape):
+        raise ValueError("tsdf and weight must be [nx,ny,nz]")
+    t = tsdf.float().contiguous()
+    w = weight.to(torch.int32).contiguous()
+    nx, ny, nz = (int(v) for v in t.shape)
+    dev = t.device
+    L = lib()
+    if min(nx, ny, nz) < 2:
+        return torch.zeros((0, 3), device=dev), torch.zeros((0, 3), dtype=torch.int32, device=dev)
+    wsb = L.saf_marching_cubes_workspace_bytes(nx * ny * nz)
+    if wsb == 0:
+        raise SafError("marching cubes: the grid is too large (2^31 voxels or more)")
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(L.saf_marching_cubes_count(t.data_ptr(), w.data_ptr(), nx, ny, nz, float(level), ws.data_ptr(), wsb,
+                                         counts.data_ptr(), current_stream_ptr()), "saf_marching_cubes_count")
+        nv, nf = (int(v) for v in counts.tolist())  # the sizes are results: one read-back
+        verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
+        check(L.saf_marching_cubes_emit(t.data_ptr(), w.data_ptr(), nx, ny, nz, float(level), ws.data_ptr(), wsb,
+                                        _abi.ptr(verts) if nv else None, nv, _abi.ptr(faces) if nf else None, nf,
+                                        current_stream_ptr()), "saf_marching_cubes_emit")
+    return verts, faces
 
 
 _WIDE_EPILOGUES = {"scores": _abi.SAF_QW_SCORES, "vs_background": _abi.SAF_QW_VS_BACKGROUND,
@@ -564,12 +593,39 @@ class Clip(torch.nn.Module):
         tiles = rgb_imgs.unfold(2, patch_size, patch_stride).unfold(3, patch_size, patch_stride)
         return tiles.permute(0, 2, 3, 1, 4, 5)
 
+    def tiles_224(self, rgb_imgs, patch_size, patch_stride, dtype=None):
+        """[B,3,H,W] in 0..1 -> the [B*npy*npx, 3, 224, 224] batch the ViT consumes (clipfusion.py:808-823: normalise,
+        unfold, resize).  On the HIP device one fused kernel (saf_clip_tiles) writes it once, in ``dtype`` (default:
+        the autocast dtype when autocast is on, else fp32); on the CPU the reference's three PyTorch steps."""
+        _, _, imheight, imwidth = rgb_imgs.shape
+        assert (imheight - patch_size) % patch_stride == 0
+        assert (imwidth - patch_size) % patch_stride == 0
+        if not rgb_imgs.is_cuda:
+            patches = self.get_patches(self.normalize_img(rgb_imgs), patch_size, patch_stride)
+            bsz, npy, npx = patches.shape[:3]
+            patches = patches.reshape(bsz * npy * npx, 3, patch_size, patch_size)
+            return torch.nn.functional.interpolate(patches, size=(224, 224), mode="bilinear", align_corners=False)
+        if dtype is None:
+            dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        x = rgb_imgs if rgb_imgs.dtype == torch.float32 else rgb_imgs.float()
+        bsz = x.shape[0]
+        npy, npx = 1 + (imheight - patch_size) // patch_stride, 1 + (imwidth - patch_size) // patch_stride
+        out = torch.empty((bsz * npy * npx, 3, 224, 224), dtype=dtype, device=x.device)
+        mean = (C.c_float * 3)(*self.channel_mean.detach().reshape(-1).tolist())
+        std = (C.c_float * 3)(*self.channel_std.detach().reshape(-1).tolist())
+        sb, sc, sy, sx = x.stride()
+        with torch.cuda.device(x.device):
+            rc = lib().saf_clip_tiles(x.data_ptr(), bsz, imheight, imwidth, sb, sc, sy, sx, int(patch_size), int(patch_stride),
+                                      224, mean, std, out.data_ptr(), _DT[dtype], current_stream_ptr())
+        check(rc, "saf_clip_tiles")
+        return out
+
     def img_inference_tiled(self, rgb_imgs, patch_size, patch_stride):
         """[B,3,H,W] in 0..1 -> [B,D,npy,npx] CLIP embedding per tile (clipfusion.py:808-839)."""
-        patches = self.get_patches(self.normalize_img(rgb_imgs), patch_size, patch_stride)
-        bsz, npy, npx = patches.shape[:3]
-        patches = patches.reshape(bsz * npy * npx, 3, patch_size, patch_size)
-        patches = torch.nn.functional.interpolate(patches, size=(224, 224), mode="bilinear", align_corners=False)
+        patches = self.tiles_224(rgb_imgs, patch_size, patch_stride)
+        bsz = rgb_imgs.shape[0]
+        npy = 1 + (rgb_imgs.shape[2] - patch_size) // patch_stride
+        npx = 1 + (rgb_imgs.shape[3] - patch_size) // patch_stride
         feats = torch.empty(len(patches), self.feature_dim, device=rgb_imgs.device)
         step = int(self.max_patch_batch_size)
         for start in range(0, len(patches), step):

@@ -221,6 +221,53 @@ __global__ __launch_bounds__(256) void sample_vertices_kernel(
   }
 }
 
+
+// ---- the tiled CLIP front-end in one pass (clipfusion.py:789-823) ----
+// normalize_img (:783-784), Unfold into overlapping p x p tiles at stride s (:797-804) and the bilinear resize of every
+// tile to 224 x 224 (:821-823, align_corners = False) fused: an output pixel reads its four source pixels straight from
+// the frame (any strides: channel-last as the loaders yield it, or planar), normalises them and blends --
+// ATen's arithmetic: src = scale * (dst + 0.5) - 0.5 clamped at 0, i1 = min(i0 + 1, p - 1),
+// out = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11).  The [tiles, 3, 224, 224] batch is written once, in the
+// dtype the ViT consumes (fp32, or bf16 / fp16 under autocast) instead of three fp32 round trips through HBM.
+struct TileArgs {
+  const float* rgb;
+  int B, H, W, p, s, npy, npx, out;
+  int64_t sb, sc, sy, sx;
+  float mean[3], stdv[3], scale;
+};
+template <int OT>
+__global__ __launch_bounds__(256) void clip_tiles_kernel(TileArgs a, void* __restrict__ dst) {
+  const int ox = blockIdx.x * 256 + threadIdx.x;  // x fastest: coalesced planar stores
+  const int oy = blockIdx.y, tile = blockIdx.z;
+  if (ox >= a.out) return;
+  const int px = tile % a.npx, py = (tile / a.npx) % a.npy, b = tile / (a.npx * a.npy);
+  float fy = a.scale * ((float)oy + 0.5f) - 0.5f, fx = a.scale * ((float)ox + 0.5f) - 0.5f;
+  fy = fy < 0.0f ? 0.0f : fy;
+  fx = fx < 0.0f ? 0.0f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < a.p - 1 ? 1 : 0), x1 = x0 + (x0 < a.p - 1 ? 1 : 0);
+  const float h1 = fy - (float)y0, h0 = 1.0f - h1, w1 = fx - (float)x0, w0 = 1.0f - w1;
+  const float* base = a.rgb + (int64_t)b * a.sb + (int64_t)(py * a.s) * a.sy + (int64_t)(px * a.s) * a.sx;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* pc = base + (int64_t)c * a.sc;
+    const float v00 = (pc[(int64_t)y0 * a.sy + (int64_t)x0 * a.sx] - a.mean[c]) / a.stdv[c];
+    const float v01 = (pc[(int64_t)y0 * a.sy + (int64_t)x1 * a.sx] - a.mean[c]) / a.stdv[c];
+    const float v10 = (pc[(int64_t)y1 * a.sy + (int64_t)x0 * a.sx] - a.mean[c]) / a.stdv[c];
+    const float v11 = (pc[(int64_t)y1 * a.sy + (int64_t)x1 * a.sx] - a.mean[c]) / a.stdv[c];
+    const float v = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+    const int64_t o = (((int64_t)tile * 3 + c) * a.out + oy) * a.out + ox;
+    if (OT == SAF_F32) {
+      static_cast<float*>(dst)[o] = v;
+    } else if (OT == SAF_BF16) {
+      static_cast<uint16_t*>(dst)[o] = (uint16_t)f32_to_bf16_bits(v);
+    } else {
+      const _Float16 hv = (_Float16)v;
+      static_cast<uint16_t*>(dst)[o] = __builtin_bit_cast(uint16_t, hv);
+    }
+  }
+}
+
 }  // namespace
 }  // namespace saf
 
@@ -280,6 +327,34 @@ int saf_label_argmax(const int32_t* labels_one_hot, int64_t n_vox, int32_t n_cla
   hipLaunchKernelGGL(label_argmax_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      labels_one_hot, n_vox, n_classes, out);
   return check_launch("label_argmax_kernel");
+}
+
+int saf_clip_tiles(const float* rgb, int32_t batch, int32_t height, int32_t width, int64_t stride_b, int64_t stride_c,
+                   int64_t stride_y, int64_t stride_x, int32_t patch, int32_t stride, int32_t out_size,
+                   const float* mean3, const float* std3, void* out, int32_t out_dtype, void* stream) {
+  if (!rgb || !out || !mean3 || !std3 || batch <= 0 || height <= 0 || width <= 0 || patch <= 0 || stride <= 0 || out_size <= 0)
+    return fail(SAF_E_INVALID, "clip_tiles: bad arguments");
+  if (patch > height || patch > width || (height - patch) % stride != 0 || (width - patch) % stride != 0)
+    return fail(SAF_E_INVALID, "clip_tiles: (H - patch) and (W - patch) must be non-negative multiples of the stride "
+                               "(the reference asserts the same, clipfusion.py:792-793)");
+  TileArgs a;
+  a.rgb = rgb; a.B = batch; a.H = height; a.W = width; a.p = patch; a.s = stride; a.out = out_size;
+  a.npy = 1 + (height - patch) / stride;
+  a.npx = 1 + (width - patch) / stride;
+  a.sb = stride_b; a.sc = stride_c; a.sy = stride_y; a.sx = stride_x;
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
+  a.scale = (float)patch / (float)out_size;  // ATen area_pixel_compute_scale, align_corners = false
+  const int64_t tiles = (int64_t)batch * a.npy * a.npx;
+  if (tiles > 65535 || out_size > 65535) return fail(SAF_E_UNSUPPORTED, "clip_tiles: more than 65535 tiles in one call");
+  const dim3 grid((out_size + 255) / 256, out_size, (unsigned)tiles);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (out_dtype) {
+    case SAF_F32: hipLaunchKernelGGL(clip_tiles_kernel<SAF_F32>, grid, dim3(256), 0, s, a, out); break;
+    case SAF_BF16: hipLaunchKernelGGL(clip_tiles_kernel<SAF_BF16>, grid, dim3(256), 0, s, a, out); break;
+    case SAF_F16: hipLaunchKernelGGL(clip_tiles_kernel<SAF_F16>, grid, dim3(256), 0, s, a, out); break;
+    default: return fail(SAF_E_INVALID, "clip_tiles: bad out_dtype %d", out_dtype);
+  }
+  return check_launch("clip_tiles_kernel");
 }
 
 }  // extern "C"

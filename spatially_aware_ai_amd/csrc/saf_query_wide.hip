@@ -439,7 +439,11 @@ template <int FT, int OT, int KS, int EPI>
 __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1))) void query_wide2_kernel(Wide2Args wa) {
   constexpr int D = KS * 16;
   constexpr int ROWB = D * 2 + 16;  // padded LDS row in bytes: the 16 lanes of a ds_read_b128 group hit distinct bank quads
+#ifdef SAF_W2_NO_DMA
+  constexpr bool kDma = false;
+#else
   constexpr bool kDma = (D == 512);  // a text row is exactly one 1 KiB LDS-DMA piece
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char s_tiles[];  // 2 x [32][ROWB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -466,25 +470,45 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
   prev = cur;
   f32x16_t acc[2][2];  // [step parity][fragment]: the tile being accumulated and the previous one awaiting its epilogue
 
-  // One step = one (row block, query tile) pair.  In program order: barrier (tile in LDS) -> LDS-DMA of the next
-  // tile -> all of this tile's text fragments into registers -> the PREVIOUS tile's epilogue -> 64 MFMAs.  The
-  // epilogue's vector work and stores have no dependence on the MFMAs that follow them, so the scheduler may
-  // interleave the two; the fragments arrive while the epilogue runs.
+  // the 64 rows per wave of row block `bi` of this workgroup: addresses of the lane's two rows
+  auto block_rows = [&](int64_t bi, int64_t& row_a, int64_t& row_b, const uint16_t*& pa, const uint16_t*& pb) {
+    const int64_t blk = blockIdx.x + bi * gridDim.x;
+    const int64_t row0 = (blk * kW2Waves + wave) * kW2Rows;
+    row_a = row0 + r;
+    row_b = row0 + 32 + r;
+    const int64_t ra = row_a < wa.n_rows ? row_a : wa.n_rows - 1, rb = row_b < wa.n_rows ? row_b : wa.n_rows - 1;
+    pa = wa.feats + ra * wa.fstride + 8 * h;
+    pb = wa.feats + rb * wa.fstride + 8 * h;
+  };
+  {  // the first block's rows
+    const uint16_t *pa, *pb;
+    block_rows(0, cur.row_a, cur.row_b, pa, pb);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      a0[s] = ld_stream_u4(pa + 16 * s);
+      a1[s] = ld_stream_u4(pb + 16 * s);
+    }
+  }
+#ifndef SAF_W2_NO_STAGGER
+  // Every workgroup runs the same schedule, so without this they would all reach their row-block switch -- a burst of
+  // 256 KiB of feature rows per workgroup with no MFMA beside it -- at the same moment: HBM idle for a block, then
+  // asked for 64 MiB at once.  Sixteen start phases spread the switches over the block time (the price: at most one
+  // block time of sleep at the start of the kernel, well under a percent).
+  {
+    const int phase = blockIdx.x & 15;
+    for (int k = 0; k < phase; ++k) __builtin_amdgcn_s_sleep(127);  // ~8 k cycles (4 us) each: 16 phases ~ one block time
+  }
+#endif
+
+  // One step = one (row block, query tile) pair.  In program order: barrier (tile in LDS) -> transfer of the next tile
+  // issued -> the first 16 text fragments requested -> the PREVIOUS tile's epilogue (vector work and stores that do not
+  // depend on what follows) -> 64 MFMAs, each pair consuming one fragment and requesting the one 16 steps ahead (the
+  // LDS counter tracks 15 outstanding reads).  In the LAST tile of a row block every MFMA pair is followed by the loads
+  // of the next block's rows into the registers it has just read for the last time.
   auto step_body = [&](int64_t step, f32x16_t& c0, f32x16_t& c1, const f32x16_t& p0, const f32x16_t& p1) {
     const int qt = (int)(step % n_qt);
-    if (qt == 0) {  // a new row block: its 64 rows per wave, register resident for every query tile
-      const int64_t blk = blockIdx.x + (step / n_qt) * gridDim.x;
-      const int64_t row0 = (blk * kW2Waves + wave) * kW2Rows;
-      cur.row_a = row0 + r;
-      cur.row_b = row0 + 32 + r;
-      const int64_t ra = cur.row_a < wa.n_rows ? cur.row_a : wa.n_rows - 1, rb = cur.row_b < wa.n_rows ? cur.row_b : wa.n_rows - 1;
-      const uint16_t* pa = wa.feats + ra * wa.fstride + 8 * h;
-      const uint16_t* pb = wa.feats + rb * wa.fstride + 8 * h;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        a0[s] = ld_stream_u4(pa + 16 * s);
-        a1[s] = ld_stream_u4(pb + 16 * s);
-      }
+    const int64_t bi = step / n_qt;
+    if (qt == 0) {  // a new row block: its rows are in a0 / a1 (loaded above, or behind the last block's MFMAs)
       cur.inv0 = cur.inv1 = wa.scale;
       if (wa.normalize) {
         float ss0 = 0.f, ss1 = 0.f;
@@ -516,7 +540,7 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     cur.qt = qt;
     const unsigned char* curb = s_tiles + (size_t)(step & 1) * kWTile * ROWB;
     unsigned char* nxt = s_tiles + (size_t)((step + 1) & 1) * kWTile * ROWB;
-    // this tile's text is in LDS (its DMA / copy was issued a step ago) and every wave is done reading the other buffer
+    // this tile's text is in LDS (its transfer was issued a step ago) and every wave is done reading the other buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool more = step + 1 < n_steps;
@@ -542,18 +566,39 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       }
     }
-    // every text fragment of the tile into registers: the reads stream while the previous tile's epilogue runs
+    constexpr int AHEAD = KS < 16 ? KS : 16;
     uint4 t[KS];
     const unsigned char* trow = curb + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h
 #pragma unroll
-    for (int s = 0; s < KS; ++s) t[s] = *reinterpret_cast<const uint4*>(trow + 32 * s);
+    for (int s = 0; s < AHEAD; ++s) t[s] = *reinterpret_cast<const uint4*>(trow + 32 * s);
     if (step > 0) w2_epilogue<OT, EPI>(wa, p0, p1, prev, st, r, h, n_qt, vec_ok);
 #pragma unroll
     for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
+    const bool switch_rows = qt == n_qt - 1 && bi + 1 < my_blocks;
+    if (!switch_rows) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      c0 = mfma16<FT>(t[s], a0[s], c0);  // C[query][feature row]
-      c1 = mfma16<FT>(t[s], a1[s], c1);
+      for (int s = 0; s < KS; ++s) {
+        c0 = mfma16<FT>(t[s], a0[s], c0);  // C[query][feature row]
+        c1 = mfma16<FT>(t[s], a1[s], c1);
+        if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + 32 * (s + AHEAD));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const uint16_t *pa, *pb;
+      int64_t na, nb;
+      block_rows(bi + 1, na, nb, pa, pb);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        c0 = mfma16<FT>(t[s], a0[s], c0);
+        c1 = mfma16<FT>(t[s], a1[s], c1);
+        if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + 32 * (s + AHEAD));
+        a0[s] = ld_stream_u4(pa + 16 * s);  // the next block's rows, behind this block's last use of the registers
+        a1[s] = ld_stream_u4(pb + 16 * s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      prev = cur;  // (the epilogue of this tile still describes the old block)
+      cur.row_a = na;
+      cur.row_b = nb;
     }
     if (more && !kDma) {
 #pragma unroll
@@ -565,9 +610,10 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       }
     }
-    prev = cur;
+    if (!switch_rows) prev = cur;
   };
 
+  __syncthreads();  // tile 0 of the first block is in LDS
   int64_t step = 0;
   for (; step + 1 < n_steps; step += 2) {
     step_body(step, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);

@@ -60,3 +60,33 @@ def test_tile_shape_asserts_like_the_reference():
     clip = Clip("stub", None, backbone=StubBackbone(), tokenizer=None)
     with pytest.raises(AssertionError):  # (H - p) % s != 0, clipfusion.py:792-793
         clip.get_patches(torch.zeros(1, 3, 50, 64), 16, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_fused_tile_kernel_matches_reference(golden, case):
+    """saf_clip_tiles (normalise + unfold + 224^2 resize in one HIP pass) against the reference's own tiles, for planar
+    frames and for the channel-last frames integrate() receives (a permuted view: no copy is made)."""
+    g = golden
+    rgb = torch.from_numpy(g[f"c{case}_rgb"])
+    ps, st = (int(v) for v in g[f"c{case}_patch"])
+    bb = StubBackbone()
+    clip = Clip("stub", None, backbone=bb, tokenizer=None).cuda()
+    planar = rgb.cuda()
+    channel_last = rgb.permute(0, 2, 3, 1).contiguous().cuda().permute(0, 3, 1, 2)  # [B,H,W,3] storage, [B,3,H,W] view
+    for x in (planar, channel_last):
+        tiles = clip.tiles_224(x, ps, st)
+        assert tiles.dtype == torch.float32 and tiles.shape[1:] == (3, 224, 224)
+        np.testing.assert_allclose(tiles[:, :, ::13, ::11].cpu().numpy(), g[f"c{case}_resized_sample"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(tiles.double().sum(dim=(1, 2, 3)).cpu().numpy(), g[f"c{case}_resized_sum"], rtol=1e-6)
+        bb.seen.clear()
+        feats = clip.img_inference_tiled(x, ps, st)
+        np.testing.assert_allclose(feats.cpu().numpy(), g[f"c{case}_feats"], rtol=1e-5, atol=2e-6)
+    # the dtype the ViT consumes under autocast
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        t16 = clip.tiles_224(planar, ps, st)
+    assert t16.dtype == torch.bfloat16
+    ref = clip.tiles_224(planar, ps, st)
+    assert torch.equal(t16, ref.to(torch.bfloat16)), "bf16 tiles are the fp32 tiles rounded once"
+    with pytest.raises(AssertionError):
+        clip.tiles_224(planar[:, :, :-1], ps, st)
