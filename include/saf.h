@@ -301,6 +301,27 @@ int saf_marching_cubes_emit(const float* tsdf, const int32_t* weight, int32_t nx
                             void* workspace, size_t workspace_bytes, float* verts, int64_t verts_capacity,
                             int32_t* faces, int64_t faces_capacity, void* stream);
 
+/*
+ * On-disk and wire formats of the fused results (host code, any thread).
+ *   saf_save_npy   data (device memory when on_device != 0, read after `stream` has drained; else host memory) ->
+ *                  NumPy .npy v1.0 at `path`, C order.  dtype_code: 0 f32, 1 bf16 (written as 2-byte records '<V2'),
+ *                  2 f16, 3 i32, 4 i64, 5 u8.  Device arrays stream through two pinned 64 MiB buffers (copy of chunk
+ *                  k + 1 beside the write of chunk k).  The files of save_files_and_broadcast (clip_seem_fusion.py:563-581).
+ *   saf_mesh_json  {"vertices": [[x, y, z], ...], "faces": [[i, j, k], ...], "colors": [[...], ...]} (clip_seem_fusion.py:
+ *                  553-559, handy_utils.py:233-239) from HOST arrays; floats are printed as the shortest decimal that
+ *                  round-trips the double value of each f32, so a JSON parser returns exactly ndarray.tolist().
+ *                  *out is malloc'ed: release it with saf_free.
+ *   saf_save_ply   binary little-endian PLY (x y z float, optional red green blue alpha uchar from colours in 0..1,
+ *                  faces as `list uchar int`) from HOST arrays: mesh_rgb.ply / mesh_segmentation.ply (:584-600).
+ */
+int saf_save_npy(const void* data, int32_t on_device, int32_t dtype_code, const int64_t* shape, int32_t ndim,
+                 const char* path, void* stream);
+int saf_mesh_json(const float* verts, int64_t n_verts, const int32_t* faces, int64_t n_faces, const float* colors,
+                  int32_t n_color, char** out, int64_t* out_len);
+void saf_free(void* p);
+int saf_save_ply(const char* path, const float* verts, int64_t n_verts, const int32_t* faces, int64_t n_faces,
+                 const float* colors, int32_t n_color);
+
 /* Per-voxel argmax of the label histogram with the all-zero row -> -1 rule
  * (clip_seem_fusion.py:315-325).  out[N] i32. */
 int saf_label_argmax(const int32_t* labels_one_hot, int64_t n_voxels, int32_t n_classes,

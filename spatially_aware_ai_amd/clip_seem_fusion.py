@@ -213,6 +213,16 @@ class TextQueryEngine:
             return None
         return {"vertices": self.verts, "faces": self.faces, "colors": relevance_to_rgba(rel).tolist()}
 
+    def clip_text_query_json(self, text: str):
+        """The same answer already serialised (UTF-8 JSON bytes, or None): what app_unity.py:66-71 hands to jsonify, without
+        the detour through Python lists (io.mesh_to_json; the parsed result equals clip_text_query's dict for f32 meshes)."""
+        from .io import mesh_to_json
+
+        rel = self.relevance(text)
+        if rel is None:
+            return None
+        return mesh_to_json(self.verts, self.faces, relevance_to_rgba(rel).astype(np.float32))
+
 
 def relevance_to_rgba(relevance):
     """turbo colour map, alpha = 0.5 * relevance (clip_seem_fusion.py:544-548)."""

@@ -1,0 +1,251 @@
+// saf_io.hip -- on-disk and wire formats of the fused results, host code.
+//
+// After acceleration the reference's save_files_and_broadcast (clip_seem_fusion.py:563-607) and the JSON answers of
+// clip_text_query / mesh_to_json (clip_seem_fusion.py:553-559, handy_utils.py:214-241) dominate a reprocess_scan: the
+// volume is copied to the host as a whole, np.save'd, and meshes travel as Python lists through json.dumps.  Here:
+//   saf_save_npy      a device (or host) array -> NumPy .npy v1.0, streamed through two pinned buffers: the copy of
+//                     chunk k+1 overlaps the write of chunk k, no host copy of the whole array ever exists
+//                     (voxel_clip_feats.npy is 34 GB at 256^3 x 512).  np.load reads it (query_mesh.py:22).
+//   saf_mesh_json     {"vertices": [[x,y,z],...], "faces": [[i,j,k],...], "colors": [[...],...]} as UTF-8 text, every
+//                     float printed as the shortest decimal that round-trips the DOUBLE value of the f32 (what
+//                     json.dumps(ndarray.tolist()) prints, up to exponent spelling): parsing it gives exactly the lists
+//                     the reference sends.
+//   saf_save_ply      binary little-endian PLY with per-vertex RGBA bytes and triangle faces -- the layout trimesh's
+//                     export writes for mesh_rgb.ply / mesh_segmentation.ply (clip_seem_fusion.py:584-600) and
+//                     trimesh.load_mesh / open3d read (query_mesh.py:42, handy_utils.py:219).
+#include <charconv>
+#include <errno.h>
+#include <fcntl.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <unistd.h>
+
+#include "saf_host.h"
+
+namespace saf {
+namespace {
+
+const char* npy_descr(int dtype_code) {
+  switch (dtype_code) {
+    case 0: return "<f4";
+    case 1: return "<V2";  // bfloat16 has no NumPy dtype: raw 2-byte records
+    case 2: return "<f2";
+    case 3: return "<i4";
+    case 4: return "<i8";
+    case 5: return "|u1";
+    default: return nullptr;
+  }
+}
+size_t npy_itemsize(int dtype_code) {
+  switch (dtype_code) {
+    case 0: case 3: return 4;
+    case 1: case 2: return 2;
+    case 4: return 8;
+    case 5: return 1;
+    default: return 0;
+  }
+}
+
+bool write_all(int fd, const void* p, size_t n) {
+  const char* c = static_cast<const char*>(p);
+  while (n) {
+    const ssize_t w = ::write(fd, c, n);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    c += w;
+    n -= (size_t)w;
+  }
+  return true;
+}
+
+inline void put_double(std::string& out, double v) {
+  if (isnan(v)) { out += "NaN"; return; }          // what json.dumps prints (allow_nan defaults to True)
+  if (isinf(v)) { out += v > 0 ? "Infinity" : "-Infinity"; return; }
+  char buf[40];
+  auto r = std::to_chars(buf, buf + sizeof(buf), v);  // shortest round-trip form
+  bool integral = true;
+  for (char* c = buf; c != r.ptr; ++c)
+    if (*c == '.' || *c == 'e' || *c == 'n' || *c == 'i') integral = false;
+  out.append(buf, r.ptr);
+  if (integral) out += ".0";  // a float stays a float after parsing, as in Python's repr
+}
+inline void put_int(std::string& out, long long v) {
+  char buf[24];
+  auto r = std::to_chars(buf, buf + sizeof(buf), v);
+  out.append(buf, r.ptr);
+}
+
+}  // namespace
+}  // namespace saf
+
+using namespace saf;
+
+extern "C" {
+
+int saf_save_npy(const void* data, int32_t on_device, int32_t dtype_code, const int64_t* shape, int32_t ndim, const char* path,
+                 void* stream) {
+  const char* descr = npy_descr(dtype_code);
+  if (!path || !shape || ndim < 0 || ndim > 8 || !descr) return fail(SAF_E_INVALID, "save_npy: bad arguments");
+  size_t count = 1;
+  std::string shp = "(";
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] < 0) return fail(SAF_E_INVALID, "save_npy: negative dimension");
+    count *= (size_t)shape[i];
+    shp += std::to_string(shape[i]);
+    shp += (ndim == 1 || i + 1 < ndim) ? "," : "";
+    if (i + 1 < ndim) shp += " ";
+  }
+  shp += ")";
+  if (!data && count) return fail(SAF_E_INVALID, "save_npy: data is NULL");
+  std::string hdr = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': " + shp + ", }";
+  // magic (6) + version (2) + header length (2) + header, padded with spaces to a multiple of 64, ending in '\n'
+  size_t total = 10 + hdr.size() + 1;
+  const size_t pad = (64 - total % 64) % 64;
+  hdr.append(pad, ' ');
+  hdr += '\n';
+  if (hdr.size() > 65535) return fail(SAF_E_INVALID, "save_npy: header too long");
+  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return fail(SAF_E_INVALID, "save_npy: cannot open %s: %s", path, strerror(errno));
+  unsigned char pre[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, (unsigned char)(hdr.size() & 255), (unsigned char)(hdr.size() >> 8)};
+  int rc = SAF_OK;
+  const size_t bytes = count * npy_itemsize(dtype_code);
+  if (!write_all(fd, pre, 10) || !write_all(fd, hdr.data(), hdr.size())) rc = fail(SAF_E_INVALID, "save_npy: write failed: %s", strerror(errno));
+  if (rc == SAF_OK && bytes) {
+    if (!on_device) {
+      if (!write_all(fd, data, bytes)) rc = fail(SAF_E_INVALID, "save_npy: write failed: %s", strerror(errno));
+    } else {
+      // the producer's stream must be done with `data`; then chunks alternate between two pinned buffers
+      hipStream_t prod = static_cast<hipStream_t>(stream);
+      constexpr size_t kChunk = (size_t)64 << 20;
+      void* pin[2] = {nullptr, nullptr};
+      hipStream_t cs = nullptr;
+      hipEvent_t ev[2] = {nullptr, nullptr};
+      if (hipStreamSynchronize(prod) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess ||
+          hipHostMalloc(&pin[0], kChunk, hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc(&pin[1], kChunk, hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) {
+        rc = fail(SAF_E_HIP, "save_npy: could not set up the pinned staging buffers");
+      } else {
+        const char* src = static_cast<const char*>(data);
+        const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+        auto issue = [&](size_t k) {
+          const size_t off = k * kChunk, len = bytes - off < kChunk ? bytes - off : kChunk;
+          return hipMemcpyAsync(pin[k & 1], src + off, len, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+                 hipEventRecord(ev[k & 1], cs) == hipSuccess;
+        };
+        bool ok = issue(0);
+        for (size_t k = 0; ok && k < n_chunks; ++k) {
+          ok = hipEventSynchronize(ev[k & 1]) == hipSuccess;
+          if (ok && k + 1 < n_chunks) ok = issue(k + 1);  // (the other buffer was written out in the last iteration)
+          const size_t off = k * kChunk, len = bytes - off < kChunk ? bytes - off : kChunk;
+          if (ok && !write_all(fd, pin[k & 1], len)) {
+            rc = fail(SAF_E_INVALID, "save_npy: write failed: %s", strerror(errno));
+            break;
+          }
+        }
+        if (!ok && rc == SAF_OK) rc = fail(SAF_E_HIP, "save_npy: device-to-host copy failed");
+        (void)hipStreamSynchronize(cs);
+      }
+      for (int i = 0; i < 2; ++i) {
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (pin[i]) (void)hipHostFree(pin[i]);
+      }
+      if (cs) (void)hipStreamDestroy(cs);
+    }
+  }
+  if (::close(fd) != 0 && rc == SAF_OK) rc = fail(SAF_E_INVALID, "save_npy: close failed: %s", strerror(errno));
+  return rc;
+}
+
+/* verts [n_verts,3] f32, faces [n_faces,3] i32 (may be NULL with n_faces = 0), colors [n_verts, n_color] f32 (may be
+ * NULL): HOST pointers.  Returns a malloc'ed UTF-8 buffer in *out (free with saf_free) and its length in *out_len. */
+int saf_mesh_json(const float* verts, int64_t n_verts, const int32_t* faces, int64_t n_faces, const float* colors,
+                  int32_t n_color, char** out, int64_t* out_len) {
+  if (!out || !out_len || n_verts < 0 || n_faces < 0 || (n_verts && !verts) || (n_faces && !faces) || (colors && n_color <= 0))
+    return fail(SAF_E_INVALID, "mesh_json: bad arguments");
+  std::string s;
+  s.reserve((size_t)n_verts * (72 + (colors ? 24 * (size_t)n_color : 0)) + (size_t)n_faces * 30 + 64);
+  auto rows_f = [&](const float* p, int64_t n, int w) {
+    s += '[';
+    for (int64_t i = 0; i < n; ++i) {
+      s += i ? ", [" : "[";
+      for (int j = 0; j < w; ++j) {
+        if (j) s += ", ";
+        put_double(s, (double)p[i * w + j]);
+      }
+      s += ']';
+    }
+    s += ']';
+  };
+  s += "{\"vertices\": ";
+  rows_f(verts, n_verts, 3);
+  s += ", \"faces\": [";
+  for (int64_t i = 0; i < n_faces; ++i) {
+    s += i ? ", [" : "[";
+    put_int(s, faces[3 * i]); s += ", ";
+    put_int(s, faces[3 * i + 1]); s += ", ";
+    put_int(s, faces[3 * i + 2]);
+    s += ']';
+  }
+  s += ']';
+  if (colors) {
+    s += ", \"colors\": ";
+    rows_f(colors, n_verts, n_color);
+  }
+  s += '}';
+  char* buf = static_cast<char*>(malloc(s.size() + 1));
+  if (!buf) return fail(SAF_E_INVALID, "mesh_json: out of memory");
+  memcpy(buf, s.data(), s.size());
+  buf[s.size()] = 0;
+  *out = buf;
+  *out_len = (int64_t)s.size();
+  return SAF_OK;
+}
+
+void saf_free(void* p) { free(p); }
+
+/* Binary little-endian PLY: vertices x y z (float) + red green blue alpha (uchar; colors [n_verts, n_color] f32 in 0..1,
+ * n_color 3 or 4, alpha 255 when absent; NULL = no colour properties), faces as `list uchar int`.  HOST pointers. */
+int saf_save_ply(const char* path, const float* verts, int64_t n_verts, const int32_t* faces, int64_t n_faces,
+                 const float* colors, int32_t n_color) {
+  if (!path || n_verts < 0 || n_faces < 0 || (n_verts && !verts) || (n_faces && !faces) || (colors && n_color != 3 && n_color != 4))
+    return fail(SAF_E_INVALID, "save_ply: bad arguments");
+  std::string h = "ply\nformat binary_little_endian 1.0\ncomment spatially_aware_ai_amd\nelement vertex " + std::to_string(n_verts) +
+                  "\nproperty float x\nproperty float y\nproperty float z\n";
+  if (colors) h += "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty uchar alpha\n";
+  h += "element face " + std::to_string(n_faces) + "\nproperty list uchar int vertex_indices\nend_header\n";
+  const size_t vrec = 12 + (colors ? 4 : 0);
+  std::string body;
+  body.resize((size_t)n_verts * vrec + (size_t)n_faces * 13);
+  char* w = &body[0];
+  for (int64_t i = 0; i < n_verts; ++i) {
+    memcpy(w, verts + 3 * i, 12);
+    w += 12;
+    if (colors) {
+      for (int c = 0; c < 4; ++c) {
+        float v = c < n_color ? colors[i * n_color + c] : 1.0f;
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        *w++ = (char)(unsigned char)nearbyintf(v * 255.0f);
+      }
+    }
+  }
+  for (int64_t i = 0; i < n_faces; ++i) {
+    *w++ = 3;
+    memcpy(w, faces + 3 * i, 12);
+    w += 12;
+  }
+  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return fail(SAF_E_INVALID, "save_ply: cannot open %s: %s", path, strerror(errno));
+  int rc = SAF_OK;
+  if (!write_all(fd, h.data(), h.size()) || !write_all(fd, body.data(), body.size()))
+    rc = fail(SAF_E_INVALID, "save_ply: write failed: %s", strerror(errno));
+  if (::close(fd) != 0 && rc == SAF_OK) rc = fail(SAF_E_INVALID, "save_ply: close failed: %s", strerror(errno));
+  return rc;
+}
+
+}  // extern "C"

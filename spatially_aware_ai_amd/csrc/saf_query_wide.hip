@@ -509,6 +509,17 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     const int qt = (int)(step % n_qt);
     const int64_t bi = step / n_qt;
     if (qt == 0) {  // a new row block: its rows are in a0 / a1 (loaded above, or behind the last block's MFMAs)
+#ifdef SAF_W2_NO_PREFETCH
+      if (bi > 0) {
+        const uint16_t *pa, *pb;
+        block_rows(bi, cur.row_a, cur.row_b, pa, pb);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          a0[s] = ld_stream_u4(pa + 16 * s);
+          a1[s] = ld_stream_u4(pb + 16 * s);
+        }
+      }
+#endif
       cur.inv0 = cur.inv1 = wa.scale;
       if (wa.normalize) {
         float ss0 = 0.f, ss1 = 0.f;
@@ -566,7 +577,11 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       }
     }
+#ifdef SAF_W2_AHEAD_ALL
+    constexpr int AHEAD = KS;  // every fragment requested up front (the earlier form)
+#else
     constexpr int AHEAD = KS < 16 ? KS : 16;
+#endif
     uint4 t[KS];
     const unsigned char* trow = curb + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h
 #pragma unroll
@@ -574,14 +589,21 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     if (step > 0) w2_epilogue<OT, EPI>(wa, p0, p1, prev, st, r, h, n_qt, vec_ok);
 #pragma unroll
     for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
+#ifdef SAF_W2_NO_PREFETCH
+    const bool switch_rows = false;
+    if (qt == n_qt - 1 && bi + 1 < my_blocks) {}
+#else
     const bool switch_rows = qt == n_qt - 1 && bi + 1 < my_blocks;
+#endif
     if (!switch_rows) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         c0 = mfma16<FT>(t[s], a0[s], c0);  // C[query][feature row]
         c1 = mfma16<FT>(t[s], a1[s], c1);
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + 32 * (s + AHEAD));
+#ifndef SAF_W2_NO_SCHEDBAR
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     } else {
       const uint16_t *pa, *pb;

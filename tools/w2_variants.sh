@@ -7,9 +7,10 @@ mkdir -p $OUT
 C=spatially_aware_ai_amd/csrc
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wno-unused-function"
 OTHERS="$C/saf_fuse.o $C/saf_window.o $C/saf_query.o $C/saf_misc.o $C/saf_ccl.o $C/saf_mesh.o"
-for v in ${VARIANTS:-base NO_DMA NO_STAGGER "NO_DMA -DSAF_W2_NO_STAGGER"}; do
-  tag=$(echo $v | tr -d ' ' | tr -c 'A-Za-z_\n' '_')
-  def=""; [ "$v" != base ] && def="-DSAF_W2_$v"
+# VARIANTS: space-separated; a variant is `base` or switches joined by '+', e.g. NO_DMA+NO_STAGGER
+for v in ${VARIANTS:-base NO_DMA NO_STAGGER NO_DMA+NO_STAGGER}; do
+  tag=$(echo $v | tr '+' '_')
+  def=""; [ "$v" != base ] && def=$(echo $v | sed 's/^/-DSAF_W2_/; s/+/ -DSAF_W2_/g')
   /opt/rocm/bin/hipcc $FLAGS $def -c $C/saf_query_wide.hip -o /tmp/qw_$tag.o && \
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libsaf_$tag.so /tmp/qw_$tag.o $OTHERS && \
   SAF_LIB_PATH=/tmp/libsaf_$tag.so python3 bench.py --query --query-wide-only --steps 3 --warmup 1 --cpu-frames 0 > $OUT/$tag.json 2> $OUT/$tag.err
