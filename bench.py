@@ -223,7 +223,7 @@ def main():
         L.saf_profiler_set_stride(prof, a.profile_stride)
 
     def fuse_into(fz, frame_arr, n_frames, profiler):
-        vol = fz._c_volume()
+        vol = fz._c_volume(for_fuse=True)  # (neither the frame queue nor the deferred clear of reset() is resolved here)
         rc = L.saf_fuse_frames_profiled(C.byref(vol), frame_arr, n_frames, ws.data_ptr(), ws.numel(),
                                         fusion.fuse_stats.data_ptr(), profiler, stream)
         check(rc, "saf_fuse_frames_profiled")
@@ -255,8 +255,13 @@ def main():
             fz = fusions[slot]
             if merge_done[slot] is not None:  # this volume's previous merge must have drained
                 main_stream.wait_event(merge_done[slot])
+            # reset(): the small buffers are zeroed, the 34 GB of feature rows are NOT -- the windowed path never reads a
+            # row whose weight is 0 -- and the rows still unwritten at the end of the job are zeroed below (flush / merge),
+            # inside the timed region: every buffer ends bit-identical to an up-front clear
             fz.reset(accum_mode=_abi.SAF_SUM if world > 1 else _abi.SAF_RUNNING_MEAN)
             fuse_into(fz, frames, a.frames, profiler)
+            if world == 1:
+                fz.flush()
             if world > 1:
                 if overlap:
                     fused = main_stream.record_event()
@@ -427,7 +432,7 @@ def main():
         prof2 = L.saf_profiler_create(3 * n_iso)
         torch.cuda.synchronize()
         for i in range(n_iso):
-            vol_i = fusion._c_volume()
+            vol_i = fusion._c_volume(for_fuse=True)
             check(L.saf_fuse_frames_profiled(C.byref(vol_i), C.byref(frames[i]), 1, ws.data_ptr(), ws.numel(),
                                              fusion.fuse_stats.data_ptr(), prof2, stream), "isolated pass")
         torch.cuda.synchronize()

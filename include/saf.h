@@ -131,6 +131,15 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
                     void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
 
+/* Which device path saf_fuse_frames would take for this call: 1 = windowed (never reads the feature rows of voxels
+ * with weight 0), 0 = per-frame pipeline, -1 = invalid arguments.  Host-only, launches nothing. */
+int saf_fuse_path(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes);
+
+/* Zero the clip_feat rows of voxels [first, first + n) whose weight is 0.  A volume recycled for a new scan may skip the
+ * up-front clear of its 4*D*N feature bytes: zero `weight` (and the other small buffers), fuse through the windowed path
+ * only, and call this before anything else reads clip_feat (the Python host does all of that behind reset()). */
+int saf_clear_unwritten_rows(const saf_volume* vol, int64_t first_voxel, int64_t n_voxels, void* stream);
+
 /* The per-frame pipeline hands sweep(i) to fuse(i) on the device; a fuse workgroup that waited ~2 s without
  * seeing its sweep gives up (stats[4]) and sets a host-visible latch.  Once set, saf_fuse_frame(s) on that
  * device return SAF_E_HIP (the volume of the earlier call is incomplete); this polls the latch without

@@ -125,38 +125,111 @@ def label_components(labels_grid, null_class=133, min_voxels=3):
     return ids.view(nx, ny, nz), first[:k], cls[:k], cnt[:k]
 
 
-def discover_objects(labels_grid, class_names, class_colors=None, null_class=133, min_voxels=3):
-    """``scene_knowledge["unique_objects"]`` / ``["object_counts"]`` and ``voxel_obj_idx`` as
-    ``flood_fill_3d`` builds them for a first scan (no in-situ model; handy_utils.py:244-292, :352-353,
-    :430-452, :483-498): ids ``"<class label>:<running count>"`` in raster order of the objects' first
-    voxels.  ``voxels`` holds each object's voxel coordinates in raster order (the reference lists them
-    in flood-fill visiting order)."""
-    voxel_obj_idx, first, cls, cnt = label_components(labels_grid, null_class, min_voxels)
+def _obj_counts(object_counts, obj_id):
+    """handy_utils.py:483-498: "<label>:<n>" ids count under their label; the running count makes the new id."""
+    if ":" in obj_id:
+        possible_label, possible_int = obj_id.split(":")[0], obj_id.split(":")[-1]
+        if possible_int.isdigit():
+            class_label = possible_label
+        else:  # the reference dies here with an UnboundLocalError; keep the whole string as the label instead
+            class_label = obj_id
+    else:
+        class_label = obj_id
+    object_counts[class_label] = object_counts.get(class_label, 0) + 1
+    return f"{class_label}:{object_counts[class_label]}", class_label
+
+
+def discover_objects(labels_grid, class_names, class_colors=None, null_class=133, min_voxels=3, insitu_model=None,
+                     voxel_clip_feats=None, voxel_rgb=None, scene_knowledge_prev=None, preprocess=None):
+    """``scene_knowledge`` and ``voxel_obj_idx`` as ``flood_fill_3d`` builds them (handy_utils.py:295-480).
+
+    The connected components come from the HIP kernel (``label_components``); objects are visited in raster order of
+    their first voxel, which is the reference's discovery order.
+
+    * First scan (``insitu_model`` None or not ``model_trained``): ids ``"<class label>:<running count>"``, indices
+      ``-2, -3, ...`` (handy_utils.py:352-353, :430-452).
+    * Repeat scan (handy_utils.py:396-452, :455-478): for every object its voxels' features (``voxel_clip_feats``
+      [nx,ny,nz,D], ``voxel_rgb`` [nx,ny,nz,3], coordinates) go through ``preprocess([features], None, inference=True)``
+      (the reference's ``InSituVoxelData.preprocess``; default: the feature dict itself in a list) to
+      ``insitu_model.predict``; a prediction > 0 re-identifies the object: it takes the user's label
+      ``insitu_model.labels[pred]``, the POSITIVE voxel index ``pred``, ``user_modified``, is listed in
+      ``unchanged_objects``, and its id joins ``insitu_model.labels`` if new; other objects keep running negative
+      indices.  Labels of the previous scan that found no object go to ``missing_objects`` (needs
+      ``scene_knowledge_prev``).  The DGCNN classifier itself is the reference's (dgcnn/, not part of the fused path):
+      any object with ``model_trained``, ``labels`` and ``predict`` works.
+
+    ``voxels`` holds each object's voxel coordinates in raster order (the reference lists them in flood-fill visiting
+    order).  Returns ``(scene_knowledge, voxel_obj_idx int32 [nx,ny,nz])``."""
+    comp_idx, first, cls, cnt = label_components(labels_grid, null_class, min_voxels)
     unique_objects, object_counts = {}, {}
-    flat = voxel_obj_idx.reshape(-1)
+    unchanged_objects, new_objects, missing_objects = {}, {}, {}
+    flat = comp_idx.reshape(-1)
     order = torch.argsort(-flat.long(), stable=True)  # -1 (none) first, then object 0, 1, ... each in raster order
     n_none = int((flat == -1).sum())
     order = order[n_none:]
     ny, nz = int(labels_grid.shape[1]), int(labels_grid.shape[2])
-    coords = torch.stack((order // (ny * nz), (order // nz) % ny, order % nz), dim=1).cpu().numpy()
+    coords_dev = torch.stack((order // (ny * nz), (order // nz) % ny, order % nz), dim=1)
+    coords = coords_dev.cpu().numpy()
     offs = np.concatenate(([0], np.cumsum(cnt.cpu().numpy())))
     cls_h = cls.cpu().tolist()
+    trained = bool(insitu_model is not None and insitu_model.model_trained)
+    labels_frozen = list(insitu_model.labels[1:]) if insitu_model is not None else []  # handy_utils.py:364
+    gt_labels = insitu_model.labels if insitu_model is not None else ["null"]
+    if trained and (voxel_clip_feats is None or voxel_rgb is None):
+        raise ValueError("a trained in-situ model needs voxel_clip_feats and voxel_rgb to describe the objects")
+    if trained:
+        vcf = torch.as_tensor(voxel_clip_feats)
+        vcf = vcf.reshape(-1, vcf.shape[-1])
+        vrgb = torch.as_tensor(voxel_rgb).reshape(-1, 3)
+    new_index = torch.empty(len(cls_h), dtype=torch.int32)  # voxel index of object k in the final grid
+    negative_object_index = -2
     for k, class_id in enumerate(cls_h):
         class_label = class_names[class_id]
-        object_counts[class_label] = object_counts.get(class_label, 0) + 1
-        obj_id = f"{class_label}:{object_counts[class_label]}"
+        user_modified = False
+        object_index = negative_object_index
+        pred = 0
+        if trained:
+            sel = order[offs[k]:offs[k + 1]]
+            feats = {"clip_feats": vcf[sel.to(vcf.device)], "rgb": vrgb[sel.to(vrgb.device)],
+                     "voxels": coords[offs[k]:offs[k + 1]]}
+            all_features = preprocess([feats], None, inference=True) if preprocess is not None else [feats]
+            pred = int(insitu_model.predict(all_features))
+            if pred > 0:  # found in the previous scan: the user's label and a stable, positive index
+                class_label = insitu_model.labels[pred]
+                user_modified = True
+                object_index = pred
+        obj_id, class_label = _obj_counts(object_counts, class_label)
+        if user_modified and obj_id not in gt_labels:
+            gt_labels.append(obj_id)  # handy_utils.py:268-272: training labels are defined here
         unique_objects[obj_id] = {
             "class_id": class_id,
             "class_label": class_label,
             "voxels": [tuple(int(c) for c in v) for v in coords[offs[k]:offs[k + 1]]],
-            "object_index": -2 - k,
+            "object_index": object_index,
             "gt_label": obj_id,
-            "user_modified": False,
-            "merged": False,
+            "user_modified": user_modified,
+            "merged": "merged" in class_label,
             "removed": False,
             "color": None if class_colors is None else class_colors[class_id],
         }
-    return {"unique_objects": unique_objects, "object_counts": object_counts}, voxel_obj_idx
+        if trained and pred > 0:
+            unchanged_objects[obj_id] = unique_objects[obj_id]
+        new_index[k] = object_index
+        if object_index < 0:
+            negative_object_index -= 1
+    if scene_knowledge_prev:
+        for gt_label in labels_frozen:
+            if gt_label not in unique_objects:
+                missing_objects[gt_label] = scene_knowledge_prev["unique_objects"][gt_label]
+    if len(cls_h):
+        # the kernel numbered the objects -2 - k; re-identified objects carry their positive label index instead
+        lut = new_index.to(comp_idx.device)
+        voxel_obj_idx = torch.where(comp_idx < -1, lut[(-2 - comp_idx).clamp(min=0).long()], comp_idx)
+    else:
+        voxel_obj_idx = comp_idx
+    scene_knowledge = {"unique_objects": unique_objects, "object_counts": object_counts,
+                       "unchanged_objects": unchanged_objects, "new_objects": new_objects, "missing_objects": missing_objects}
+    return scene_knowledge, voxel_obj_idx
 
 
 class TextQueryEngine:
@@ -215,7 +288,7 @@ class TextQueryEngine:
 
     def clip_text_query_json(self, text: str):
         """The same answer already serialised (UTF-8 JSON bytes, or None): what app_unity.py:66-71 hands to jsonify, without
-        the detour through Python lists (io.mesh_to_json; the parsed result equals clip_text_query's dict for f32 meshes)."""
+        the detour through Python lists (io.mesh_to_json; vertices and faces parse to exactly clip_text_query's lists, the RGBA values -- float64 out of matplotlib -- are rounded to f32 first)."""
         from .io import mesh_to_json
 
         rel = self.relevance(text)

@@ -84,30 +84,37 @@ class _FusionVolumeMixin:
         self.__dict__.setdefault("defer_frames", True)  # queue small integrate() calls into 64-frame windows
         self.__dict__["_pending_n"] = 0
         self.__dict__["_stage"] = None
+        self.__dict__["_feat_stale"] = False
 
     # -- C structs -------------------------------------------------------------------------
-    def _c_volume(self):
+    def _c_volume(self, for_fuse=False):
+        """The saf_volume descriptor of the buffers.  ``for_fuse``: for the fuse kernels themselves -- neither the
+        queued frames nor the deferred clear (reset) are resolved first."""
+        if not for_fuse:
+            self._sync_volume()
+        b = self._buffers
         nx, ny, nz = (int(v) for v in self.nvox)
-        labels = getattr(self, "labels_one_hot", None)
-        require_cuda(self.clip_feat, "the fusion volume")
+        labels = b.get("labels_one_hot")
+        require_cuda(b["clip_feat"], "the fusion volume")
         for name in ("tsdf", "rgb", "clip_feat", "weight", "tsdf_weight"):
-            if not getattr(self, name).is_contiguous():
+            if not b[name].is_contiguous():
                 raise SafError(f"buffer {name} must be contiguous")
         p = _abi.ptr
         return _abi.SafVolume(
             nx, ny, nz, int(self.n_clip_feats), 0 if labels is None else int(labels.shape[1]),
-            _abi.SAF_BF16 if self.clip_feat.dtype == torch.bfloat16 else _abi.SAF_F32, int(self.accum_mode),
+            _abi.SAF_BF16 if b["clip_feat"].dtype == torch.bfloat16 else _abi.SAF_F32, int(self.accum_mode),
             float(self.trunc),
-            p(self.axis_x), p(self.axis_y), p(self.axis_z),
-            p(self.tsdf), p(self.tsdf_weight), p(self.weight), p(self.rgb), p(self.clip_feat), p(labels),
+            p(b["axis_x"]), p(b["axis_y"]), p(b["axis_z"]),
+            p(b["tsdf"]), p(b["tsdf_weight"]), p(b["weight"]), p(b["rgb"]), p(b["clip_feat"]), p(labels),
         )
 
     def _get_workspace(self, npy, npx):
-        n = self.tsdf.numel()
+        tsdf = self._buffers["tsdf"]
+        n = tsdf.numel()
         need = lib().saf_fuse_workspace_bytes(n, int(self.n_clip_feats), int(npy), int(npx))
         ws = self._workspace
-        if ws is None or ws.numel() < need or ws.device != self.tsdf.device:
-            ws = torch.empty(need, dtype=torch.uint8, device=self.tsdf.device)
+        if ws is None or ws.numel() < need or ws.device != tsdf.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=tsdf.device)
             self._workspace = ws
         return ws
 
@@ -169,7 +176,7 @@ class _FusionVolumeMixin:
     def _fuse(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False):
         bsz = int(depth_imgs.shape[0])
         if clip_feat_img.dim() != 4 or not self._defer_ok(bsz, clip_feat_img):
-            self.flush()
+            self._flush_pending()
             return self._fuse_now(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
         h, w = int(depth_imgs.shape[1]), int(depth_imgs.shape[2])
         if tuple(rgb_imgs.shape) != (bsz, h, w, 3):
@@ -189,7 +196,7 @@ class _FusionVolumeMixin:
         key = (h, w, tuple(int(v) for v in clip_feat_img.shape[1:]), label_maps is not None, bool(rgb_bilinear))
         st = self.__dict__.get("_stage")
         if st is None or st["key"] != key:
-            self.flush()
+            self._flush_pending()
             dev = self._buffers["tsdf"].device
             n = _abi.SAF_WINDOW_FRAMES
             mk = lambda *shape: torch.empty((n,) + shape, dtype=torch.float32, device=dev)
@@ -212,12 +219,26 @@ class _FusionVolumeMixin:
                     st["labels"][k].copy_(label_maps[i], non_blocking=True)
                 self.__dict__["_pending_n"] = k + 1
                 if k + 1 == _abi.SAF_WINDOW_FRAMES:
-                    self.flush()
+                    self._flush_pending()
 
     def flush(self):
-        """Fuse the frames queued behind integrate() (no-op when nothing is pending).  Readers of the volume never
-        need to call it -- every access to a registered buffer flushes -- it exists for callers that hold raw
-        pointers or tensors obtained earlier."""
+        """Bring the registered buffers up to date: fuse the frames queued behind integrate() and finish a deferred
+        clear (reset).  Readers of the volume never need to call it -- every access to a registered buffer does -- it
+        exists for callers that hold raw pointers or tensors obtained earlier."""
+        self._sync_volume()
+
+    def _sync_volume(self):
+        self._flush_pending()
+        if self.__dict__.get("_feat_stale"):
+            # reset() did not clear the feature rows: zero the ones that are still unwritten (weight 0)
+            self.__dict__["_feat_stale"] = False
+            vol = self._c_volume(for_fuse=True)
+            dev = self._buffers["tsdf"].device
+            with torch.cuda.device(dev):
+                check(lib().saf_clear_unwritten_rows(C.byref(vol), 0, self._buffers["tsdf"].numel(), current_stream_ptr()),
+                      "saf_clear_unwritten_rows")
+
+    def _flush_pending(self):
         n = self.__dict__.get("_pending_n", 0)
         if not n:
             return
@@ -236,30 +257,31 @@ class _FusionVolumeMixin:
 
     def __getattr__(self, name):
         # registered buffers live in _buffers, so every read of one comes through here
-        if name in _VOLUME_BUFFERS and self.__dict__.get("_pending_n", 0):
-            self.flush()
+        if name in _VOLUME_BUFFERS and (self.__dict__.get("_pending_n", 0) or self.__dict__.get("_feat_stale")):
+            self._sync_volume()
         return super().__getattr__(name)
 
     def __setattr__(self, name, value):
-        if (name in _VOLUME_BUFFERS or name == "accum_mode") and self.__dict__.get("_pending_n", 0):
-            self.flush()  # queued frames belong to the buffers / mode that were current when they were queued
+        if (name in _VOLUME_BUFFERS or name == "accum_mode") and (self.__dict__.get("_pending_n", 0) or self.__dict__.get("_feat_stale")):
+            self._sync_volume()  # queued frames belong to the buffers / mode that were current when they were queued
         super().__setattr__(name, value)
 
     def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .cpu() / .float()
-        self.flush()
+        if self.__dict__.get("_pending_n", 0) or self.__dict__.get("_feat_stale"):
+            self._sync_volume()
         self.__dict__["_stage"] = None
         return super()._apply(fn, *args, **kwargs)
 
     def _save_to_state_dict(self, *args, **kwargs):
-        self.flush()
+        self._sync_volume()
         return super()._save_to_state_dict(*args, **kwargs)
 
     def _load_from_state_dict(self, *args, **kwargs):
-        self.flush()
+        self._sync_volume()
         return super()._load_from_state_dict(*args, **kwargs)
 
     def named_buffers(self, *args, **kwargs):
-        self.flush()
+        self._sync_volume()
         return super().named_buffers(*args, **kwargs)
 
     def _fuse_now(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False):
@@ -269,13 +291,16 @@ class _FusionVolumeMixin:
                 f"{self._shard_range} of a merged job; all_gather it (merge_volumes(..., gather=True)) before fusing more frames"
             )
         arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
-        vol = self._c_volume()
+        vol = self._c_volume(for_fuse=True)
         ws = self._get_workspace(npy, npx)
+        if self.__dict__.get("_feat_stale") and lib().saf_fuse_path(C.byref(vol), arr, len(arr), ws.numel()) != 1:
+            # the per-frame pipeline reads every row it updates: the deferred clear has to happen first
+            self._sync_volume()
         # the module's device, not the caller's current one, owns the launch (and its current stream)
-        with torch.cuda.device(self.tsdf.device):
+        with torch.cuda.device(self._buffers["tsdf"].device):
             stream = torch.cuda.current_stream()
             rc = lib().saf_fuse_frames(
-                C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self.fuse_stats.data_ptr(), stream.cuda_stream
+                C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), stream.cuda_stream
             )
             check(rc, "saf_fuse_frames")
             # the launches are asynchronous: keep inputs alive until the stream has consumed them
@@ -285,16 +310,22 @@ class _FusionVolumeMixin:
                 t.record_stream(stream)
 
     # -- extensions (not in the reference) ---------------------------------------------------
-    def reset(self, accum_mode=_abi.SAF_RUNNING_MEAN):
+    def reset(self, accum_mode=_abi.SAF_RUNNING_MEAN, lazy=True):
         """Back to the freshly constructed state: every volume buffer zero (the reference builds a new module per
-        scan, clip_seem_fusion.py:291-302)."""
+        scan, clip_seem_fusion.py:291-302).  ``lazy``: the 4*D*N bytes of ``clip_feat`` are not cleared here -- a voxel
+        with weight 0 has a zero row by contract and the windowed fuse path never reads such rows; the rows still
+        unwritten are zeroed when something first looks (any buffer access, state_dict, the merge, flush())."""
         self.__dict__["_pending_n"] = 0  # frames still queued would be fused into a volume that is being discarded
-        for name in ("clip_feat", "rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot"):
-            t = self._buffers.get(name)
+        self.__dict__["_feat_stale"] = False
+        b = self._buffers
+        lazy = bool(lazy) and b["clip_feat"].is_cuda
+        for name in ("rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot") + (() if lazy else ("clip_feat",)):
+            t = b.get(name)
             if t is not None:
                 t.zero_()
-        self.accum_mode = accum_mode
+        super().__setattr__("accum_mode", accum_mode)
         self._shard_range = None
+        self.__dict__["_feat_stale"] = lazy
 
 
     def integrate_features(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None):

@@ -1023,6 +1023,12 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
 
 int saf_poll_async_error(void) { return poll_latch(); }
 
+int saf_fuse_path(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
+  KVol kv;
+  if (make_kvol(vol, &kv) || n_frames <= 0 || !frames) return -1;
+  return window_ok(kv, frames, n_frames, workspace_bytes) ? 1 : 0;
+}
+
 saf_profiler* saf_profiler_create(int32_t capacity_pairs) {
   if (capacity_pairs <= 0) return nullptr;
   saf_profiler* p = new saf_profiler;

@@ -222,6 +222,35 @@ __global__ __launch_bounds__(256) void sample_vertices_kernel(
 }
 
 
+// Rows of voxels that were never written (weight == 0) are zero by contract (include/saf.h, saf_volume).  A volume that
+// is recycled for a new scan need not be cleared up front -- the windowed fuse path never reads such rows -- as long as
+// the rows that are STILL unwritten are zeroed before anyone else looks: this kernel.  A wave checks 64 weights at a
+// time and writes zeros only where needed (after a 512-frame scan: almost nowhere).
+template <int ESZ>
+__global__ __launch_bounds__(256) void clear_unwritten_kernel(void* __restrict__ feat, const int* __restrict__ weight, int64_t first,
+                                                              int64_t count, int row_bytes) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i0 = wave * 64; i0 < count; i0 += n_waves * 64) {
+    const int64_t n = first + i0 + lane;
+    unsigned long long zero = __ballot(i0 + lane < count && weight[n] == 0);
+    while (zero) {
+      const int l = __ffsll((long long)zero) - 1;
+      zero &= zero - 1ull;
+      unsigned char* row = static_cast<unsigned char*>(feat) + (first + i0 + l) * (int64_t)row_bytes;
+      if ((row_bytes & 15) == 0) {
+        for (int o = lane * 16; o < row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(row + o) = make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        for (int o = lane * ESZ; o < row_bytes; o += 64 * ESZ) {
+          if (ESZ == 4) *reinterpret_cast<uint32_t*>(row + o) = 0u;
+          else *reinterpret_cast<uint16_t*>(row + o) = 0;
+        }
+      }
+    }
+  }
+}
+
 // ---- the tiled CLIP front-end in one pass (clipfusion.py:789-823) ----
 // normalize_img (:783-784), Unfold into overlapping p x p tiles at stride s (:797-804) and the bilinear resize of every
 // tile to 224 x 224 (:821-823, align_corners = False) fused: an output pixel reads its four source pixels straight from
@@ -355,6 +384,27 @@ int saf_clip_tiles(const float* rgb, int32_t batch, int32_t height, int32_t widt
     default: return fail(SAF_E_INVALID, "clip_tiles: bad out_dtype %d", out_dtype);
   }
   return check_launch("clip_tiles_kernel");
+}
+
+int saf_clear_unwritten_rows(const saf_volume* vol, int64_t first_voxel, int64_t n_rows, void* stream) {
+  if (!vol || !vol->clip_feat || !vol->weight) return fail(SAF_E_INVALID, "clear_unwritten_rows: volume has a NULL buffer");
+  const int64_t N = n_voxels(vol);
+  if (first_voxel < 0 || n_rows < 0 || first_voxel + n_rows > N) return fail(SAF_E_INVALID, "clear_unwritten_rows: bad voxel range");
+  if (n_rows == 0) return SAF_OK;
+  const int esz = vol->feat_dtype == SAF_F32 ? 4 : 2;
+  const int row_bytes = vol->feat_dim * esz;
+  int64_t blocks = (n_rows + 255) / 256;
+  const int64_t cap = (int64_t)device_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((uintptr_t)vol->clip_feat & 15) return fail(SAF_E_INVALID, "clear_unwritten_rows: clip_feat must be 16-byte aligned");
+  if (esz == 4)
+    hipLaunchKernelGGL(clear_unwritten_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, vol->clip_feat, vol->weight, first_voxel,
+                       n_rows, row_bytes);
+  else
+    hipLaunchKernelGGL(clear_unwritten_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, vol->clip_feat, vol->weight, first_voxel,
+                       n_rows, row_bytes);
+  return check_launch("clear_unwritten_kernel");
 }
 
 }  // extern "C"

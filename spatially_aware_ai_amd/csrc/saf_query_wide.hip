@@ -233,9 +233,6 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
 // keeps only the best query and its score per row (eval_scannet_segmentation.py:553-560, first label of the
 // argsort); QUERY_MAX keeps only the best row and its score per query.  The last two write no N x Q output.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kW2Threads = 256;
-constexpr int kW2Waves = 4;
-constexpr int kW2Rows = 64;  // feature rows per wave
 
 typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_stream_u4(const uint16_t* p) {  // the volume is read once: keep it out of the caches' way
@@ -279,73 +276,60 @@ struct Wide2Args {
 };
 
 // What the epilogue of a tile needs to know about the tile (it runs one step later, beside the next tile's MFMAs,
-// possibly after the workgroup has moved on to its next row block).
+// possibly after the workgroup has moved on to its next row block).  NF = 32-row fragments per wave.
+template <int NF>
 struct W2Tile {
-  float inv0, inv1;     // scale / row norm of the lane's two feature rows
-  int64_t row_a, row_b; // their true indices (may be >= n_rows on the last block)
-  int qt;               // query tile
+  float inv[NF];     // scale / row norm of the lane's feature rows
+  int64_t row[NF];   // their true indices (may be >= n_rows on the last block)
+  int qt;            // query tile
 };
 // per-row-block epilogue state (ROW_ARGMAX: running best; VS_BACKGROUND: log-sum-exp of the backgrounds)
+template <int NF>
 struct W2State {
-  float best_v0, best_v1, lse0, lse1;
-  int best_q0, best_q1;
+  float best_v[NF], lse[NF];
+  int best_q[NF];
 };
 
-template <int OT, int EPI>
-__device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t& c0, const f32x16_t& c1, const W2Tile& t,
-                                            W2State& st, int r, int h, int n_qt, bool vec_ok) {
-  // lane (r, h): feature rows row_a (c0) / row_b (c1); register 4 g + i holds query qt*32 + 8 g + 4 h + i
+template <int OT, int EPI, int NF>
+__device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t (&c)[NF], const W2Tile<NF>& t, W2State<NF>& st,
+                                            int r, int h, int n_qt, bool vec_ok) {
+  // lane (r, h): feature row t.row[f] in fragment f; register 4 g + i holds query qt*32 + 8 g + 4 h + i
   const int qbase = t.qt * kWTile + 4 * h;
   if (EPI == SAF_QW_SCORES || EPI == SAF_QW_VS_BACKGROUND) {
-    float v0[16], v1[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { v0[i] = c0[i] * t.inv0; v1[i] = c1[i] * t.inv1; }
-    int col0 = qbase;  // output column of register 0
-    bool write = true;
-    if (EPI == SAF_QW_VS_BACKGROUND) {
-      if (t.qt == 0) {  // tile 0 holds the backgrounds: per-row log-sum-exp of their scaled scores, no output
-        float m0 = -INFINITY, m1 = -INFINITY;
+    for (int f = 0; f < NF; ++f) {
+      float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const bool bg = 8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg;
-          m0 = bg ? fmaxf(m0, v0[i]) : m0;
-          m1 = bg ? fmaxf(m1, v1[i]) : m1;
-        }
-        m0 = fmaxf(m0, __shfl_xor(m0, 32));
-        m1 = fmaxf(m1, __shfl_xor(m1, 32));
-        float e0 = 0.f, e1 = 0.f;
+      for (int i = 0; i < 16; ++i) v[i] = c[f][i] * t.inv[f];
+      int col0 = qbase;  // output column of register 0
+      bool write = true;
+      if (EPI == SAF_QW_VS_BACKGROUND) {
+        if (t.qt == 0) {  // tile 0 holds the backgrounds: per-row log-sum-exp of their scaled scores, no output
+          float m = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const bool bg = 8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg;
-          e0 += bg ? __expf(v0[i] - m0) : 0.f;
-          e1 += bg ? __expf(v1[i] - m1) : 0.f;
-        }
-        e0 += __shfl_xor(e0, 32);
-        e1 += __shfl_xor(e1, 32);
-        st.lse0 = m0 + __logf(e0);
-        st.lse1 = m1 + __logf(e1);
-        write = false;
-      } else {
-        // softmax([bg..., target])[-1] = 1 / (1 + exp(lse_bg - z_target))
-        const bool rescale = (wa.flags & 1) != 0;  // query_mesh.py:39: ((r - 0.5) * 2).clamp(0, 1)
+          for (int i = 0; i < 16; ++i) m = (8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg) ? fmaxf(m, v[i]) : m;
+          m = fmaxf(m, __shfl_xor(m, 32));
+          float e = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float p0 = __builtin_amdgcn_rcpf(1.0f + __expf(st.lse0 - v0[i])), p1 = __builtin_amdgcn_rcpf(1.0f + __expf(st.lse1 - v1[i]));
-          if (rescale) {
-            p0 = fminf(fmaxf((p0 - 0.5f) * 2.0f, 0.0f), 1.0f);
-            p1 = fminf(fmaxf((p1 - 0.5f) * 2.0f, 0.0f), 1.0f);
+          for (int i = 0; i < 16; ++i) e += (8 * (i >> 2) + 4 * h + (i & 3) < wa.n_bg) ? __expf(v[i] - m) : 0.f;
+          e += __shfl_xor(e, 32);
+          st.lse[f] = m + __logf(e);
+          write = false;
+        } else {
+          // softmax([bg..., target])[-1] = 1 / (1 + exp(lse_bg - z_target))
+          const bool rescale = (wa.flags & 1) != 0;  // query_mesh.py:39: ((r - 0.5) * 2).clamp(0, 1)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float p = __builtin_amdgcn_rcpf(1.0f + __expf(st.lse[f] - v[i]));
+            if (rescale) p = fminf(fmaxf((p - 0.5f) * 2.0f, 0.0f), 1.0f);
+            v[i] = p;
           }
-          v0[i] = p0; v1[i] = p1;
+          col0 = qbase - kWTile;
         }
-        col0 = qbase - kWTile;
       }
-    }
-    if (write) {
-      const int ncols = EPI == SAF_QW_VS_BACKGROUND ? wa.Q - kWTile : wa.Q;
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const float* v = f ? v1 : v0;
-        const int64_t row = f ? t.row_b : t.row_a;
+      if (write) {
+        const int ncols = EPI == SAF_QW_VS_BACKGROUND ? wa.Q - kWTile : wa.Q;
+        const int64_t row = t.row[f];
         if (OT == SAF_F32) {
           if (row < wa.n_rows) {
 #pragma unroll
@@ -389,162 +373,213 @@ __device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t&
       }
     }
   } else if (EPI == SAF_QW_ROW_ARGMAX) {
-    if (t.qt == 0) {
-      st.best_v0 = st.best_v1 = -INFINITY;
-      st.best_q0 = st.best_q1 = 0;
-    }
     const bool last = t.qt == n_qt - 1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int q = qbase + 8 * (i >> 2) + (i & 3);
-      float x0 = c0[i] * t.inv0, x1 = c1[i] * t.inv1;
-      if (last && q >= wa.Q) { x0 = -INFINITY; x1 = -INFINITY; }  // zero-padded text rows are no candidates
-      if (x0 > st.best_v0) { st.best_v0 = x0; st.best_q0 = q; }  // queries ascend: the first maximum stays
-      if (x1 > st.best_v1) { st.best_v1 = x1; st.best_q1 = q; }
-    }
-    if (last) {
-      // both halves of a row: the larger score, the smaller query on ties
-      const float ov0 = __shfl_xor(st.best_v0, 32), ov1 = __shfl_xor(st.best_v1, 32);
-      const int oq0 = __shfl_xor(st.best_q0, 32), oq1 = __shfl_xor(st.best_q1, 32);
-      if (ov0 > st.best_v0 || (ov0 == st.best_v0 && oq0 < st.best_q0)) { st.best_v0 = ov0; st.best_q0 = oq0; }
-      if (ov1 > st.best_v1 || (ov1 == st.best_v1 && oq1 < st.best_q1)) { st.best_v1 = ov1; st.best_q1 = oq1; }
-      if (h == 0) {
-        if (t.row_a < wa.n_rows) { wa.out_index[t.row_a] = st.best_q0; wa.out_value[t.row_a] = st.best_v0; }
-        if (t.row_b < wa.n_rows) { wa.out_index[t.row_b] = st.best_q1; wa.out_value[t.row_b] = st.best_v1; }
+    for (int f = 0; f < NF; ++f) {
+      float bv = t.qt == 0 ? -INFINITY : st.best_v[f];
+      int bq = t.qt == 0 ? 0 : st.best_q[f];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int q = qbase + 8 * (i >> 2) + (i & 3);
+        float x = c[f][i] * t.inv[f];
+        if (last && q >= wa.Q) x = -INFINITY;  // zero-padded text rows are no candidates
+        if (x > bv) { bv = x; bq = q; }        // queries ascend: the first maximum stays
       }
+      if (last) {
+        // both halves of a row: the larger score, the smaller query on ties
+        const float ov = __shfl_xor(bv, 32);
+        const int oq = __shfl_xor(bq, 32);
+        if (ov > bv || (ov == bv && oq < bq)) { bv = ov; bq = oq; }
+        if (h == 0 && t.row[f] < wa.n_rows) { wa.out_index[t.row[f]] = bq; wa.out_value[t.row[f]] = bv; }
+      }
+      st.best_v[f] = bv;
+      st.best_q[f] = bq;
     }
-  } else {  // SAF_QW_QUERY_MAX: the best of the wave's 64 rows per query, one atomic per query and wave
+  } else {  // SAF_QW_QUERY_MAX: the best of the wave's rows per query, one atomic per query and wave
     const bool last = t.qt == n_qt - 1;
-    const bool ok_a = t.row_a < wa.n_rows, ok_b = t.row_b < wa.n_rows;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int q = qbase + 8 * (i >> 2) + (i & 3);
-      const float x0 = ok_a ? c0[i] * t.inv0 : -INFINITY, x1 = ok_b ? c1[i] * t.inv1 : -INFINITY;
-      float m = fmaxf(x0, x1);
+      float x[NF];
+      float m = -INFINITY;
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));  // every lane of the half: the 64 rows' maximum
-      // the smallest row that reaches it: fragment a (rows row0 + r) before fragment b (rows row0 + 32 + r)
-      const unsigned long long ba = __ballot(x0 == m), bb = __ballot(x1 == m);
-      const uint32_t ha = (uint32_t)(ba >> (32 * h)), hb = (uint32_t)(bb >> (32 * h));
-      const uint32_t slot = ha ? (uint32_t)__ffs((int)ha) - 1u : 32u + (uint32_t)__ffs((int)hb) - 1u;
+      for (int f = 0; f < NF; ++f) {
+        x[f] = t.row[f] < wa.n_rows ? c[f][i] * t.inv[f] : -INFINITY;
+        m = fmaxf(m, x[f]);
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));  // every lane of the half: the wave's maximum
+      // the smallest row that reaches it: fragment 0 (rows row0 + r) before fragment 1 (rows row0 + 32 + r)
+      uint32_t slot = 0xffffffffu;
+#pragma unroll
+      for (int f = NF - 1; f >= 0; --f) {
+        const uint32_t hb = (uint32_t)(__ballot(x[f] == m) >> (32 * h));
+        slot = hb ? 32u * f + (uint32_t)__ffs((int)hb) - 1u : slot;
+      }
       if (r == 0 && !(last && q >= wa.Q) && m > -INFINITY) {
-        const uint32_t row = (uint32_t)(t.row_a + wa.row_offset) + slot;  // row_a of lane r = 0 is the wave's first row
+        const uint32_t row = (uint32_t)(t.row[0] + wa.row_offset) + slot;  // row[0] of lane r = 0 is the wave's first row
         atomicMax(&wa.qkeys[q], ((unsigned long long)ordered_bits(m) << 32) | (uint32_t)~row);
       }
     }
   }
 }
 
-template <int FT, int OT, int KS, int EPI>
-__global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1))) void query_wide2_kernel(Wide2Args wa) {
+// The same epilogue cut into pieces that sit BETWEEN the MFMAs of the next tile.  A wave issues in order: a block of
+// epilogue instructions in front of the MFMA block costs its full issue time on top of the matrix pipe's, while six
+// vector instructions fit in the shadow of every v_mfma_f32_32x32x16 (8 of its 32 cycles hold the issue port).  So for
+// interior tiles -- every row of the wave valid, aligned output, all 32 columns real: a wave-uniform condition -- the
+// previous tile's accumulator register i is finished right after MFMA step i * KS / 16 of the current tile, branch-free.
+// `w2_fast_piece(i)` does register i of every fragment; stores go out after registers 7 and 15 (8 scores per lane each).
+template <int NF>
+struct W2Fast {
+  float v[NF][16];                 // scaled scores / probabilities of the previous tile (SCORES, VS_BACKGROUND)
+  unsigned long long qk[16];       // QUERY_MAX: per register, the wave's best (ordered score, ~row) for lane r = 0
+};
+
+template <int OT, int EPI, int NF>
+__device__ __forceinline__ void w2_fast_piece(int i, const Wide2Args& wa, const f32x16_t (&c)[NF], const W2Tile<NF>& t,
+                                              W2State<NF>& st, W2Fast<NF>& fs, int r, int h, int n_qt) {
+  const int qbase = t.qt * kWTile + 4 * h;
+  if (EPI == SAF_QW_SCORES || EPI == SAF_QW_VS_BACKGROUND) {
+    const bool rescale = (wa.flags & 1) != 0;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      float x = c[f][i] * t.inv[f];
+      if (EPI == SAF_QW_VS_BACKGROUND) {
+        float p = __builtin_amdgcn_rcpf(1.0f + __expf(st.lse[f] - x));
+        const float pr = fminf(fmaxf((p - 0.5f) * 2.0f, 0.0f), 1.0f);
+        x = rescale ? pr : p;
+      }
+      fs.v[f][i] = x;
+      if ((i & 7) == 7) {  // registers 8 gp .. 8 gp + 7 are complete: this lane's 8 columns of the pair of groups gp
+        const int gp = i >> 3;
+        const int col0 = EPI == SAF_QW_VS_BACKGROUND ? qbase - kWTile : qbase;
+        const float* v = fs.v[f];
+        if (OT == SAF_F32) {
+          float* o = static_cast<float*>(wa.out) + t.row[f] * wa.ostride + col0 + 16 * gp;
+          *reinterpret_cast<float4*>(o) = make_float4(v[8 * gp], v[8 * gp + 1], v[8 * gp + 2], v[8 * gp + 3]);
+          *reinterpret_cast<float4*>(o + 8) = make_float4(v[8 * gp + 4], v[8 * gp + 5], v[8 * gp + 6], v[8 * gp + 7]);
+        } else {
+          uint2 lo = pack4_16<OT>(v[8 * gp], v[8 * gp + 1], v[8 * gp + 2], v[8 * gp + 3]);
+          uint2 hi = pack4_16<OT>(v[8 * gp + 4], v[8 * gp + 5], v[8 * gp + 6], v[8 * gp + 7]);
+          auto rx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+          auto ry = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+          uint16_t* o = static_cast<uint16_t*>(wa.out) + t.row[f] * wa.ostride + (col0 - 4 * h) + 16 * gp + 8 * h;
+          *reinterpret_cast<uint4*>(o) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        }
+      }
+    }
+  } else if (EPI == SAF_QW_ROW_ARGMAX) {
+    const int q = qbase + 8 * (i >> 2) + (i & 3);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const float x = c[f][i] * t.inv[f];
+      const bool better = x > st.best_v[f];  // queries ascend: the first maximum stays
+      st.best_v[f] = better ? x : st.best_v[f];
+      st.best_q[f] = better ? q : st.best_q[f];
+    }
+  } else {  // SAF_QW_QUERY_MAX
+    float x[NF];
+    float m = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      x[f] = c[f][i] * t.inv[f];
+      m = fmaxf(m, x[f]);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    uint32_t slot = 0xffffffffu;
+#pragma unroll
+    for (int f = NF - 1; f >= 0; --f) {
+      const uint32_t hb = (uint32_t)(__ballot(x[f] == m) >> (32 * h));
+      slot = hb ? 32u * f + (uint32_t)__ffs((int)hb) - 1u : slot;
+    }
+    const uint32_t row = (uint32_t)(t.row[0] - r + wa.row_offset) + slot;  // row[0] - r: the wave's first row
+    fs.qk[i] = ((unsigned long long)ordered_bits(m) << 32) | (uint32_t)~row;
+  }
+}
+
+// NF = 2: 64 rows per wave, 4 waves per workgroup, one wave per SIMD (the whole 512-register file);
+// NF = 1: 32 rows per wave, 8 waves per workgroup, two waves per SIMD (the two interleave on the matrix pipe by themselves).
+// TH = threads per workgroup: 512 (one workgroup per CU) or, for NF = 1, 256 (two independent workgroups per CU: while
+// one waits at its barrier or loads its next rows, the other one has the matrix pipes).
+template <int FT, int OT, int KS, int EPI, int NF, int TH>
+__global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(NF == 2 ? 1 : 2, NF == 2 ? 1 : 2))) void
+query_wide2_kernel(Wide2Args wa) {
+  constexpr int kThreads = TH, kWaves = kThreads / 64, kRows = 32 * NF;
   constexpr int D = KS * 16;
   constexpr int ROWB = D * 2 + 16;  // padded LDS row in bytes: the 16 lanes of a ds_read_b128 group hit distinct bank quads
-#ifdef SAF_W2_NO_DMA
-  constexpr bool kDma = false;
-#else
   constexpr bool kDma = (D == 512);  // a text row is exactly one 1 KiB LDS-DMA piece
-#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char s_tiles[];  // 2 x [32][ROWB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n_qt = wa.Qpad / kWTile;
-  const int64_t rows_per_wg = (int64_t)kW2Waves * kW2Rows;
+  const int64_t rows_per_wg = (int64_t)kWaves * kRows;
   const int64_t n_blocks = (wa.n_rows + rows_per_wg - 1) / rows_per_wg;
   const int64_t my_blocks = blockIdx.x < n_blocks ? (n_blocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   const int64_t n_steps = my_blocks * n_qt;  // (row block, query tile) pairs of this workgroup, in order
   if (n_steps == 0) return;
   constexpr int PIECES = kWTile * (D / 8);
-  constexpr int PPT = (PIECES + kW2Threads - 1) / kW2Threads;
+  constexpr int PPT = (PIECES + kThreads - 1) / kThreads;
   const bool vec_ok = (wa.ostride % 8 == 0) && (((uintptr_t)wa.out & 15) == 0);
 
-  for (int p = tid; p < PIECES; p += kW2Threads) {  // tile 0 of the first block
+  for (int p = tid; p < PIECES; p += kThreads) {  // tile 0 of the first block
     const int q = p / (D / 8), c = p - q * (D / 8);
     *reinterpret_cast<uint4*>(s_tiles + q * ROWB + c * 16) = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)q * D + c * 8);
   }
 
-  uint4 a0[KS], a1[KS];
-  W2Tile cur, prev;
-  W2State st;
-  st.best_v0 = st.best_v1 = -INFINITY; st.best_q0 = st.best_q1 = 0; st.lse0 = st.lse1 = 0.f;
-  cur.inv0 = cur.inv1 = 0.f; cur.row_a = cur.row_b = 0; cur.qt = 0;
-  prev = cur;
-  f32x16_t acc[2][2];  // [step parity][fragment]: the tile being accumulated and the previous one awaiting its epilogue
-
-  // the 64 rows per wave of row block `bi` of this workgroup: addresses of the lane's two rows
-  auto block_rows = [&](int64_t bi, int64_t& row_a, int64_t& row_b, const uint16_t*& pa, const uint16_t*& pb) {
-    const int64_t blk = blockIdx.x + bi * gridDim.x;
-    const int64_t row0 = (blk * kW2Waves + wave) * kW2Rows;
-    row_a = row0 + r;
-    row_b = row0 + 32 + r;
-    const int64_t ra = row_a < wa.n_rows ? row_a : wa.n_rows - 1, rb = row_b < wa.n_rows ? row_b : wa.n_rows - 1;
-    pa = wa.feats + ra * wa.fstride + 8 * h;
-    pb = wa.feats + rb * wa.fstride + 8 * h;
-  };
-  {  // the first block's rows
-    const uint16_t *pa, *pb;
-    block_rows(0, cur.row_a, cur.row_b, pa, pb);
+  uint4 a[NF][KS];
+  W2Tile<NF> cur, prev;
+  W2State<NF> st;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      a0[s] = ld_stream_u4(pa + 16 * s);
-      a1[s] = ld_stream_u4(pb + 16 * s);
-    }
+  for (int f = 0; f < NF; ++f) {
+    st.best_v[f] = -INFINITY; st.best_q[f] = 0; st.lse[f] = 0.f;
+    cur.inv[f] = 0.f; cur.row[f] = 0;
   }
-#ifndef SAF_W2_NO_STAGGER
-  // Every workgroup runs the same schedule, so without this they would all reach their row-block switch -- a burst of
-  // 256 KiB of feature rows per workgroup with no MFMA beside it -- at the same moment: HBM idle for a block, then
-  // asked for 64 MiB at once.  Sixteen start phases spread the switches over the block time (the price: at most one
-  // block time of sleep at the start of the kernel, well under a percent).
-  {
-    const int phase = blockIdx.x & 15;
-    for (int k = 0; k < phase; ++k) __builtin_amdgcn_s_sleep(127);  // ~8 k cycles (4 us) each: 16 phases ~ one block time
-  }
-#endif
+  cur.qt = 0;
+  prev = cur;
+  f32x16_t acc[2][NF];  // [step parity][fragment]: the tile being accumulated and the previous one awaiting its epilogue
 
   // One step = one (row block, query tile) pair.  In program order: barrier (tile in LDS) -> transfer of the next tile
-  // issued -> the first 16 text fragments requested -> the PREVIOUS tile's epilogue (vector work and stores that do not
-  // depend on what follows) -> 64 MFMAs, each pair consuming one fragment and requesting the one 16 steps ahead (the
-  // LDS counter tracks 15 outstanding reads).  In the LAST tile of a row block every MFMA pair is followed by the loads
-  // of the next block's rows into the registers it has just read for the last time.
-  auto step_body = [&](int64_t step, f32x16_t& c0, f32x16_t& c1, const f32x16_t& p0, const f32x16_t& p1) {
+  // issued -> the first text fragments requested -> the PREVIOUS tile's epilogue (vector work and stores that do not
+  // depend on what follows) -> the MFMAs, each group consuming one fragment and requesting the one AHEAD steps ahead.
+  auto step_body = [&](int64_t step, f32x16_t (&c)[NF], const f32x16_t (&pc)[NF]) {
     const int qt = (int)(step % n_qt);
-    const int64_t bi = step / n_qt;
-    if (qt == 0) {  // a new row block: its rows are in a0 / a1 (loaded above, or behind the last block's MFMAs)
-#ifdef SAF_W2_NO_PREFETCH
-      if (bi > 0) {
-        const uint16_t *pa, *pb;
-        block_rows(bi, cur.row_a, cur.row_b, pa, pb);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          a0[s] = ld_stream_u4(pa + 16 * s);
-          a1[s] = ld_stream_u4(pb + 16 * s);
-        }
-      }
+#ifdef SAF_W2_NO_FEATLOAD  // (development switches: timing only, wrong results)
+    if (step == 0) {
+#else
+    if (qt == 0) {  // a new row block: its rows per wave, register resident for every query tile
 #endif
-      cur.inv0 = cur.inv1 = wa.scale;
-      if (wa.normalize) {
-        float ss0 = 0.f, ss1 = 0.f;
+      const int64_t blk = blockIdx.x + (step / n_qt) * gridDim.x;
+      const int64_t row0 = (blk * kWaves + wave) * kRows;
+      float ss[NF];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const uint32_t w0[4] = {a0[s].x, a0[s].y, a0[s].z, a0[s].w};
-          const uint32_t w1[4] = {a1[s].x, a1[s].y, a1[s].z, a1[s].w};
+      for (int f = 0; f < NF; ++f) {
+        cur.row[f] = row0 + 32 * f + r;
+        const int64_t rr = cur.row[f] < wa.n_rows ? cur.row[f] : wa.n_rows - 1;  // padded lanes recompute the last row
+        const uint16_t* pa = wa.feats + rr * wa.fstride + 8 * h;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float lo = elem16_to_f32<FT>((uint16_t)(w0[j] & 0xffffu)), hi = elem16_to_f32<FT>((uint16_t)(w0[j] >> 16));
-            ss0 = __builtin_fmaf(lo, lo, ss0);
-            ss0 = __builtin_fmaf(hi, hi, ss0);
-            lo = elem16_to_f32<FT>((uint16_t)(w1[j] & 0xffffu)); hi = elem16_to_f32<FT>((uint16_t)(w1[j] >> 16));
-            ss1 = __builtin_fmaf(lo, lo, ss1);
-            ss1 = __builtin_fmaf(hi, hi, ss1);
+        for (int s = 0; s < KS; ++s) a[f][s] = ld_stream_u4(pa + 16 * s);
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        cur.inv[f] = wa.scale;
+        ss[f] = 0.f;
+        if (wa.normalize) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const uint32_t w[4] = {a[f][s].x, a[f][s].y, a[f][s].z, a[f][s].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = elem16_to_f32<FT>((uint16_t)(w[j] & 0xffffu)), hi = elem16_to_f32<FT>((uint16_t)(w[j] >> 16));
+              ss[f] = __builtin_fmaf(lo, lo, ss[f]);
+              ss[f] = __builtin_fmaf(hi, hi, ss[f]);
+            }
           }
-        }
-        ss0 += __shfl_xor(ss0, 32);
-        ss1 += __shfl_xor(ss1, 32);
-        if (wa.normalize == SAF_NORM_L2_CLAMP) {
-          cur.inv0 = wa.scale / fmaxf(sqrtf(ss0), 0.1f);
-          cur.inv1 = wa.scale / fmaxf(sqrtf(ss1), 0.1f);
-        } else {  // SAF_NORM_L2 with nan_to_num: an all-zero row scores 0
-          cur.inv0 = ss0 > 0.0f ? wa.scale / sqrtf(ss0) : 0.0f;
-          cur.inv1 = ss1 > 0.0f ? wa.scale / sqrtf(ss1) : 0.0f;
+          ss[f] += __shfl_xor(ss[f], 32);
+          // SAF_NORM_L2_CLAMP: norm.clamp_min(0.1); SAF_NORM_L2 with nan_to_num: an all-zero row scores 0
+          cur.inv[f] = wa.normalize == SAF_NORM_L2_CLAMP ? wa.scale / fmaxf(sqrtf(ss[f]), 0.1f)
+                                                         : (ss[f] > 0.0f ? wa.scale / sqrtf(ss[f]) : 0.0f);
         }
       }
     }
@@ -552,16 +587,22 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     const unsigned char* curb = s_tiles + (size_t)(step & 1) * kWTile * ROWB;
     unsigned char* nxt = s_tiles + (size_t)((step + 1) & 1) * kWTile * ROWB;
     // this tile's text is in LDS (its transfer was issued a step ago) and every wave is done reading the other buffer
+#ifndef SAF_W2_NO_BARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
+#ifdef SAF_W2_NO_TEXTLOAD
+    const bool more = false;
+#else
     const bool more = step + 1 < n_steps;
+#endif
     const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
     uint4 stage[kDma ? 1 : PPT];
     if (more) {
       if (kDma) {
 #pragma unroll
-        for (int k = 0; k < kWTile / kW2Waves; ++k) {
-          const int q = wave * (kWTile / kW2Waves) + k;
+        for (int k = 0; k < kWTile / kWaves; ++k) {
+          const int q = wave * (kWTile / kWaves) + k;
           const uint16_t* src = wa.text16 + (int64_t)(qt_next * kWTile + q) * D + lane * 8;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)(nxt + q * ROWB), 16, 0, 0);
@@ -569,83 +610,83 @@ __global__ __launch_bounds__(kW2Threads) __attribute__((amdgpu_waves_per_eu(1, 1
       } else {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-          const int p = tid + k * kW2Threads;
+          const int p = tid + k * kThreads;
           if (p < PIECES) {
-            const int q = p / (D / 8), c = p - q * (D / 8);
-            stage[k] = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)(qt_next * kWTile + q) * D + c * 8);
+            const int q = p / (D / 8), cc = p - q * (D / 8);
+            stage[k] = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)(qt_next * kWTile + q) * D + cc * 8);
           }
         }
       }
     }
-#ifdef SAF_W2_AHEAD_ALL
-    constexpr int AHEAD = KS;  // every fragment requested up front (the earlier form)
-#else
-    constexpr int AHEAD = KS < 16 ? KS : 16;
+#ifndef SAF_W2_AHEAD
+#define SAF_W2_AHEAD 8
 #endif
+    constexpr int AHEAD = KS < SAF_W2_AHEAD ? KS : SAF_W2_AHEAD;
     uint4 t[KS];
     const unsigned char* trow = curb + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) t[s] = *reinterpret_cast<const uint4*>(trow + 32 * s);
-    if (step > 0) w2_epilogue<OT, EPI>(wa, p0, p1, prev, st, r, h, n_qt, vec_ok);
+    // Is the previous tile an interior one (wave-uniform)?  Then its epilogue rides between this tile's MFMAs.
+    bool fast = step > 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
-#ifdef SAF_W2_NO_PREFETCH
-    const bool switch_rows = false;
-    if (qt == n_qt - 1 && bi + 1 < my_blocks) {}
-#else
-    const bool switch_rows = qt == n_qt - 1 && bi + 1 < my_blocks;
+    for (int f = 0; f < NF; ++f) fast = fast && __all(prev.row[f] < wa.n_rows);
+    if (EPI == SAF_QW_SCORES) fast = fast && vec_ok && (prev.qt + 1) * kWTile <= wa.Q;
+    if (EPI == SAF_QW_VS_BACKGROUND) fast = fast && vec_ok && prev.qt > 0 && (prev.qt + 1) * kWTile <= wa.Q;
+    if (EPI == SAF_QW_ROW_ARGMAX) fast = fast && prev.qt > 0 && prev.qt < n_qt - 1;  // first / last tile: reset / write-out
+    if (EPI == SAF_QW_QUERY_MAX) fast = fast && (prev.qt + 1) * kWTile <= wa.Q;
+#ifdef SAF_W2_NO_FAST
+    fast = false;
 #endif
-    if (!switch_rows) {
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!fast) {
+      if (step > 0) w2_epilogue<OT, EPI, NF>(wa, pc, prev, st, r, h, n_qt, vec_ok);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        c0 = mfma16<FT>(t[s], a0[s], c0);  // C[query][feature row]
-        c1 = mfma16<FT>(t[s], a1[s], c1);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) c[f] = mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);  // C[query][feature row]
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + 32 * (s + AHEAD));
-#ifndef SAF_W2_NO_SCHEDBAR
-        __builtin_amdgcn_sched_barrier(0);
-#endif
       }
     } else {
-      const uint16_t *pa, *pb;
-      int64_t na, nb;
-      block_rows(bi + 1, na, nb, pa, pb);
+      W2Fast<NF> fs;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        c0 = mfma16<FT>(t[s], a0[s], c0);
-        c1 = mfma16<FT>(t[s], a1[s], c1);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) c[f] = mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + 32 * (s + AHEAD));
-        a0[s] = ld_stream_u4(pa + 16 * s);  // the next block's rows, behind this block's last use of the registers
-        a1[s] = ld_stream_u4(pb + 16 * s);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = (s * 16) / KS; i < ((s + 1) * 16) / KS; ++i) w2_fast_piece<OT, EPI, NF>(i, wa, pc, prev, st, fs, r, h, n_qt);
+        __builtin_amdgcn_sched_barrier(0);  // keep the pieces where they are: between the MFMAs
       }
-      prev = cur;  // (the epilogue of this tile still describes the old block)
-      cur.row_a = na;
-      cur.row_b = nb;
+      if (EPI == SAF_QW_QUERY_MAX) {
+        if (r == 0) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) atomicMax(&wa.qkeys[prev.qt * kWTile + 4 * h + 8 * (i >> 2) + (i & 3)], fs.qk[i]);
+        }
+      }
     }
     if (more && !kDma) {
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
-        const int p = tid + k * kW2Threads;
+        const int p = tid + k * kThreads;
         if (p < PIECES) {
-          const int q = p / (D / 8), c = p - q * (D / 8);
-          *reinterpret_cast<uint4*>(nxt + q * ROWB + c * 16) = stage[k];
+          const int q = p / (D / 8), cc = p - q * (D / 8);
+          *reinterpret_cast<uint4*>(nxt + q * ROWB + cc * 16) = stage[k];
         }
       }
     }
-    if (!switch_rows) prev = cur;
+    prev = cur;
   };
 
-  __syncthreads();  // tile 0 of the first block is in LDS
   int64_t step = 0;
   for (; step + 1 < n_steps; step += 2) {
-    step_body(step, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
-    step_body(step + 1, acc[1][0], acc[1][1], acc[0][0], acc[0][1]);
+    step_body(step, acc[0], acc[1]);
+    step_body(step + 1, acc[1], acc[0]);
   }
   if (step < n_steps) {
-    step_body(step, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
-    w2_epilogue<OT, EPI>(wa, acc[0][0], acc[0][1], prev, st, r, h, n_qt, vec_ok);
+    step_body(step, acc[0], acc[1]);
+    w2_epilogue<OT, EPI, NF>(wa, acc[0], prev, st, r, h, n_qt, vec_ok);
   } else {
-    w2_epilogue<OT, EPI>(wa, acc[1][0], acc[1][1], prev, st, r, h, n_qt, vec_ok);
+    w2_epilogue<OT, EPI, NF>(wa, acc[1], prev, st, r, h, n_qt, vec_ok);
   }
 }
 
@@ -699,21 +740,30 @@ int launch_wide_ot(int ot, int D, const uint16_t* feats, int64_t n_rows, int64_t
   }
 }
 
-template <int FT, int OT, int KS, int EPI>
-int launch_wide2(const Wide2Args& wa, hipStream_t s) {
+template <int FT, int OT, int KS, int EPI, int NF, int TH>
+int launch_wide2_nf(const Wide2Args& wa, hipStream_t s) {
   constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16);
-  auto fn = query_wide2_kernel<FT, OT, KS, EPI>;
+  auto fn = query_wide2_kernel<FT, OT, KS, EPI, NF, TH>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)shmem);
     if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const int64_t rows_per_wg = (int64_t)kW2Waves * kW2Rows;
+  const int64_t rows_per_wg = (TH / 64) * 32 * NF;
   int64_t blocks = (wa.n_rows + rows_per_wg - 1) / rows_per_wg;
-  const int64_t cap = device_cus();  // persistent: one workgroup (4 waves, one per SIMD) per CU
+  const int64_t cap = (int64_t)device_cus() * (NF == 1 && TH == 256 ? 2 : 1);  // persistent: one or two workgroups per CU
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kW2Threads), shmem, s, wa);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(TH), shmem, s, wa);
   return check_launch("query_wide2_kernel");
+}
+
+// SAF_WIDE_ROWS=32 / 64 in the environment picks the geometry (development; the default is the measured-faster one)
+template <int FT, int OT, int KS, int EPI>
+int launch_wide2(const Wide2Args& wa, hipStream_t s) {
+  static const int rows_env = getenv("SAF_WIDE_ROWS") ? atoi(getenv("SAF_WIDE_ROWS")) : 0;
+  if (rows_env == 64) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
+  if (rows_env == 33) return launch_wide2_nf<FT, OT, KS, EPI, 1, 256>(wa, s);  // 32 rows per wave, two workgroups per CU
+  return launch_wide2_nf<FT, OT, KS, EPI, 1, 512>(wa, s);
 }
 
 template <int FT, int KS>

@@ -170,3 +170,48 @@ def test_hip_components_edge_cases_and_objects(oracle):
         x, y, z = o["voxels"][0]
         assert (x * 10 + y) * 14 + z == int(o_first[k])
         assert oid == f"{names[o['class_id']]}:{oid.split(':')[1]}"
+
+
+@pytest.mark.gpu
+def test_repeat_scan_bookkeeping_matches_reference_goldens():
+    """The in-situ-model half of flood_fill_3d (handy_utils.py:396-452, :455-478) from the reference's own run with a
+    stub model (the DGCNN classifier is not in the snapshot): re-identified objects take the user's label and a positive
+    voxel index, the others running negative ones; unchanged / missing lists; labels appended to the model."""
+    from spatially_aware_ai_amd import discover_objects
+
+    class Trained:
+        def __init__(self):
+            self.labels = ["null", "class1:1", "my lamp", "sofa merged"]
+            self.model_trained = True
+            self.seen = []
+
+        def predict(self, all_features):
+            f = all_features[0]
+            self.seen.append((tuple(f["clip_feats"].shape), tuple(f["rgb"].shape)))
+            n = len(f["voxels"])
+            return n % 4 if n % 4 in (1, 2, 3) and n % 3 != 0 else 0
+
+    g, _ = _golden_cases()
+    for c in range(3):
+        lab = torch.from_numpy(g[f"c{c}_labels"]).cuda()
+        shape = tuple(lab.shape)
+        model = Trained()
+        prev = {"unique_objects": {l: {"was": l} for l in model.labels[1:]}}
+        feats = torch.from_numpy(np.random.default_rng(int([21, 22, 23][c])).random(shape + (2,)).astype(np.float32)).cuda()
+        rgb = torch.from_numpy(np.random.default_rng(int([21, 22, 23][c]) + 1).random(shape + (3,)).astype(np.float32)).cuda()
+        know, ids = discover_objects(lab, [str(s) for s in g[f"c{c}_class_names"]], insitu_model=model, voxel_clip_feats=feats,
+                                     voxel_rgb=rgb, scene_knowledge_prev=prev)
+        objs = know["unique_objects"]
+        assert np.array_equal(ids.cpu().numpy(), g[f"r{c}_voxel_obj_ids"]), f"case {c}: voxel_obj_ids"
+        assert list(objs.keys()) == [str(s) for s in g[f"r{c}_ids"]]
+        assert [o["object_index"] for o in objs.values()] == g[f"r{c}_object_index"].tolist()
+        assert [o["class_label"] for o in objs.values()] == [str(s) for s in g[f"r{c}_class_label"]]
+        assert [o["user_modified"] for o in objs.values()] == g[f"r{c}_user_modified"].tolist()
+        assert [o["merged"] for o in objs.values()] == g[f"r{c}_merged"].tolist()
+        assert list(know["unchanged_objects"].keys()) == [str(s) for s in g[f"r{c}_unchanged"]]
+        assert list(know["missing_objects"].keys()) == [str(s) for s in g[f"r{c}_missing"]]
+        assert model.labels == [str(s) for s in g[f"r{c}_labels_after"]]
+        assert list(know["object_counts"].keys()) == [str(s) for s in g[f"r{c}_counts_keys"]]
+        assert list(know["object_counts"].values()) == g[f"r{c}_counts_vals"].tolist()
+        assert all(a[0][1] == 2 and a[1][1] == 3 and a[0][0] == a[1][0] for a in model.seen)
+        assert any(v > 0 for v in g[f"r{c}_object_index"].tolist()), "the golden must contain re-identified objects"

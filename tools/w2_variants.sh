@@ -1,12 +1,13 @@
 #!/bin/bash
-# Development probe (run on a GPU box): builds variants of the wide-scan kernel (SAF_W2_NO_DMA: text tiles staged
-# through registers instead of LDS-DMA; SAF_W2_NO_STAGGER: all workgroups start in phase) and times the cases of
-# `bench.py --query` with each, same box, same process order.  Usage: bash tools/w2_variants.sh <outdir>
+# Development probe (run on a GPU box): builds variants of the wide-scan kernel with parts of a step removed
+# (SAF_W2_NO_FEATLOAD: rows loaded once; SAF_W2_NO_TEXTLOAD: no transfer of the next text tile; SAF_W2_NO_BARRIER;
+# SAF_W2_NO_FAST: epilogue in front of the MFMA block instead of between the MFMAs) and times the cases of
+# `bench.py --query` with each, same box, same process order.  The variants' RESULTS are wrong; only timings count.  Usage: bash tools/w2_variants.sh <outdir>
 OUT=${1:-gpurun_out/w2v}
 mkdir -p $OUT
 C=spatially_aware_ai_amd/csrc
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wno-unused-function"
-OTHERS="$C/saf_fuse.o $C/saf_window.o $C/saf_query.o $C/saf_misc.o $C/saf_ccl.o $C/saf_mesh.o"
+OTHERS=$(ls $C/*.o | grep -v saf_query_wide.o | tr "\n" " ")
 # VARIANTS: space-separated; a variant is `base` or switches joined by '+', e.g. NO_DMA+NO_STAGGER
 for v in ${VARIANTS:-base NO_DMA NO_STAGGER NO_DMA+NO_STAGGER}; do
   tag=$(echo $v | tr '+' '_')
