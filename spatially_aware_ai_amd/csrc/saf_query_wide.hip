@@ -545,14 +545,14 @@ query_wide2_kernel(Wide2Args wa) {
   // depend on what follows) -> the MFMAs, each group consuming one fragment and requesting the one AHEAD steps ahead.
   auto step_body = [&](int64_t step, f32x16_t (&c)[NF], const f32x16_t (&pc)[NF]) {
     const int qt = (int)(step % n_qt);
-#ifdef SAF_W2_NO_FEATLOAD  // (development switches: timing only, wrong results)
-    if (step == 0) {
-#else
-    if (qt == 0) {  // a new row block: its rows per wave, register resident for every query tile
-#endif
+    if (qt == 0) {
+      // A new row block: its rows per wave, register resident for every query tile.  A 32-row fragment per wave-load
+      // touches 32 rows x 32 bytes (each lane holds 16 bytes of its OWN row: the MFMA operand layout), and nothing runs
+      // beside this phase: 3.7 of 19.4 ms at config 5.  Tried and measured slower: requesting the next block's rows
+      // behind the last tile's MFMAs (a load into a register an MFMA is still reading stalls the in-order issue: 20.8 ms),
+      // staggered workgroup phases, two independent workgroups per CU.
       const int64_t blk = blockIdx.x + (step / n_qt) * gridDim.x;
       const int64_t row0 = (blk * kWaves + wave) * kRows;
-      float ss[NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         cur.row[f] = row0 + 32 * f + r;
@@ -564,22 +564,22 @@ query_wide2_kernel(Wide2Args wa) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         cur.inv[f] = wa.scale;
-        ss[f] = 0.f;
         if (wa.normalize) {
+          float ss = 0.f;
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
             const uint32_t w[4] = {a[f][s].x, a[f][s].y, a[f][s].z, a[f][s].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float lo = elem16_to_f32<FT>((uint16_t)(w[j] & 0xffffu)), hi = elem16_to_f32<FT>((uint16_t)(w[j] >> 16));
-              ss[f] = __builtin_fmaf(lo, lo, ss[f]);
-              ss[f] = __builtin_fmaf(hi, hi, ss[f]);
+              ss = __builtin_fmaf(lo, lo, ss);
+              ss = __builtin_fmaf(hi, hi, ss);
             }
           }
-          ss[f] += __shfl_xor(ss[f], 32);
+          ss += __shfl_xor(ss, 32);
           // SAF_NORM_L2_CLAMP: norm.clamp_min(0.1); SAF_NORM_L2 with nan_to_num: an all-zero row scores 0
-          cur.inv[f] = wa.normalize == SAF_NORM_L2_CLAMP ? wa.scale / fmaxf(sqrtf(ss[f]), 0.1f)
-                                                         : (ss[f] > 0.0f ? wa.scale / sqrtf(ss[f]) : 0.0f);
+          cur.inv[f] = wa.normalize == SAF_NORM_L2_CLAMP ? wa.scale / fmaxf(sqrtf(ss), 0.1f)
+                                                         : (ss > 0.0f ? wa.scale / sqrtf(ss) : 0.0f);
         }
       }
     }
@@ -587,15 +587,9 @@ query_wide2_kernel(Wide2Args wa) {
     const unsigned char* curb = s_tiles + (size_t)(step & 1) * kWTile * ROWB;
     unsigned char* nxt = s_tiles + (size_t)((step + 1) & 1) * kWTile * ROWB;
     // this tile's text is in LDS (its transfer was issued a step ago) and every wave is done reading the other buffer
-#ifndef SAF_W2_NO_BARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#endif
-#ifdef SAF_W2_NO_TEXTLOAD
-    const bool more = false;
-#else
     const bool more = step + 1 < n_steps;
-#endif
     const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
     uint4 stage[kDma ? 1 : PPT];
     if (more) {
@@ -623,9 +617,11 @@ query_wide2_kernel(Wide2Args wa) {
 #endif
     constexpr int AHEAD = KS < SAF_W2_AHEAD ? KS : SAF_W2_AHEAD;
     uint4 t[KS];
+    // (tried: fragments straight from a fragment-ordered copy of the text in L2 / L1, no LDS, no barrier: 24.0 vs 19.3 ms)
     const unsigned char* trow = curb + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h
+#define SAF_W2_TOFF(s) (32 * (s))
 #pragma unroll
-    for (int s = 0; s < AHEAD; ++s) t[s] = *reinterpret_cast<const uint4*>(trow + 32 * s);
+    for (int s = 0; s < AHEAD; ++s) t[s] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s));
     // Is the previous tile an interior one (wave-uniform)?  Then its epilogue rides between this tile's MFMAs.
     bool fast = step > 0;
 #pragma unroll
@@ -644,7 +640,7 @@ query_wide2_kernel(Wide2Args wa) {
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) c[f] = mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);  // C[query][feature row]
-        if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + 32 * (s + AHEAD));
+        if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
       }
     } else {
       W2Fast<NF> fs;
@@ -652,7 +648,7 @@ query_wide2_kernel(Wide2Args wa) {
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) c[f] = mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);
-        if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + 32 * (s + AHEAD));
+        if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
 #pragma unroll
         for (int i = (s * 16) / KS; i < ((s + 1) * 16) / KS; ++i) w2_fast_piece<OT, EPI, NF>(i, wa, pc, prev, st, fs, r, h, n_qt);
         __builtin_amdgcn_sched_barrier(0);  // keep the pieces where they are: between the MFMAs
@@ -762,7 +758,10 @@ template <int FT, int OT, int KS, int EPI>
 int launch_wide2(const Wide2Args& wa, hipStream_t s) {
   static const int rows_env = getenv("SAF_WIDE_ROWS") ? atoi(getenv("SAF_WIDE_ROWS")) : 0;
   if (rows_env == 64) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
-  if (rows_env == 33) return launch_wide2_nf<FT, OT, KS, EPI, 1, 256>(wa, s);  // 32 rows per wave, two workgroups per CU
+  if (rows_env == 32) return launch_wide2_nf<FT, OT, KS, EPI, 1, 512>(wa, s);
+  // measured at config 5 (ms, 32 vs 64 rows per wave): heat maps 27.5 / 31.4, best query per voxel 19.3 / 20.4, raw scores
+  // 25.7 / 27.8, best voxel per query 55.5 / 45.0 (its per-tile shuffle reduction is per WAVE, so fewer, larger waves win)
+  if (EPI == SAF_QW_QUERY_MAX) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
   return launch_wide2_nf<FT, OT, KS, EPI, 1, 512>(wa, s);
 }
 
@@ -801,11 +800,12 @@ __global__ void text_tiles_kernel(const float* __restrict__ text, int Q, int64_t
   int src = q;
   if (n_bg > 0) src = q < kWTile ? (q < n_bg ? q : -1) : q - kWTile + n_bg;
   const float v = (src >= 0 && src < Q) ? text[(int64_t)src * tstride + k] : 0.0f;
+  const int o = i;
   if (FT == SAF_BF16) {
-    out[i] = (uint16_t)f32_to_bf16_bits(v);
+    out[o] = (uint16_t)f32_to_bf16_bits(v);
   } else {
     const _Float16 hv = (_Float16)v;
-    out[i] = __builtin_bit_cast(uint16_t, hv);
+    out[o] = __builtin_bit_cast(uint16_t, hv);
   }
 }
 
