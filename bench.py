@@ -222,10 +222,12 @@ def main():
         prof = L.saf_profiler_create(3 * a.frames * max(1, a.steps))
         L.saf_profiler_set_stride(prof, a.profile_stride)
 
+    stats_ptr = fusion._buffers["fuse_stats"].data_ptr()
+
     def fuse_into(fz, frame_arr, n_frames, profiler):
         vol = fz._c_volume(for_fuse=True)  # (neither the frame queue nor the deferred clear of reset() is resolved here)
         rc = L.saf_fuse_frames_profiled(C.byref(vol), frame_arr, n_frames, ws.data_ptr(), ws.numel(),
-                                        fusion.fuse_stats.data_ptr(), profiler, stream)
+                                        stats_ptr, profiler, stream)
         check(rc, "saf_fuse_frames_profiled")
 
     def merge(fz):

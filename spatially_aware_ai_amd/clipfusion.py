@@ -257,8 +257,11 @@ class _FusionVolumeMixin:
 
     def __getattr__(self, name):
         # registered buffers live in _buffers, so every read of one comes through here
-        if name in _VOLUME_BUFFERS and (self.__dict__.get("_pending_n", 0) or self.__dict__.get("_feat_stale")):
-            self._sync_volume()
+        if name in _VOLUME_BUFFERS:
+            if name == "clip_feat" and self.__dict__.get("_feat_stale"):
+                self._sync_volume()  # queued frames AND the deferred clear: the rows are about to be looked at
+            elif self.__dict__.get("_pending_n", 0):
+                self._flush_pending()
         return super().__getattr__(name)
 
     def __setattr__(self, name, value):
