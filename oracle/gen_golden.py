@@ -13,6 +13,7 @@ detectron2, ... -- the recipe verified in SURVEY.md §8c), drives
   * the clip_text_query post-processing arithmetic (clip_seem_fusion.py:507-548)
   * flood_fill_3d, first scan         (handy_utils.py:295-480)
   * Clip.get_patches / img_inference_tiled with a stub encode_image (clipfusion.py:789-839)
+  * KmaxSegmentationModel.run_on_image around a stub detectron2 model (handy_utils.py:60-161)
 
 on small seeded inputs and writes inputs + outputs as .npz fixtures under tests/golden/.
 The backbones (CLIP ViT, kMaX-DeepLab) are replaced by seeded feature / label maps: they
@@ -506,6 +507,77 @@ def gen_label_components(out_dir):
     print("label_components:", [int(out[f"c{i}_count"].size) for i in range(len(cases))], "objects per case")
 
 
+class _PanopticPredictionD2:
+    """Stand-in for detectron2==0.6 (environment.yml:83) `detectron2.utils.visualizer._PanopticPrediction`, a third-party
+    class absent from this image, restated from its published source: segments sorted by area, `semantic_masks()` yields
+    the non-thing segments that have an info entry, `instance_masks()` the thing segments with a non-empty mask."""
+
+    def __init__(self, panoptic_seg, segments_info, metadata=None):
+        self._seg = panoptic_seg
+        self._sinfo = {s["id"]: s for s in segments_info}
+        segment_ids, areas = torch.unique(panoptic_seg, sorted=True, return_counts=True)
+        areas = areas.numpy()
+        sorted_idxs = np.argsort(-areas)
+        self._seg_ids, self._seg_areas = segment_ids[sorted_idxs].tolist(), areas[sorted_idxs]
+        for sid, area in zip(self._seg_ids, self._seg_areas):
+            if sid in self._sinfo:
+                self._sinfo[sid]["area"] = float(area)
+
+    def semantic_masks(self):
+        for sid in self._seg_ids:
+            sinfo = self._sinfo.get(sid)
+            if sinfo is None or sinfo["isthing"]:
+                continue
+            yield (self._seg == sid).numpy().astype(bool), sinfo
+
+    def instance_masks(self):
+        for sid in self._seg_ids:
+            sinfo = self._sinfo.get(sid)
+            if sinfo is None or not sinfo["isthing"]:
+                continue
+            mask = (self._seg == sid).numpy().astype(bool)
+            if mask.sum() > 0:
+                yield mask, sinfo
+
+
+def gen_kmax_wrapper(out_dir):
+    """KmaxSegmentationModel.run_on_image (handy_utils.py:60-161) with the detectron2 model replaced by a stub that
+    records its input and returns a seeded panoptic map: pins the reference's pre- and post-processing around the
+    backbone (row a13).  The class is instantiated without its __init__ (which builds the real model)."""
+    import handy_utils as hu
+
+    hu._PanopticPrediction = _PanopticPredictionD2
+    out = {}
+    for ci, (h, w, seed) in enumerate([(48, 64, 1), (64, 48, 2), (30, 30, 3)]):
+        g = torch.Generator().manual_seed(seed)
+        image = torch.rand(3, h, w, generator=g)
+        pan = torch.randint(0, 7, (h, w), generator=g).int()  # ids 0..6; 0 = unlabelled, 6 has no info entry
+        infos = [{"id": 1, "isthing": True, "category_id": 56}, {"id": 2, "isthing": False, "category_id": 100},
+                 {"id": 3, "isthing": True, "category_id": 0}, {"id": 4, "isthing": False, "category_id": 132},
+                 {"id": 5, "isthing": True, "category_id": 62}, {"id": 9, "isthing": True, "category_id": 1}]
+        seen = {}
+
+        def model(inputs, pan=pan, infos=infos, seen=seen):
+            seen["image"] = inputs[0]["image"].clone()
+            seen["hw"] = (inputs[0]["height"], inputs[0]["width"])
+            return [{"panoptic_seg": (pan.clone(), [dict(i) for i in infos])}]
+
+        m = object.__new__(hu.KmaxSegmentationModel)
+        m.model, m.metadata, m.cpu_device = model, None, torch.device("cpu")
+        res = m.run_on_image(image)
+        out[f"c{ci}_image"] = image.numpy()
+        out[f"c{ci}_panoptic"] = pan.numpy()
+        out[f"c{ci}_model_input_shape"] = np.array(seen["image"].shape)
+        out[f"c{ci}_model_input_sample"] = seen["image"][:, ::9, ::11].numpy().astype(np.int16)  # values 0..255
+        out[f"c{ci}_model_input_sum"] = np.array(seen["image"].long().sum(dim=(1, 2)).numpy())
+        out[f"c{ci}_hw"] = np.array(seen["hw"])
+        out[f"c{ci}_result"] = res.numpy()
+    out["infos"] = np.array([[i["id"], int(i["isthing"]), i["category_id"]] for i in infos])
+    out["n_cases"] = np.array(3)
+    np.savez_compressed(os.path.join(out_dir, "kmax_wrapper.npz"), **out)
+    print("kmax wrapper: model inputs", [tuple(out[f"c{i}_model_input_shape"]) for i in range(3)])
+
+
 def stub_encode_image(x):
     """Deterministic stand-in for open_clip's encode_image used to pin the tiling front-end (a12): 12 numbers per
     224x224 tile that depend on the tile's content and position-sensitive samples of it."""
@@ -561,6 +633,7 @@ def main():
     gen_extract_mesh(ref_cf, ref_csf, args.out)
     gen_label_components(args.out)
     gen_tiled_clip(ref_cf, args.out)
+    gen_kmax_wrapper(args.out)
     with open(os.path.join(args.out, "README.md"), "w") as f:
         f.write(
             "Golden vectors produced by `oracle/gen_golden.py` from the reference's own Python\n"
