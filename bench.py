@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--merge", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
     ap.add_argument("--no-overlap-merge", action="store_true",
                     help="N > 1: skip the second timed region (merge of job k overlapped with the fusion of job k+1)")
+    ap.add_argument("--no-voxel-sharded", action="store_true",
+                    help="N > 1: skip the third timed region (every rank fuses every frame into its slab of the volume)")
     ap.add_argument("--check-frames", type=int, default=4,
                     help="N > 1: frames per rank of the untimed merge-integrity job (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -186,13 +188,15 @@ def main():
     fdt = torch.bfloat16 if a.feat_dtype == "bf16" else torch.float32
     esz = 2 if a.feat_dtype == "bf16" else 4
 
-    def new_volume():
+    def new_volume(nvox=None, index_offset=(0, 0, 0)):
+        nvox = grid.nvox if nvox is None else nvox
         if a.labels:
-            fz = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, a.height // 3,
-                                a.height // 6, ResidentFeatures(), None, keep_xyz_world=False, feat_dtype=fdt)
+            fz = ClipSeemFusion(grid.origin, grid.voxel_size, nvox, grid.trunc, False, a.height // 3,
+                                a.height // 6, ResidentFeatures(), None, keep_xyz_world=False, feat_dtype=fdt,
+                                index_offset=index_offset)
         else:
-            fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, ResidentFeatures(), None,
-                            a.height // 3, a.height // 6, keep_xyz_world=False, feat_dtype=fdt)
+            fz = ClipFusion(grid.origin, grid.voxel_size, nvox, grid.trunc, False, ResidentFeatures(), None,
+                            a.height // 3, a.height // 6, keep_xyz_world=False, feat_dtype=fdt, index_offset=index_offset)
         return fz.to(device)
 
     # N > 1 keeps two volumes: the second one lets job k+1 fuse while job k's merge drains (second timed
@@ -226,6 +230,8 @@ def main():
 
     def fuse_into(fz, frame_arr, n_frames, profiler):
         vol = fz._c_volume(for_fuse=True)  # (neither the frame queue nor the deferred clear of reset() is resolved here)
+        if fz._feat_stale and L.saf_fuse_path(C.byref(vol), frame_arr, n_frames, ws.numel()) != 1:
+            fz.flush()  # a short call takes the per-frame pipeline, which reads the rows it updates: clear first
         rc = L.saf_fuse_frames_profiled(C.byref(vol), frame_arr, n_frames, ws.data_ptr(), ws.numel(),
                                         stats_ptr, profiler, stream)
         check(rc, "saf_fuse_frames_profiled")
@@ -318,6 +324,12 @@ def main():
         overlapped = {"value": round(total_frames / dt2, 2), "unit": "frames/s", "ms_per_step": round(dt2 / a.steps * 1e3, 3),
                       "note": "job k's merge on a side stream beside job k+1's fusion into a second volume: a stream of "
                               "independent jobs, not BASELINE config 4's single job (that is `value`)"}
+
+    # ---- timed region 3 (N > 1): the same job VOXEL-sharded -- every rank fuses every frame into its x-slab, no merge ----
+    voxel_sharded = None
+    if world > 1 and not a.no_voxel_sharded and int(grid.nvox[0]) >= world:
+        voxel_sharded = bench_voxel_sharded(a, dist, sdist, grid, fusions, (depth, rgb, poses, ks, feat, label_maps), new_volume,
+                                            world, rank, device, L, stream, npy, npx)
 
     # ---- N > 1: the merged shard of a small sharded job against a single-rank fusion of ALL its frames ----
     if world > 1 and a.check_frames > 0:
@@ -527,6 +539,7 @@ def main():
                 "rccl_world": dist.get_world_size() if world > 1 else 1, "backend": a.backend if world > 1 else None,
             },
             "overlapped_merge": overlapped,
+            "voxel_sharded": voxel_sharded,
             "merge_check": merge_check,
             "roofline": roofline,
             "kernel_breakdown": breakdown,
@@ -733,6 +746,87 @@ def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value)
             "windowed": st["window_rows"] > 0,
             "note": "one frame per integrate_features() call, deferred window queue (64-frame windows), includes the reset "
                     "of the volume and the final flush; `vs_bulk` = this / the bulk `value` of the same run"}
+
+
+def bench_voxel_sharded(a, dist, sdist, grid, fusions, tensors, new_volume, world, rank, device, L, stream, npy, npx):
+    """The same job with VOXELS sharded instead of frames: rank k owns the x-slab k of the volume
+    and fuses ALL world * frames_per_rank frames into it; the only exchange is the frames (an all-gather of 5 MB per
+    frame, inside the timed region -- every rank starts with its own frames only), there is no merge, and the volume ends
+    sharded the way the sharded query reads it.  Untimed check: the slab equals, bit for bit, the same x-range of a
+    full-size volume fused on this rank alone from the same frames in the same order."""
+    nx, ny, nz = (int(v) for v in grid.nvox)
+    first_x, cnt = sdist.slab_of_rank(nx, rank, world)
+    slab = new_volume(torch.tensor([cnt, ny, nz], dtype=torch.int32), (first_x, 0, 0))
+    ws = slab._get_workspace(npy, npx)
+    stats = slab._buffers["fuse_stats"]
+    uniq = tensors[0].shape[0]
+    gathered = sdist.gather_frames(tensors)  # the receive buffers persist: their frame descriptors are built once
+    arr_all, keep, _, _ = slab._make_frames(*gathered[:5], gathered[5], a.labels)
+    n_all = world * uniq
+    frames_all = (_abi.SafFrame * (world * a.frames))()
+    for r in range(world):
+        for i in range(a.frames):
+            frames_all[r * a.frames + i] = arr_all[r * uniq + i % uniq]
+
+    def job():
+        slab.reset()
+        for dst, src in zip(gathered, sdist.gather_frames(tensors)):  # the exchange of this job's inputs
+            if dst is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        vol = slab._c_volume(for_fuse=True)
+        check(L.saf_fuse_frames_profiled(C.byref(vol), frames_all, world * a.frames, ws.data_ptr(), ws.numel(),
+                                         stats.data_ptr(), None, stream), "saf_fuse_frames (slab)")
+        slab.flush()
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    job()
+    barrier()
+    stats.zero_()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        job()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    st = slab.stats()
+    assert st["frames"] == world * a.frames * a.steps
+    assert int(slab.weight.sum(dtype=torch.int64)) * a.steps == st["valid"]
+    # untimed: a full-size volume fused here from a few of the same frames must agree with the slab on its x-range
+    c = min(max(1, a.check_frames), uniq)
+    sub = (_abi.SafFrame * (world * c))()
+    for r in range(world):
+        for i in range(c):
+            sub[r * c + i] = arr_all[r * uniq + i]
+    full = fusions[1]
+    full.reset(lazy=False)  # (a handful of frames: the per-frame pipeline reads the rows it updates)
+    wsf = full._get_workspace(npy, npx)
+    volf = full._c_volume(for_fuse=True)
+    check(L.saf_fuse_frames_profiled(C.byref(volf), sub, world * c, wsf.data_ptr(), wsf.numel(), full._buffers["fuse_stats"].data_ptr(),
+                                     None, stream), "check (full volume)")
+    slab.reset(lazy=False)
+    vols = slab._c_volume(for_fuse=True)
+    check(L.saf_fuse_frames_profiled(C.byref(vols), sub, world * c, ws.data_ptr(), ws.numel(), stats.data_ptr(), None, stream),
+          "check (slab)")
+    lo, hi = first_x * ny * nz, (first_x + cnt) * ny * nz
+    same = all(bool(torch.equal(getattr(slab, n), getattr(full, n)[lo:hi])) for n in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat"))
+    flag = torch.tensor([int(same), int((slab.weight > 0).sum())], device=device, dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    assert int(flag[0]) == 1, "voxel-sharded check: a slab differs from the same x-range of the full-size volume"
+    assert int(flag[1]) > 0, "voxel-sharded check: a slab was not touched by the check frames"
+    del slab, gathered
+    torch.cuda.empty_cache()
+    total = world * a.frames * a.steps
+    return {"value": round(total / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "slab_voxels": cnt * ny * nz, "frames_fused_per_rank_per_step": world * a.frames, "collective": "all_gather of the frames",
+            "slab_equals_full_volume_range": True,
+            "note": "every rank fuses all frames of the job into its x-slab of the volume: no merge, one all-gather of the frames "
+                    "(inside the timed step), the volume stays voxel-sharded; NOT BASELINE config 4's layout (that is `value`)"}
 
 
 def check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, tensors, c, world, rank, device):

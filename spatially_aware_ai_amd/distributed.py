@@ -1,4 +1,9 @@
-"""Frame-sharded multi-GPU fusion (new capability; the reference is single-device).
+"""Multi-GPU fusion (new capability; the reference is single-device): frame-sharded with one merge (BASELINE config 4),
+or voxel-sharded with no merge at all (``slab_of_rank`` / ``gather_frames``: every rank fuses EVERY frame into its own
+x-slab of the volume -- a fusion module built with ``index_offset`` -- so the only exchange is the frames themselves and
+the volume is born sharded the way ``query_sharded`` reads it).
+
+Frame-sharded:
 
 One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI on ROCm).  Frames
 are independent units, so rank r fuses its contiguous block of frames into a private volume kept
@@ -89,6 +94,34 @@ def _all_gather_rows(t, group, rank, world):
     if n > per * world:
         src = world - 1
         dist.broadcast(t[per * world :], src=dist.get_global_rank(group, src) if group else src, group=group)
+
+
+def slab_of_rank(nx: int, rank: int, world: int):
+    """(first x index, number of x planes) of the volume slab rank owns in the VOXEL-sharded job: x-planes are whole
+    contiguous ranges of the flat voxel index n = (x*ny + y)*nz + z, so slab k is voxel range k."""
+    base, rem = divmod(nx, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def gather_frames(tensors, group=None):
+    """The exchange step of the voxel-sharded job: every rank contributes its frames (depth, rgb, poses, K, feature maps,
+    [label maps]) and receives everybody's, in rank order -- 5 MB per 640x480 frame instead of the 34 GB of a volume merge.
+    ``tensors``: a sequence of [F, ...] tensors (None entries stay None); ranks must hold the same number of frames."""
+    world = dist.get_world_size(group)
+    out = []
+    for t in tensors:
+        if t is None:
+            out.append(None)
+            continue
+        t = t.contiguous()
+        full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(full, t, group=group)
+        else:
+            dist.all_gather(list(full.split(t.shape[0])), t, group=group)
+        out.append(full)
+    return out
 
 
 VOLUME_TENSORS = ("clip_feat", "rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot")

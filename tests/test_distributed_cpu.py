@@ -166,3 +166,29 @@ def test_two_rank_sharded_query_equals_single_process(tmp_path, oracle, from_mer
         assert np.array_equal(g["row_argmax_0"], ri.numpy()) and np.array_equal(g["row_argmax_1"], rv.numpy())
         first, count = sdist.voxel_shard(ref.n, r, world)
         np.testing.assert_allclose(g["vs_background_0"], vb.numpy()[first:first + count], rtol=1e-6, atol=1e-7)
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = [torch.full((3, 4, 5), float(rank)), None, torch.arange(3 * 2).view(3, 2) + 100 * rank]
+        out = sdist.gather_frames(mine)
+        assert out[1] is None
+        np.savez(os.path.join(out_dir, f"g{rank}.npz"), a=out[0].numpy(), c=out[2].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_voxel_sharded_job_exchanges_frames_in_rank_order(tmp_path):
+    """The voxel-sharded job's only exchange: every rank ends with all frames, rank after rank; slabs tile the x axis."""
+    world = 2
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        g = np.load(os.path.join(tmp_path, f"g{r}.npz"))
+        assert g["a"].shape == (6, 4, 5) and (g["a"][:3] == 0).all() and (g["a"][3:] == 1).all()
+        assert g["c"][:, 0].tolist() == [0, 2, 4, 100, 102, 104]
+    for nx, w in ((256, 8), (33, 3), (5, 8)):
+        slabs = [sdist.slab_of_rank(nx, r, w) for r in range(w)]
+        assert sum(c for _, c in slabs) == nx and all(slabs[i][0] + slabs[i][1] == slabs[i + 1][0] for i in range(w - 1))

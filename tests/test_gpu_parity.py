@@ -925,3 +925,34 @@ def test_reset_defers_the_feature_clear_invisibly(oracle):
     # eager form
     fz.reset(lazy=False)
     assert not fz._feat_stale and float(fz._buffers["clip_feat"].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("dim,n_frames", [(512, 20), (64, 3)])
+def test_voxel_slabs_equal_the_full_volume(dim, n_frames):
+    """Voxel-sharded fusion (distributed.slab_of_rank): a module built over an x-slab of the grid (index_offset) fuses
+    exactly what the full volume holds in that x-range -- bit for bit, windowed path and per-frame pipeline alike --
+    because its axis table is the same expression on the same indices."""
+    from spatially_aware_ai_amd import ClipFusion
+    from spatially_aware_ai_amd import distributed as sdist
+
+    w, h, nvox = 64, 48, (33, 32, 48)
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid(nvox, side=2.56 * nvox[0] / max(nvox))
+    frames = syn.make_frames(515, n_frames, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="B", missing_depth_frac=0.05)
+    cat = lambda k: torch.cat([f[k] for f in frames]).cuda()
+    args = [cat(k) for k in ("depth", "rgb", "pose", "K", "feat")]
+    full = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, FakeClip(dim), None, 10, 10).cuda()
+    full.integrate_features(*args)
+    world, covered = 3, 0
+    for rank in range(world):
+        first, cnt = sdist.slab_of_rank(nvox[0], rank, world)
+        slab = ClipFusion(grid.origin, grid.voxel_size, torch.tensor([cnt, nvox[1], nvox[2]]), grid.trunc, False, FakeClip(dim), None,
+                          10, 10, index_offset=(first, 0, 0)).cuda()
+        assert torch.equal(slab.xyz_world, full.xyz_world.view(*nvox, 3)[first:first + cnt].reshape(-1, 3))
+        slab.integrate_features(*args)
+        lo, hi = first * nvox[1] * nvox[2], (first + cnt) * nvox[1] * nvox[2]
+        for nm in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat"):
+            assert torch.equal(getattr(slab, nm), getattr(full, nm)[lo:hi]), (rank, nm)
+        covered += cnt
+    assert covered == nvox[0] and int(full.weight.sum()) > 0
+    assert [sdist.slab_of_rank(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 32)]
