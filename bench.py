@@ -408,8 +408,10 @@ def main():
             roofline["tsdf_voxels_per_launch"] = round(ut, 1)
             roofline["hits_per_row"] = round(st["valid"] / max(1, st["window_rows"]), 3)
             roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of 64 "
-                                "frames (hits applied in frame order: bit-identical to frame-by-frame fusion); the window's "
-                                "classification + TSDF run in classify_window_kernel (kernel_breakdown.sweep_us, per window)")
+                                "frames (hits applied in frame order: bit-identical to frame-by-frame fusion); the NEXT window's "
+                                "classification + TSDF (classify kernels, kernel_breakdown.sweep_us per 32 frames) run beside it on "
+                                "a second stream, so this launch duration is that of a kernel sharing the chip: `isolated` is the "
+                                "same kernel alone")
         breakdown = {
             "prep_us": round(ms["prep"][0] / max(1, ms["prep"][1]) * 1e3, 2),
             "sweep_us": round(ms["sweep"][0] / max(1, ms["sweep"][1]) * 1e3, 2),
@@ -418,6 +420,32 @@ def main():
             "frame_algorithmic_bytes": int(frame_bytes),
             "frame_hbm_frac": round(frame_bytes / (dt / (a.frames * a.steps)) / 1e9 / HBM_PEAK_GBS, 4),
         }
+
+    # ---- the row kernel with nothing beside it (the timed region runs the NEXT window's classification next to it) ----
+    if roofline is not None and windowed and rank == 0 and world == 1:
+        prof4 = L.saf_profiler_create(3 * a.frames)
+        L.saf_profiler_set_stride(prof4, a.profile_stride)
+        os.environ["SAF_WIN_OVERLAP"] = "0"  # read per call by saf_fuse_frames: every kernel on the caller's stream
+        try:
+            fusion.reset()
+            fuse_into(fusion, frames, a.frames, prof4)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["SAF_WIN_OVERLAP"]
+        tot, n = C.c_double(0), C.c_int64(0)
+        check(L.saf_profiler_read(prof4, 2, C.byref(tot), C.byref(n)), "saf_profiler_read")
+        tot_c, n_c = C.c_double(0), C.c_int64(0)
+        check(L.saf_profiler_read(prof4, 1, C.byref(tot_c), C.byref(n_c)), "saf_profiler_read")
+        L.saf_profiler_destroy(prof4)
+        if n.value:
+            iso = tot.value / n.value * 1e-3
+            roofline["isolated"] = {"avg_launch_us": round(iso * 1e6, 2), "achieved": round(fuse_bytes / iso / 1e9, 1),
+                                    "frac": round(fuse_bytes / iso / 1e9 / HBM_PEAK_GBS, 4), "launches": int(n.value),
+                                    "classify_us_alone": round(tot_c.value / max(1, n_c.value) * 1e3, 2),
+                                    "note": "SAF_WIN_OVERLAP=0: classification and row kernel one after the other on one stream; "
+                                            "in the timed region window w + 1 is classified beside window w's row kernel, "
+                                            "which lengthens each kernel and shortens the step"}
+        fusion.fuse_stats.zero_()
 
     # ---- the same launches into a WARM volume (no zeroing: every touched row is read), untimed in `value` ----
     if roofline is not None and windowed and rank == 0 and world == 1:

@@ -938,8 +938,18 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
-  if (window_ok(kv, frames, n_frames, workspace_bytes))
-    return fuse_many_windowed(kv, frames, n_frames, workspace, stats, prof, s);
+  if (window_ok(kv, frames, n_frames, workspace_bytes)) {
+    // SAF_WIN_OVERLAP=0: every kernel of the windowed path on the caller's stream (read per call: same-process A/Bs)
+    const char* ov_env = getenv("SAF_WIN_OVERLAP");
+    PipeRes* pr = (ov_env && ov_env[0] == '0') || n_frames <= SAF_WINDOW_FRAMES ? nullptr : pipe_acquire();
+    if (!pr) return fuse_many_windowed(kv, frames, n_frames, workspace, stats, prof, s, nullptr);
+    WinOverlap ov;
+    ov.aux = pr->aux; ov.fork = pr->fork; ov.join = pr->join;
+    ov.cls_done[0] = pr->fused[0]; ov.cls_done[1] = pr->fused[1]; ov.fuse_done[0] = pr->fused[2]; ov.fuse_done[1] = pr->fused[3];
+    rc = fuse_many_windowed(kv, frames, n_frames, workspace, stats, prof, s, &ov);
+    pipe_release(pr);
+    return rc;
+  }
   // counters and the completion counter start at zero; afterwards every sweep zeroes its successor's set
   if (hipMemsetAsync(ws, 0, kHdrBytes, s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
   // SAF_PIPELINE=0 keeps everything on the caller's stream (debugging / per-kernel timing)

@@ -288,7 +288,13 @@ struct ScopedPair {
 // the windowed path (saf_window.hip), called by saf_fuse_frames
 size_t window_workspace_bytes(int64_t n_vox, int D, int P);
 bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes);
+// Streams / events for running the classification of window w + 1 beside the row kernel of window w (may be NULL:
+// everything on the caller's stream).
+struct WinOverlap {
+  hipStream_t aux;
+  hipEvent_t fork, join, cls_done[2], fuse_done[2];
+};
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, uint64_t* stats,
-                       saf_profiler* prof, hipStream_t s);
+                       saf_profiler* prof, hipStream_t s, const WinOverlap* ov);
 
 }  // namespace saf

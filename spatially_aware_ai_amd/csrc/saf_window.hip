@@ -7,7 +7,8 @@
 namespace saf {
 namespace {
 
-constexpr size_t kHdrBytes = 2048;  // workspace header (piece counter)
+constexpr size_t kHdrBytes = 2048;   // one workspace header (piece counter, dmax, counter shards)
+constexpr size_t kHdrTotal = 2 * kHdrBytes;  // two of them, and two mask buffers: window w + 1 is classified while window w's rows are fused
 
 // Pixel-major image for the windowed path, whose taps are read from global memory (L2): row p holds
 // the D channels of map position p contiguously (a wave's tap load is one contiguous D*4 bytes), row P
@@ -87,7 +88,7 @@ __device__ unsigned long long g_win_t[16];
 #endif
 
 #ifndef SAF_WIN_P2
-#define SAF_WIN_P2 4
+#define SAF_WIN_P2 2  // tap groups in flight: 2 -> 133 VGPRs, so that two row-kernel waves leave room for classification waves on a SIMD (alone, 2 / 3 / 4 / 6 time the same)
 #endif
 #ifndef SAF_CLS_WPE
 #define SAF_CLS_WPE 5  // classify_bricks_kernel: waves per SIMD the register budget is set for (78 VGPRs, no spills)
@@ -99,7 +100,7 @@ __device__ unsigned long long g_win_t[16];
 #define SAF_WIN_SPLIT_LOG2 2  // a piece is handed out in 2^k parts (quarters measured best: halves 6967, quarters 7165, eighths 6049 frames/s on the coherent scene)
 #endif
 #ifndef SAF_WIN_SR2
-#define SAF_WIN_SR2 6
+#define SAF_WIN_SR2 5  // 5-row sub-chunks: 71 KB of LDS per workgroup, two of them leave room for a classification workgroup
 #endif
 #ifndef SAF_WIN_WPE
 #define SAF_WIN_WPE 2
@@ -562,6 +563,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
                    const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc) {
   using Cfg = WinCfg<CPL>;
   constexpr int SR = Cfg::SR;
+  // (s_setprio 1 / 3 here, ahead of the classification waves that share the SIMDs, changes nothing: 105.4 / 105.7 / 105.8 ms)
   // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
   constexpr int P = BF16 && Cfg::P > 2 ? Cfg::P - 1 : Cfg::P;
   extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -911,7 +913,7 @@ WinLayout win_layout(int64_t n_vox, int D, int P) {
   w.maps_bytes = (size_t)kWin * w.img_bytes;
   w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
-  w.total = kHdrBytes + w.maps_bytes + w.mask_bytes;
+  w.total = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;
   return w;
 }
 
@@ -952,7 +954,7 @@ bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
 }
 
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, uint64_t* stats,
-                       saf_profiler* prof, hipStream_t s) {
+                       saf_profiler* prof, hipStream_t s, const WinOverlap* ov) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   KFrame kf0;
@@ -979,18 +981,12 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
                                        (int)win_lds);
     if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", win_lds, hipGetErrorString(e));
   }
-  float* maps = reinterpret_cast<float*>(ws + kHdrBytes);
-  uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrBytes + wl.maps_bytes);
-  unsigned int* piece_ctr = reinterpret_cast<unsigned int*>(ws);
+  float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
   static const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
   uint32_t grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : 2);
   const uint32_t n_pieces = (uint32_t)(((int64_t)kv.N + kPiece - 1) / kPiece);
   const uint32_t n_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
   if (grid > n_wgs) grid = n_wgs;
-  // Everything is ordered on the caller's stream: classification, map images, row kernel, window after
-  // window.  Running the classification of window w+1 beside the row kernel of window w (second stream)
-  // was measured: the pair costs the sum of the two either way (both are limited by the memory system),
-  // and with 64-frame windows the row kernel's 156 KB of LDS per CU leave no room for it.
   static const int tile_env = getenv("SAF_WIN_TILE") ? atoi(getenv("SAF_WIN_TILE")) : -1;
   int tile = tile_env >= 0 ? tile_env : 32;
   {
@@ -1004,61 +1000,100 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   static const bool bricks_on = !(getenv("SAF_WIN_BRICKS") && getenv("SAF_WIN_BRICKS")[0] == '0');
   const bool bricks = bricks_on && kv.nx % kBrickX == 0 && kv.ny % kBrickY == 0 && kv.nz % kBrickZ == 0;
   const int brick_tiles = (kv.nx / kBrickX) % 8 == 0 && (kv.ny / kBrickY) % 8 == 0 ? 1 : 0;
-  float* dmax = reinterpret_cast<float*>(ws + kDmaxOff);
-  unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(ws + kClsAccOff);
   static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kDmaxOff + 32 * sizeof(float) <= kClsAccOff,
                 "workspace header layout");
   const int n_win = (n_frames + kWin - 1) / kWin;
-  for (int w = 0; w < n_win; ++w) {
+
+  // Two streams.  The classification (VALU-bound; TSDF, depth images, one mask plane per 32 frames) of window w + 1 runs
+  // on `cs` while the row kernel (memory-bound) of window w runs on the caller's stream: the row kernel leaves 18 KB of
+  // LDS and 112 registers per SIMD free (5-row sub-chunks, 197 VGPRs at two waves per SIMD), which is one classification
+  // workgroup per CU beside it.  Masks and header are double-buffered by window parity:
+  //   classify(w) -> fuse(w)       event cls_done[w & 1]
+  //   fuse(w) -> classify(w + 2)   event fuse_done[w & 1]  (same mask buffer and header)
+  // Without `ov` everything is queued on the caller's stream in order.
+  hipStream_t cs = ov ? ov->aux : s;
+  if (ov) {
+    if (hipEventRecord(ov->fork, s) != hipSuccess || hipStreamWaitEvent(cs, ov->fork, 0) != hipSuccess)
+      return fail(SAF_E_HIP, "windowed path: could not fork the classification stream");
+  }
+  auto frame_args = [&](int w, WinArgs& wa, PrepArgs& pa) {
     const int f0 = w * kWin;
     const int F = n_frames - f0 < kWin ? n_frames - f0 : kWin;
-    WinArgs wa;
     wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
-    PrepArgs pa;
     for (int k = 0; k < kWin; ++k) {
       const saf_frame& fr = frames[f0 + (k < F ? k : 0)];
       wa.depth[k] = fr.depth; wa.rgb[k] = fr.rgb; wa.pose[k] = fr.pose; wa.K[k] = fr.K; wa.label_map[k] = fr.label_map;
       pa.feat_map[k] = fr.feat_map;
     }
+    return F;
+  };
+  auto classify = [&](int w) -> int {
+    WinArgs wa;
+    PrepArgs pa;
+    const int F = frame_args(w, wa, pa), f0 = w * kWin, par = w & 1;
+    unsigned char* hdr = ws + (size_t)par * kHdrBytes;
+    uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
+    float* dmax = reinterpret_cast<float*>(hdr + kDmaxOff);
+    unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
+    if (ov && w >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
     // header: piece counter, dmax, the classification launches' counter shards
-    if (hipMemsetAsync(ws, 0, kHdrBytes, s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
+    if (hipMemsetAsync(hdr, 0, kHdrBytes, cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
     for (int fb = 0; fb < F; fb += 32) {
       const int fe = fb + 32 < F ? fb + 32 : F;
       uint32_t* plane = masks + (size_t)(fb / 32) * wl.mask_plane;
       if (bricks) {  // the frames' largest depths feed the bricks' frame cull
-        if (hipMemsetAsync(dmax, 0, 32 * sizeof(float), s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(dmax)");
-        hipLaunchKernelGGL(depth_max_kernel, dim3(32, fe - fb), dim3(256), 0, s, wa, fb, kf0.H * kf0.W,
+        if (hipMemsetAsync(dmax, 0, 32 * sizeof(float), cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(dmax)");
+        hipLaunchKernelGGL(depth_max_kernel, dim3(32, fe - fb), dim3(256), 0, cs, wa, fb, kf0.H * kf0.W,
                            reinterpret_cast<int*>(dmax));
       }
-      ScopedPair t(prof, 1, f0 + fb, s);
+      ScopedPair t(prof, 1, f0 + fb, cs);
       if (bricks) {
         if (sum)
-          hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, brick_tiles, dmax,
+          hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(n_wgs), dim3(256), 0, cs, kv, wa, fb, fe, brick_tiles, dmax,
                              plane, reinterpret_cast<unsigned long long*>(stats), cls_acc);
         else
-          hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, brick_tiles, dmax,
+          hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(n_wgs), dim3(256), 0, cs, kv, wa, fb, fe, brick_tiles, dmax,
                              plane, reinterpret_cast<unsigned long long*>(stats), cls_acc);
       } else if (sum) {
-        hipLaunchKernelGGL(classify_window_kernel<true>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, tile, plane,
+        hipLaunchKernelGGL(classify_window_kernel<true>, dim3(n_wgs), dim3(256), 0, cs, kv, wa, fb, fe, tile, plane,
                            reinterpret_cast<unsigned long long*>(stats), cls_acc);
       } else {
-        hipLaunchKernelGGL(classify_window_kernel<false>, dim3(n_wgs), dim3(256), 0, s, kv, wa, fb, fe, tile, plane,
+        hipLaunchKernelGGL(classify_window_kernel<false>, dim3(n_wgs), dim3(256), 0, cs, kv, wa, fb, fe, tile, plane,
                            reinterpret_cast<unsigned long long*>(stats), cls_acc);
       }
     }
-    if ((rc = check_launch("classify_window_kernel"))) return rc;
+    int r = check_launch("classify_window_kernel");
+    if (r) return r;
+    if (ov && hipEventRecord(ov->cls_done[par], cs) != hipSuccess) return fail(SAF_E_HIP, "hipEventRecord");
+    return SAF_OK;
+  };
+  if ((rc = classify(0))) return rc;
+  for (int w = 0; w < n_win && rc == SAF_OK; ++w) {
+    WinArgs wa;
+    PrepArgs pa;
+    const int F = frame_args(w, wa, pa), f0 = w * kWin, par = w & 1;
+    unsigned char* hdr = ws + (size_t)par * kHdrBytes;
+    uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
+    if (ov && w + 1 < n_win && (rc = classify(w + 1))) break;  // queued now: it runs beside this window's row kernel
+    if (ov && hipStreamWaitEvent(s, ov->cls_done[par], 0) != hipSuccess) { rc = fail(SAF_E_HIP, "hipStreamWaitEvent"); break; }
     {
       ScopedPair t(prof, 0, f0, s);
       hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, pa, maps,
                          (int)(wl.img_bytes / sizeof(float)), kv.D, P);
     }
-    if ((rc = check_launch("prep_rows_kernel"))) return rc;
+    if ((rc = check_launch("prep_rows_kernel"))) break;
     {
       ScopedPair t(prof, 2, f0, s);
       hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, maps, img_vecs,
-                         reinterpret_cast<unsigned long long*>(stats), piece_ctr, masks, wl.mask_plane, cls_acc);
+                         reinterpret_cast<unsigned long long*>(stats), reinterpret_cast<unsigned int*>(hdr), masks, wl.mask_plane,
+                         reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff));
     }
-    if ((rc = check_launch("fuse_window_kernel"))) return rc;
+    if ((rc = check_launch("fuse_window_kernel"))) break;
+    if (ov && hipEventRecord(ov->fuse_done[par], s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord"); break; }
+    if (!ov && w + 1 < n_win) rc = classify(w + 1);
+  }
+  if (ov) {  // whatever was queued on the classification stream is ordered before later work of the caller (error paths too)
+    if (hipEventRecord(ov->join, cs) == hipSuccess) (void)hipStreamWaitEvent(s, ov->join, 0);
   }
 #ifdef SAF_WIN_TIMING
   {
