@@ -761,6 +761,19 @@ def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value)
 
     job()
     torch.cuda.synchronize()
+    if os.environ.get("SAF_BENCH_PROFILE_API") == "1":  # development: where does the host time of the loop go?
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        job()
+        pr.disable()
+        torch.cuda.synchronize()
+        ps = pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime")
+        ps.print_stats(8)
+        ps.print_callers("get")
+        ps.print_callees("get")
     fusion.fuse_stats.zero_()
     t0 = time.perf_counter()
     job()

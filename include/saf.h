@@ -131,6 +131,13 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
                     void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);
 
+/* Copy one frame's inputs (depth, rgb, pose, K, feature map, label map -- all f32) from `src` into the buffers `dst`
+ * points to, in ONE launch: the host queue behind integrate() keeps the frames of small calls in a staging ring until a
+ * window is full.  The source feature map is addressed through element strides (Clip.img_inference_tiled returns a
+ * permuted view); feat_channels = channels to copy; everything else is contiguous. */
+int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_stride_c, int64_t feat_stride_y,
+                    int64_t feat_stride_x, const saf_frame* dst, void* stream);
+
 /* Which device path saf_fuse_frames would take for this call: 1 = windowed (never reads the feature rows of voxels
  * with weight 0), 0 = per-frame pipeline, -1 = invalid arguments.  Host-only, launches nothing. */
 int saf_fuse_path(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes);

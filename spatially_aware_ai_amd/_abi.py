@@ -77,6 +77,7 @@ PROTOTYPES = {
         [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp, _fp],
     ),
     "saf_poll_async_error": (C.c_int, []),
+    "saf_stage_frame": (C.c_int, [C.POINTER(SafFrame), C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.POINTER(SafFrame), _fp]),
     "saf_fuse_path": (C.c_int, [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, C.c_size_t]),
     "saf_clear_unwritten_rows": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_profiler_create": (_fp, [C.c_int32]),

@@ -61,7 +61,8 @@ def check(rc: int, what: str = ""):
 def current_stream_ptr():
     import torch
 
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of the current device's current stream (no Stream object, no is_available() round trip)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def require_cuda(t, name):

@@ -163,10 +163,14 @@ class _FusionVolumeMixin:
     # clipfusion.py:1120-1133).  One frame per C call would run the per-frame pipeline; the windowed path
     # (saf_fuse_frames with 16+ frames: every touched feature row travels to HBM once per 64-frame window)
     # needs many frames in one call.  Small calls are therefore queued -- their inputs copied into a staging ring
-    # of SAF_WINDOW_FRAMES slots -- and fused when the window is full or when anything reads or replaces the
+    # of four windows (256 slots) -- and fused when the ring is full, when a window is complete and the device is idle,
+    # or when anything reads or replaces the
     # volume: the registered buffers (attribute access, state_dict, .to()), stats(), extract_mesh, the merge.
     # The two device paths are bit-identical, so a caller cannot tell -- except by speed.
     _DEFER_MAX_BATCH = 15  # calls of 16+ frames take the windowed path by themselves
+    # up to four windows per flush (from the second one on, a window is classified beside its predecessor's rows); a full
+    # window is flushed earlier when the device has finished the previous flush and would otherwise idle
+    _QUEUE_FRAMES = 4 * _abi.SAF_WINDOW_FRAMES
 
     def _defer_ok(self, bsz, feat):
         if not self.__dict__.get("defer_frames", True) or bsz > self._DEFER_MAX_BATCH:
@@ -201,28 +205,49 @@ class _FusionVolumeMixin:
         if st is None or st["key"] != key:
             self._flush_pending()
             dev = self._buffers["tsdf"].device
-            n = _abi.SAF_WINDOW_FRAMES
+            n = self._QUEUE_FRAMES
             mk = lambda *shape: torch.empty((n,) + shape, dtype=torch.float32, device=dev)
             st = {"key": key, "depth": mk(h, w), "rgb": mk(h, w, 3), "pose": mk(4, 4), "K": mk(3, 3),
                   "feat": mk(*key[2]), "labels": mk(h, w) if label_maps is not None else None, "event": None,
                   "stream": None}
             self.__dict__["_stage"] = st
-        with torch.cuda.device(self._buffers["tsdf"].device):
-            stream = torch.cuda.current_stream()
+        dev = self._buffers["tsdf"].device
+        with torch.cuda.device(dev):
+            # current_stream(dev), not current_stream(): without a device torch asks is_available() first, which looks up
+            # an environment variable by raising and catching a KeyError -- up to 100 us per call in a long-lived process
+            stream = torch.cuda.current_stream(dev)
             if st["event"] is not None and st["stream"] != stream.cuda_stream:
                 stream.wait_event(st["event"])  # the last flush may still be reading the staging ring on its stream
+            f32 = torch.float32
+            fast = all(t.dtype == f32 for t in (depth_imgs, rgb_imgs, poses, K, clip_feat_img)) and depth_imgs.is_contiguous() \
+                and rgb_imgs.is_contiguous() and poses.is_contiguous() and K.is_contiguous() and \
+                (label_maps is None or all(m.dtype == f32 and m.is_contiguous() for m in label_maps))
+            p = _abi.ptr
             for i in range(bsz):
                 k = self.__dict__["_pending_n"]
-                st["depth"][k].copy_(depth_imgs[i], non_blocking=True)
-                st["rgb"][k].copy_(rgb_imgs[i], non_blocking=True)
-                st["pose"][k].copy_(poses[i], non_blocking=True)
-                st["K"][k].copy_(K[i], non_blocking=True)
-                st["feat"][k].copy_(clip_feat_img[i], non_blocking=True)
-                if label_maps is not None:
-                    st["labels"][k].copy_(label_maps[i], non_blocking=True)
+                if fast:  # one launch per frame (saf_stage_frame)
+                    fm = clip_feat_img[i]
+                    src = _abi.SafFrame(h, w, p(depth_imgs[i]), p(rgb_imgs[i]), p(poses[i]), p(K[i]), p(fm), key[2][1], key[2][2],
+                                        p(label_maps[i]) if label_maps is not None else None, 0)
+                    dst = _abi.SafFrame(h, w, p(st["depth"][k]), p(st["rgb"][k]), p(st["pose"][k]), p(st["K"][k]), p(st["feat"][k]),
+                                        key[2][1], key[2][2], p(st["labels"][k]) if label_maps is not None else None, 0)
+                    check(lib().saf_stage_frame(C.byref(src), key[2][0], fm.stride(0), fm.stride(1), fm.stride(2), C.byref(dst),
+                                                stream.cuda_stream), "saf_stage_frame")
+                else:  # other dtypes / layouts: PyTorch copies convert
+                    st["depth"][k].copy_(depth_imgs[i], non_blocking=True)
+                    st["rgb"][k].copy_(rgb_imgs[i], non_blocking=True)
+                    st["pose"][k].copy_(poses[i], non_blocking=True)
+                    st["K"][k].copy_(K[i], non_blocking=True)
+                    st["feat"][k].copy_(clip_feat_img[i], non_blocking=True)
+                    if label_maps is not None:
+                        st["labels"][k].copy_(label_maps[i], non_blocking=True)
                 self.__dict__["_pending_n"] = k + 1
-                if k + 1 == _abi.SAF_WINDOW_FRAMES:
+                if k + 1 == self._QUEUE_FRAMES or ((k + 1) % _abi.SAF_WINDOW_FRAMES == 0 and
+                                                   (st["event"] is None or st["event"].query())):
                     self._flush_pending()
+            if fast:  # the sources are read asynchronously on this stream
+                for t in (depth_imgs, rgb_imgs, poses, K, clip_feat_img) + tuple(label_maps or ()):
+                    t.record_stream(stream)
 
     def flush(self):
         """Bring the registered buffers up to date: fuse the frames queued behind integrate() and finish a deferred
@@ -249,8 +274,9 @@ class _FusionVolumeMixin:
         st = self.__dict__["_stage"]
         labs = None if st["labels"] is None else [st["labels"][i] for i in range(n)]
         self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], st["feat"][:n], labs, st["key"][4])
-        with torch.cuda.device(self._buffers["tsdf"].device):
-            stream = torch.cuda.current_stream()
+        dev = self._buffers["tsdf"].device
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev)
             st["event"], st["stream"] = stream.record_event(), stream.cuda_stream
 
     @property
@@ -303,8 +329,9 @@ class _FusionVolumeMixin:
             # the per-frame pipeline reads every row it updates: the deferred clear has to happen first
             self._sync_volume()
         # the module's device, not the caller's current one, owns the launch (and its current stream)
-        with torch.cuda.device(self._buffers["tsdf"].device):
-            stream = torch.cuda.current_stream()
+        dev = self._buffers["tsdf"].device
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev)
             rc = lib().saf_fuse_frames(
                 C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), stream.cuda_stream
             )

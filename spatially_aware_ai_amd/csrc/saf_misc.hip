@@ -222,6 +222,32 @@ __global__ __launch_bounds__(256) void sample_vertices_kernel(
 }
 
 
+// One launch copies a frame's inputs into a slot of the staging ring behind integrate() (depth, rgb, pose, K, feature map,
+// label map): six tiny copy launches per frame would be most of the host's work per call and fill the stream's queue.
+struct StageArgs {
+  const float* src[6];
+  float* dst[6];
+  int n[6];
+  // the feature map may be a permuted view ([D, npy, npx] element strides); everything else is contiguous
+  int64_t fs0, fs1, fs2;
+  int f1, f2;
+};
+__global__ __launch_bounds__(256) void stage_frame_kernel(StageArgs a) {
+  const int seg = blockIdx.y;
+  const int n = a.n[seg];
+  const float* __restrict__ src = a.src[seg];
+  float* __restrict__ dst = a.dst[seg];
+  if (!src) return;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    if (seg == 4) {
+      const int x = i % a.f2, y = (i / a.f2) % a.f1, c = i / (a.f2 * a.f1);
+      dst[i] = src[(int64_t)c * a.fs0 + (int64_t)y * a.fs1 + (int64_t)x * a.fs2];
+    } else {
+      dst[i] = src[i];
+    }
+  }
+}
+
 // Rows of voxels that were never written (weight == 0) are zero by contract (include/saf.h, saf_volume).  A volume that
 // is recycled for a new scan need not be cleared up front -- the windowed fuse path never reads such rows -- as long as
 // the rows that are STILL unwritten are zeroed before anyone else looks: this kernel.  A wave checks 64 weights at a
@@ -405,6 +431,25 @@ int saf_clear_unwritten_rows(const saf_volume* vol, int64_t first_voxel, int64_t
     hipLaunchKernelGGL(clear_unwritten_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, vol->clip_feat, vol->weight, first_voxel,
                        n_rows, row_bytes);
   return check_launch("clear_unwritten_kernel");
+}
+
+int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_stride_c, int64_t feat_stride_y,
+                    int64_t feat_stride_x, const saf_frame* dst, void* stream) {
+  if (!src || !dst || !src->depth || !src->rgb || !src->pose || !src->K || !src->feat_map || !dst->depth || !dst->rgb ||
+      !dst->pose || !dst->K || !dst->feat_map || src->height <= 0 || src->width <= 0 || feat_channels <= 0 || src->npy <= 0 ||
+      src->npx <= 0 || (src->label_map && !dst->label_map))
+    return fail(SAF_E_INVALID, "stage_frame: bad arguments");
+  StageArgs a;
+  const int hw = src->height * src->width;
+  const float* s[6] = {src->depth, src->rgb, src->pose, src->K, src->feat_map, src->label_map};
+  float* d[6] = {const_cast<float*>(dst->depth), const_cast<float*>(dst->rgb), const_cast<float*>(dst->pose),
+                 const_cast<float*>(dst->K), const_cast<float*>(dst->feat_map), const_cast<float*>(dst->label_map)};
+  const int n[6] = {hw, 3 * hw, 16, 9, feat_channels * src->npy * src->npx, src->label_map ? hw : 0};
+  for (int k = 0; k < 6; ++k) { a.src[k] = s[k]; a.dst[k] = d[k]; a.n[k] = n[k]; }
+  a.fs0 = feat_stride_c; a.fs1 = feat_stride_y; a.fs2 = feat_stride_x; a.f1 = src->npy; a.f2 = src->npx;
+  const int blocks = (3 * hw + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(stage_frame_kernel, dim3(blocks > 0 ? blocks : 1, 6), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("stage_frame_kernel");
 }
 
 }  // extern "C"
