@@ -43,7 +43,8 @@ from spatially_aware_ai_amd import _abi  # noqa: E402
 from spatially_aware_ai_amd import synthetic as syn  # noqa: E402
 from spatially_aware_ai_amd._lib import check, lib  # noqa: E402
 
-WIN = 64  # frames per window of the windowed path (include/saf.h SAF_WINDOW_FRAMES)
+# frames per window of the windowed path (include/saf.h SAF_WINDOW_FRAMES; SAF_WIN_FRAMES=64 selects the shorter form)
+WIN = 64 if os.environ.get("SAF_WIN_FRAMES") == "64" else 128
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 
 
@@ -80,6 +81,7 @@ def parse():
                          "ViT-B/32-shaped random-weight CLIP image tower in front of the fuse (reported separately)")
     ap.add_argument("--e2e-batch", type=int, default=8, help="frames per integrate() call in the end-to-end pass")
     ap.add_argument("--e2e-dtype", default="f32", choices=["f32", "bf16"], help="backbone compute dtype")
+    ap.add_argument("--e2e-tile-batch", type=int, default=0, help="tiles per encode_image call (0 = the Clip class's default)")
     ap.add_argument("--api-b1", type=int, default=0, metavar="FRAMES",
                     help="also time FRAMES frames through integrate_features() ONE FRAME PER CALL (the reference's loop, "
                          "clipfusion.py:1125-1133) with the deferred window queue behind it; reported as api_b1")
@@ -353,7 +355,7 @@ def main():
         lab = 8 if a.labels else 0  # one label counter RMW per valid voxel
         windowed = st.get("window_rows", 0) > 0
         if windowed:
-            # SURVEY.md §8d, launches covering a frame set S (a window of up to WIN = 64 frames):
+            # SURVEY.md §8d, launches covering a frame set S (a window of up to WIN frames):
             # B_fuse(S) = U_v*(2*D*s + 2*12 + 2*4 [+2*4]) + U_t*(2*4 + 2*4) + sum_f (H*W*(4+12[+4]) + D*npy*npx*4)
             # with U_v = rows the window read-modify-wrote, U_t = voxels whose TSDF it updated (kernel counters).
             # fuse_window_kernel's share: the rows, rgb / weight / label side, rgb + label images and the maps;
@@ -500,6 +502,8 @@ def main():
 
         clip = Clip("ViT-B-32 (random weights)", None, backbone=RandomViTB32(), tokenizer=None).to(device).eval()
         clip.requires_grad_(False)
+        if a.e2e_tile_batch > 0:
+            clip.max_patch_batch_size = a.e2e_tile_batch
         fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, a.height // 3,
                         a.height // 6, keep_xyz_world=False, feat_dtype=fdt).to(device)
         nfr = min(a.end_to_end, uniq)
@@ -525,6 +529,7 @@ def main():
             d2 = time.perf_counter() - t2
         e2e = {
             "value": round(nfr / d1, 1), "unit": "frames/s", "frames": nfr, "batch": bs,
+            "tiles_per_encode_call": int(clip.max_patch_batch_size),
             "backbone": "ViT-B/32 image tower, seeded random weights (no CLIP weights offline), 35 tiles/frame, "
                         + a.e2e_dtype,
             "backbone_only_frames_per_s": round(nfr / d2, 1),
@@ -761,20 +766,24 @@ def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value)
 
     job()
     torch.cuda.synchronize()
-    if os.environ.get("SAF_BENCH_PROFILE_API") == "1":  # development: where does the host time of the loop go?
-        import cProfile
-        import pstats
-
-        pr = cProfile.Profile()
-        pr.enable()
-        job()
-        pr.disable()
+    if os.environ.get("SAF_BENCH_PROFILE_API") == "1":  # development: which calls of the loop block the host?
+        ts = []
+        fusion.reset()
+        for i in range(n):
+            t = time.perf_counter()
+            fusion.integrate_features(depth[i:i + 1], rgb[i:i + 1], poses[i:i + 1], ks[i:i + 1], feat[i:i + 1],
+                                      None if label_maps is None else [label_maps[i]])
+            ts.append(time.perf_counter() - t)
+        t = time.perf_counter()
+        fusion.flush()
+        ts.append(time.perf_counter() - t)
         torch.cuda.synchronize()
-        ps = pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime")
-        ps.print_stats(8)
-        ps.print_callers("get")
-        ps.print_callees("get")
+        print("api_b1 host us per call, buckets of 32:", " ".join(f"{sum(ts[i:i + 32]) / 32 * 1e6:.0f}" for i in range(0, n, 32)),
+              " slowest (us, call):", sorted(((round(t * 1e6), i) for i, t in enumerate(ts)), reverse=True)[:6], file=sys.stderr)
     fusion.fuse_stats.zero_()
+    import gc
+
+    gc.collect()  # a full collection of this process takes ~40 ms: not inside the timed loop (timeit's hygiene)
     t0 = time.perf_counter()
     job()
     host_s = time.perf_counter() - t0  # the host has queued everything
@@ -785,7 +794,7 @@ def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value)
     return {"value": round(n / dt, 2), "unit": "frames/s", "frames": n, "frames_per_call": 1,
             "vs_bulk": round(n / dt / bulk_value, 4), "host_enqueue_us_per_call": round(host_s / n * 1e6, 1),
             "windowed": st["window_rows"] > 0,
-            "note": "one frame per integrate_features() call, deferred window queue (64-frame windows), includes the reset "
+            "note": "one frame per integrate_features() call, deferred window queue (%d-frame windows)" % WIN + ", includes the reset "
                     "of the volume and the final flush; `vs_bulk` = this / the bulk `value` of the same run"}
 
 

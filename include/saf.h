@@ -99,8 +99,9 @@ typedef struct saf_frame {
  *      0 when the per-frame pipeline ran)  [6] voxels whose TSDF a window's classification updated
  *      (sum over windows of |union of tsdf-valid sets|)  [7] reserved */
 #define SAF_STATS_WORDS 8
-/* frames per window of the windowed path of saf_fuse_frames (stats[5] and [6] count per window) */
-#define SAF_WINDOW_FRAMES 64
+/* frames per window of the windowed path of saf_fuse_frames (stats[5] and [6] count per window); SAF_WIN_FRAMES=64 in the
+ * environment selects 64-frame windows */
+#define SAF_WINDOW_FRAMES 128
 
 const char* saf_last_error(void);
 int saf_abi_version(void);
@@ -124,7 +125,7 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
  * Two device paths, identical results bit for bit:
  *  - per-frame pipeline: one sweep + one fuse kernel per frame (any shape);
  *  - windowed, voxel-major (16 or more frames of one shape; f32 volume with feat_dim a multiple of 256, or
- *    bf16 volume with feat_dim a multiple of 512; feat_dim <= 1024): per window of SAF_WINDOW_FRAMES frames two classification launches (sweep of 32 frames each,
+ *    bf16 volume with feat_dim a multiple of 512; feat_dim <= 1024): per window of SAF_WINDOW_FRAMES frames one classification launch per 32 frames (sweep,
  *    TSDF in registers, one frame-mask word per voxel) and one row kernel that reads and writes every
  *    touched feature row once per window.
  *    SAF_WINDOW=0 in the environment forces the per-frame pipeline. */

@@ -24,6 +24,10 @@ import torch
 from . import _abi
 from ._lib import SafError, check, current_stream_ptr, lib, require_cuda
 
+_FRAME_WORDS = C.sizeof(_abi.SafFrame) // 8
+assert C.sizeof(_abi.SafFrame) == 72 and _abi.SafFrame.depth.offset == 8 and _abi.SafFrame.npy.offset == 48 and \
+    _abi.SafFrame.label_map.offset == 56 and _abi.SafFrame.rgb_bilinear.offset == 64, "struct saf_frame layout (include/saf.h)"
+
 # --------------------------------------------------------------------------------------------
 # volume plumbing shared by ClipFusion and ClipSeemFusion
 # --------------------------------------------------------------------------------------------
@@ -142,21 +146,36 @@ class _FusionVolumeMixin:
             raise ValueError("poses must be [B,4,4] and K [B,3,3]")
         if feat.dim() != 4 or feat.shape[0] != bsz or feat.shape[1] < self.n_clip_feats:
             raise ValueError(f"feature map must be [B,D>={self.n_clip_feats},npy,npx], got {tuple(feat.shape)}")
-        labs = None
-        if label_maps is not None:
+        labs = lab_ptrs = None
+        if torch.is_tensor(label_maps):  # one [B,H,W] tensor (the staging ring)
+            labs = self._f32c(label_maps, "label maps")
+            if labs.shape != (bsz, h, w):
+                raise ValueError("label maps must be [B,H,W]")
+            lab_ptrs = labs.data_ptr() + np.arange(bsz, dtype=np.int64) * (4 * h * w)
+            labs = [labs]
+        elif label_maps is not None:
             labs = [self._f32c(m, "label map") for m in label_maps]
             for m in labs:
                 if m.shape != (h, w):
                     raise ValueError("label map must be [H,W]")
+            lab_ptrs = np.fromiter((m.data_ptr() for m in labs), dtype=np.int64, count=bsz)
         npy, npx = int(feat.shape[2]), int(feat.shape[3])
-        arr = (_abi.SafFrame * bsz)()
-        p = _abi.ptr
-        for i in range(bsz):
-            arr[i] = _abi.SafFrame(
-                h, w, p(depth_imgs[i]), p(rgb_imgs[i]), p(poses[i]), p(K[i]), p(feat[i]), npy, npx,
-                p(labs[i]) if labs is not None else None, int(bool(rgb_bilinear)),
-            )
-        return arr, (depth_imgs, rgb_imgs, poses, K, feat, labs), npy, npx
+        # the descriptors as int64 words (struct saf_frame, include/saf.h: 72 bytes), filled column by column: a Python
+        # object per frame and field would be thousands of short-lived objects per flush -- garbage-collector pauses
+        # in the middle of the one-frame-per-call loop
+        arr = np.zeros((bsz, _FRAME_WORDS), dtype=np.int64)
+        idx = np.arange(bsz, dtype=np.int64)
+        arr[:, 0] = h | (w << 32)
+        arr[:, 1] = depth_imgs.data_ptr() + idx * (4 * h * w)
+        arr[:, 2] = rgb_imgs.data_ptr() + idx * (12 * h * w)
+        arr[:, 3] = poses.data_ptr() + idx * 64
+        arr[:, 4] = K.data_ptr() + idx * 36
+        arr[:, 5] = feat.data_ptr() + idx * (4 * int(feat.shape[1]) * npy * npx)
+        arr[:, 6] = npy | (npx << 32)
+        if lab_ptrs is not None:
+            arr[:, 7] = lab_ptrs
+        arr[:, 8] = int(bool(rgb_bilinear))
+        return (_abi.SafFrame * bsz).from_buffer(arr), (depth_imgs, rgb_imgs, poses, K, feat, labs), npy, npx
 
     # -- the deferred window queue ---------------------------------------------------------------
     # The reference calls integrate() with ONE frame per DataLoader batch (clip_seem_fusion.py:303-313,
@@ -209,7 +228,11 @@ class _FusionVolumeMixin:
             mk = lambda *shape: torch.empty((n,) + shape, dtype=torch.float32, device=dev)
             st = {"key": key, "depth": mk(h, w), "rgb": mk(h, w, 3), "pose": mk(4, 4), "K": mk(3, 3),
                   "feat": mk(*key[2]), "labels": mk(h, w) if label_maps is not None else None, "event": None,
-                  "stream": None}
+                  "stream": None, "src": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0),
+                  "dst": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0)}
+            # base addresses and byte strides of the ring's slots (no tensor views per call)
+            st["base"] = tuple(st[k].data_ptr() if st[k] is not None else 0 for k in ("depth", "rgb", "pose", "K", "feat", "labels"))
+            st["step"] = (4 * h * w, 12 * h * w, 64, 36, 4 * key[2][0] * key[2][1] * key[2][2], 4 * h * w)
             self.__dict__["_stage"] = st
         dev = self._buffers["tsdf"].device
         with torch.cuda.device(dev):
@@ -222,17 +245,22 @@ class _FusionVolumeMixin:
             fast = all(t.dtype == f32 for t in (depth_imgs, rgb_imgs, poses, K, clip_feat_img)) and depth_imgs.is_contiguous() \
                 and rgb_imgs.is_contiguous() and poses.is_contiguous() and K.is_contiguous() and \
                 (label_maps is None or all(m.dtype == f32 and m.is_contiguous() for m in label_maps))
-            p = _abi.ptr
+            src, dst, base, step = st["src"], st["dst"], st["base"], st["step"]
+            raw_stream = stream.cuda_stream
+            if fast:
+                fs = clip_feat_img.stride()
+                sp = (depth_imgs.data_ptr(), rgb_imgs.data_ptr(), poses.data_ptr(), K.data_ptr(), clip_feat_img.data_ptr())
             for i in range(bsz):
                 k = self.__dict__["_pending_n"]
-                if fast:  # one launch per frame (saf_stage_frame)
-                    fm = clip_feat_img[i]
-                    src = _abi.SafFrame(h, w, p(depth_imgs[i]), p(rgb_imgs[i]), p(poses[i]), p(K[i]), p(fm), key[2][1], key[2][2],
-                                        p(label_maps[i]) if label_maps is not None else None, 0)
-                    dst = _abi.SafFrame(h, w, p(st["depth"][k]), p(st["rgb"][k]), p(st["pose"][k]), p(st["K"][k]), p(st["feat"][k]),
-                                        key[2][1], key[2][2], p(st["labels"][k]) if label_maps is not None else None, 0)
-                    check(lib().saf_stage_frame(C.byref(src), key[2][0], fm.stride(0), fm.stride(1), fm.stride(2), C.byref(dst),
-                                                stream.cuda_stream), "saf_stage_frame")
+                if fast:  # one launch per frame (saf_stage_frame); addresses by arithmetic: no tensor views, no new descriptors
+                    src.depth, src.rgb, src.pose = sp[0] + i * step[0], sp[1] + i * step[1], sp[2] + i * 64
+                    src.K, src.feat_map = sp[3] + i * 36, sp[4] + i * fs[0] * 4
+                    dst.depth, dst.rgb, dst.pose = base[0] + k * step[0], base[1] + k * step[1], base[2] + k * step[2]
+                    dst.K, dst.feat_map = base[3] + k * step[3], base[4] + k * step[4]
+                    if label_maps is not None:
+                        src.label_map, dst.label_map = label_maps[i].data_ptr(), base[5] + k * step[5]
+                    check(lib().saf_stage_frame(C.byref(src), key[2][0], fs[1], fs[2], fs[3], C.byref(dst), raw_stream),
+                          "saf_stage_frame")
                 else:  # other dtypes / layouts: PyTorch copies convert
                     st["depth"][k].copy_(depth_imgs[i], non_blocking=True)
                     st["rgb"][k].copy_(rgb_imgs[i], non_blocking=True)
@@ -272,7 +300,7 @@ class _FusionVolumeMixin:
             return
         self.__dict__["_pending_n"] = 0  # first: the buffer accesses below must not re-enter
         st = self.__dict__["_stage"]
-        labs = None if st["labels"] is None else [st["labels"][i] for i in range(n)]
+        labs = None if st["labels"] is None else st["labels"][:n]
         self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], st["feat"][:n], labs, st["key"][4])
         dev = self._buffers["tsdf"].device
         with torch.cuda.device(dev):

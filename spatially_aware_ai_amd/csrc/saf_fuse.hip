@@ -941,7 +941,7 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
   if (window_ok(kv, frames, n_frames, workspace_bytes)) {
     // SAF_WIN_OVERLAP=0: every kernel of the windowed path on the caller's stream (read per call: same-process A/Bs)
     const char* ov_env = getenv("SAF_WIN_OVERLAP");
-    PipeRes* pr = (ov_env && ov_env[0] == '0') || n_frames <= SAF_WINDOW_FRAMES ? nullptr : pipe_acquire();
+    PipeRes* pr = (ov_env && ov_env[0] == '0') || n_frames <= window_frames() ? nullptr : pipe_acquire();
     if (!pr) return fuse_many_windowed(kv, frames, n_frames, workspace, stats, prof, s, nullptr);
     WinOverlap ov;
     ov.aux = pr->aux; ov.fork = pr->fork; ov.join = pr->join;

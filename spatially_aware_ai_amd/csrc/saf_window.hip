@@ -2,28 +2,22 @@
 // 64 frames two classification launches (32 frames each: sweep + TSDF in registers, one frame-mask plane) and one
 // row kernel that reads and writes every touched feature row once.  Bit-identical to the per-frame pipeline of
 // saf_fuse.hip; selected by saf_fuse_frames for calls of 16 or more frames of one shape.
+#include <chrono>
+
 #include "saf_fuse_dev.h"
 
 namespace saf {
 namespace {
 
-constexpr size_t kHdrBytes = 2048;   // one workspace header (piece counter, dmax, counter shards)
+constexpr size_t kHdrBytes = 8192;   // one workspace header (unit counters, dmax, counter shards, the window's frame table)
 constexpr size_t kHdrTotal = 2 * kHdrBytes;  // two of them, and two mask buffers: window w + 1 is classified while window w's rows are fused
 
 // Pixel-major image for the windowed path, whose taps are read from global memory (L2): row p holds
 // the D channels of map position p contiguously (a wave's tap load is one contiguous D*4 bytes), row P
 // is the zero row of the taps outside the map.
-struct PrepArgs {
-  const float* feat_map[64];  // >= kWin
-};
-__global__ __launch_bounds__(256) void prep_rows_kernel(PrepArgs pa, float* __restrict__ imgs, int img_floats, int D,
-                                                        int P) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= (P + 1) * D) return;
-  const float* __restrict__ feat_map = pa.feat_map[blockIdx.y];
-  const int c = o % D, p = o / D;
-  imgs[(size_t)blockIdx.y * img_floats + o] = p < P ? feat_map[(size_t)c * P + p] : 0.0f;
-}
+struct WinTable;
+__global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restrict__ tab, float* __restrict__ imgs,
+                                                        int img_floats, int D, int P);
 
 // ------------------------------------------------------------------------------------------
 // fuse, voxel-major over a WINDOW of up to 64 frames (saf_fuse_frames with many frames).
@@ -48,26 +42,65 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(PrepArgs pa, float* __re
 //   which are loaded from the window's map images (L2) ONCE per group, P groups in flight -- each hit
 //   updates its row in LDS, and the rows are streamed back.
 // ------------------------------------------------------------------------------------------
-constexpr int kWin = SAF_WINDOW_FRAMES;  // frames per window: two 32-bit mask words per voxel
-static_assert(kWin == 64, "the mask layout and the 6-bit frame field assume 64-frame windows");
+constexpr int kWin = SAF_WINDOW_FRAMES;  // frames of the longest window: four 32-bit mask words per voxel
+static_assert(kWin == 128, "the mask layout and the 7-bit frame field assume windows of up to 128 frames");
 constexpr int kMaskWords = kWin / 32;
+constexpr int kClsFrames = 32;  // frames of one classification launch = one mask plane
 constexpr int kWinMinFrames = 16;  // shorter calls run the per-frame pipeline
 #ifndef SAF_WIN_HITCAP
 #define SAF_WIN_HITCAP 128
 #endif
 constexpr int kHitCap = SAF_WIN_HITCAP;
+static_assert(kHitCap >= kWin, "a voxel's hits of one window must fit a chunk");
 constexpr int kWinThreads = 256;
 constexpr int kWinWaves = kWinThreads / 64;
 constexpr int kPiece = 256;
 
-struct WinArgs {
-  int F, H, W, npy, npx, rgb_bilinear;
-  const float* depth[kWin];
+// The frames of ONE classification launch travel by value (a window's 128 x 6 pointers would not fit the 4 KB
+// kernel-argument segment); the launch also files them in the window's frame table in device memory (workspace header),
+// which prep_rows_kernel and the row kernel read.
+struct ClsArgs {
+  int n, H, W;  // frames of this launch (<= kClsFrames), image size
+  int slot;     // index of the launch's first frame within the window (0, 32, 64, 96)
+  const float* depth[kClsFrames];
+  const float* rgb[kClsFrames];
+  const float* pose[kClsFrames];
+  const float* K[kClsFrames];
+  const float* label_map[kClsFrames];
+  const float* feat_map[kClsFrames];
+};
+struct WinTable {
   const float* rgb[kWin];
   const float* pose[kWin];
   const float* K[kWin];
   const float* label_map[kWin];
+  const float* feat_map[kWin];
 };
+struct WinArgs {  // what is common to a window's frames
+  int F, H, W, npy, npx, rgb_bilinear;
+};
+constexpr size_t kTableOff = 2048;  // WinTable in the workspace header
+static_assert(kTableOff + sizeof(WinTable) <= kHdrBytes, "workspace header layout");
+
+__device__ __forceinline__ void file_frames(const ClsArgs& ca, WinTable* __restrict__ tab, int tid) {
+  if (tab && blockIdx.x == 0 && tid < ca.n) {
+    const int k = ca.slot + tid;
+    tab->rgb[k] = ca.rgb[tid];
+    tab->pose[k] = ca.pose[tid];
+    tab->K[k] = ca.K[tid];
+    tab->label_map[k] = ca.label_map[tid];
+    tab->feat_map[k] = ca.feat_map[tid];
+  }
+}
+
+__global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restrict__ tab, float* __restrict__ imgs,
+                                                        int img_floats, int D, int P) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (P + 1) * D) return;
+  const float* __restrict__ feat_map = tab->feat_map[blockIdx.y];
+  const int c = o % D, p = o / D;
+  imgs[(size_t)blockIdx.y * img_floats + o] = p < P ? feat_map[(size_t)c * P + p] : 0.0f;
+}
 
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wave execute in order; this only stops the compiler from moving them
@@ -105,6 +138,7 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_WIN_WPE
 #define SAF_WIN_WPE 2
 #endif
+constexpr int kUnitVox = kPiece >> SAF_WIN_SPLIT_LOG2;  // voxels of a unit of work (a quarter piece)
 template <int CPL>
 struct WinCfg {
   static constexpr int SR = CPL == 1 ? 8 : (CPL == 2 ? SAF_WIN_SR2 : 3);  // rows of a sub-chunk (LDS resident)
@@ -115,9 +149,9 @@ struct WinCfg {
   static constexpr size_t stage_off = rows_off + rows_bytes;  // 6 arrays of kHitCap words per wave
   static constexpr size_t stage_bytes = (size_t)kWinWaves * 6 * kHitCap * 4;
   static constexpr size_t tm_off = stage_off + stage_bytes;
-  static constexpr size_t tm_bytes = (size_t)kWinWaves * kPiece * 4 * kMaskWords;
+  static constexpr size_t tm_bytes = (size_t)kWinWaves * kUnitVox * 4 * kMaskWords;  // a unit's touched voxels: masks
   static constexpr size_t tv_off = tm_off + tm_bytes;
-  static constexpr size_t tv_bytes = (size_t)kWinWaves * kPiece * 2;
+  static constexpr size_t tv_bytes = (size_t)kWinWaves * kUnitVox * 2;  // ... and local ids
   static constexpr size_t ptr_off = tv_off + tv_bytes;
   static constexpr size_t ptr_bytes = (size_t)2 * kWin * sizeof(const float*);
   static constexpr size_t cam_off = ptr_off + ptr_bytes;
@@ -129,11 +163,11 @@ struct WinCfg {
 // (clipfusion.py:681-695 with B = 1, frame after frame -- order dependent) and written once; mk4[j] collects
 // the frame bitmask of voxel j.  KFU frames at a time: their depth gathers are in flight together.
 // The classification of a lane's 4 consecutive voxels (flat indices nb .. nb+3, world coordinates xw/yw/zw,
-// inb = inside the grid) against the frames of `live` (bit k = frame f_begin + k), ascending.
+// inb = inside the grid) against the frames of `live` (bit k = frame k of the launch), ascending.
 template <int KFU, bool SUM>
-__device__ __forceinline__ void classify_voxels(const KVol& v, const WinArgs& wa, const Cam* __restrict__ s_cam, uint32_t nb,
+__device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa, const Cam* __restrict__ s_cam, uint32_t nb,
                                                 const float (&xw)[4], const float (&yw)[4], const float (&zw)[4],
-                                                const bool (&inb)[4], float rtrunc, bool tsdf_aligned, int f_begin,
+                                                const bool (&inb)[4], float rtrunc, bool tsdf_aligned,
                                                 uint32_t live, uint32_t (&mk4)[4], unsigned long long& nt_done,
                                                 unsigned long long& tsdf_rows_done) {
   float told[4];
@@ -167,7 +201,7 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const WinArgs& wa
 #pragma unroll
     for (int u = 0; u < kFU; ++u) {
       const bool on = fr[u] >= 0;
-      const Cam cam = s_cam[f_begin + (on ? fr[u] : 0)];
+      const Cam cam = s_cam[on ? fr[u] : 0];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const Proj p = project(cam, xw[j], yw[j], zw[j]);
@@ -180,7 +214,7 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const WinArgs& wa
     float depth[kFU][4];
 #pragma unroll
     for (int u = 0; u < kFU; ++u) {
-      const float* __restrict__ dimg = wa.depth[f_begin + (fr[u] >= 0 ? fr[u] : 0)];
+      const float* __restrict__ dimg = wa.depth[fr[u] >= 0 ? fr[u] : 0];
 #pragma unroll
       for (int j = 0; j < 4; ++j) depth[u][j] = pix[u][j] >= 0 ? dimg[pix[u][j]] : 0.0f;
     }
@@ -225,12 +259,12 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const WinArgs& wa
   }
 }
 
-// Classification of one piece of 256 consecutive voxels (a lane owns 4 of them) against frames
-// [f_begin, f_end) (clipfusion.py:647-695): used when the grid does not tile into bricks.
+// Classification of one piece of 256 consecutive voxels (a lane owns 4 of them) against the launch's frames
+// (clipfusion.py:647-695): used when the grid does not tile into bricks.
 template <int KFU, bool SUM>
-__device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa, const Cam* __restrict__ s_cam,
+__device__ __forceinline__ void classify_piece(const KVol& v, const ClsArgs& wa, const Cam* __restrict__ s_cam,
                                                uint32_t piece_base, int lane, float rtrunc, bool tsdf_aligned,
-                                               int f_begin, int f_end, uint32_t (&mk4)[4], unsigned long long& nt_done,
+                                               uint32_t (&mk4)[4], unsigned long long& nt_done,
                                                unsigned long long& tsdf_rows_done) {
   const uint32_t nb = piece_base + (uint32_t)lane * 4u;
   float xw[4], yw[4], zw[4];
@@ -244,10 +278,9 @@ __device__ __forceinline__ void classify_piece(const KVol& v, const WinArgs& wa,
     yw[j] = v.ay[iy];
     zw[j] = v.az[iz];
   }
-  const int nf = f_end - f_begin;
+  const int nf = wa.n;
   const uint32_t live = nf >= 32 ? 0xffffffffu : ((1u << nf) - 1u);
-  classify_voxels<KFU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, f_begin, live, mk4, nt_done,
-                            tsdf_rows_done);
+  classify_voxels<KFU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
 }
 
 // Counters of a classification launch.  One atomic per WAVE on stats[1] / stats[6] would be 131 k atomics on
@@ -276,19 +309,20 @@ __device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsig
   }
 }
 
-// classify_window_kernel: one launch per 32 frames of a window [f_begin, f_end); leaves that mask word of
+// classify_window_kernel: one launch per 32 frames of a window; leaves that mask word of
 // every voxel in its plane of `hitmask` and the updated TSDF.  (One launch over all 64 frames keeps the TSDF
 // in registers twice as long but puts 64 depth-image footprints in L2 at once: 4.2 ms against 2 x 1.9 ms.)
 template <bool SUM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_window_kernel(
-    KVol v, WinArgs wa, int f_begin, int f_end, int tile, uint32_t* __restrict__ hitmask,
-    unsigned long long* __restrict__ stats, unsigned long long* __restrict__ cls_acc) {
-  __shared__ Cam s_cam[kWin];
+    KVol v, ClsArgs wa, int tile, uint32_t* __restrict__ hitmask, unsigned long long* __restrict__ stats,
+    unsigned long long* __restrict__ cls_acc, WinTable* __restrict__ tab) {
+  __shared__ Cam s_cam[kClsFrames];
   __shared__ unsigned long long s_acc[4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid >= f_begin && tid < f_end) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
+  if (tid < wa.n) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
+  file_frames(wa, tab, tid);
   __syncthreads();
-  if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)(f_end - f_begin));
+  if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)wa.n);
   const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
   uint32_t piece = blockIdx.x * 4u + (uint32_t)wave;
   const bool on = piece < n_pieces;  // (no early return: the workgroup meets again in cls_accumulate)
@@ -310,8 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
   if (on) {
     const uint32_t nb = piece * (uint32_t)kPiece + (uint32_t)lane * 4u;
     uint32_t mk4[4] = {0u, 0u, 0u, 0u};
-    classify_piece<4, SUM>(v, wa, s_cam, piece * (uint32_t)kPiece, lane, rtrunc, tsdf_aligned, f_begin, f_end, mk4, nt_done,
-                           tsdf_rows_done);
+    classify_piece<4, SUM>(v, wa, s_cam, piece * (uint32_t)kPiece, lane, rtrunc, tsdf_aligned, mk4, nt_done, tsdf_rows_done);
     if (nb + 3u < v.N) {
       *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);
     } else {
@@ -334,8 +367,8 @@ constexpr size_t kDmaxOff = 256;  // 32 floats in the workspace header: largest 
 
 // dmax[k] = max over the pixels of frame k of max(depth, 0) (NaN ignored, +inf kept): non-negative floats
 // order like their bit patterns, so an integer atomicMax does it.
-__global__ __launch_bounds__(256) void depth_max_kernel(WinArgs wa, int f_begin, int hw, int* __restrict__ dmax_bits) {
-  const float* __restrict__ d = wa.depth[f_begin + blockIdx.y];
+__global__ __launch_bounds__(256) void depth_max_kernel(ClsArgs wa, int hw, int* __restrict__ dmax_bits) {
+  const float* __restrict__ d = wa.depth[blockIdx.y];
   float m = 0.0f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
     const float x = d[i];
@@ -350,13 +383,14 @@ __global__ __launch_bounds__(256) void depth_max_kernel(WinArgs wa, int f_begin,
 
 template <bool SUM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE))) void classify_bricks_kernel(
-    KVol v, WinArgs wa, int f_begin, int f_end, int tiled, const float* __restrict__ dmax, uint32_t* __restrict__ hitmask,
-    unsigned long long* __restrict__ stats, unsigned long long* __restrict__ cls_acc) {
-  __shared__ Cam s_cam[kWin];
+    KVol v, ClsArgs wa, int tiled, const float* __restrict__ dmax, uint32_t* __restrict__ hitmask,
+    unsigned long long* __restrict__ stats, unsigned long long* __restrict__ cls_acc, WinTable* __restrict__ tab) {
+  __shared__ Cam s_cam[kClsFrames];
   __shared__ unsigned long long s_acc[4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_f = f_end - f_begin;
-  if (tid >= f_begin && tid < f_end) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
+  const int n_f = wa.n;
+  if (tid < n_f) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
+  file_frames(wa, tab, tid);
   __syncthreads();
   if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_f);
   const uint32_t nbx = (uint32_t)v.nx / kBrickX, nby = (uint32_t)v.ny / kBrickY, nbz = (uint32_t)v.nz / kBrickZ;
@@ -398,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
     const float rho = sqrtf(hx * hx + hy * hy + hz * hz) * 1.02f + 1e-4f;  // voxel CENTRES are what is tested
     bool dead = false;
     if (lane < n_f) {
-      const Cam c = s_cam[f_begin + lane];
+      const Cam c = s_cam[lane];
       const bool pinhole = c.k01 == 0.0f && c.k10 == 0.0f && c.k20 == 0.0f && c.k21 == 0.0f && c.k22 == 1.0f;
       const float dx = cxw - c.tx, dy = cyw - c.ty, dz = czw - c.tz;
       const float xc = c.r00 * dx + c.r10 * dy + c.r20 * dz;  // R^T (X - t)
@@ -434,8 +468,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   unsigned long long nt_done = 0, tsdf_rows_done = 0;
   uint32_t mk4[4] = {0u, 0u, 0u, 0u};
   if (live)
-    classify_voxels<SAF_CLS_FU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, f_begin, live, mk4, nt_done,
-                                     tsdf_rows_done);
+    classify_voxels<SAF_CLS_FU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
   if (on) *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);  // nz % 16 == 0: aligned
   cls_accumulate(nt_done, tsdf_rows_done, lane, wave, s_acc, stats ? cls_acc : nullptr);
 }
@@ -487,7 +520,7 @@ __device__ __forceinline__ WinGroupOffs win_group_offsets(const WinCtx<CPL>& cx,
 // NB groups: request the four map rows of every group, then blend group after group into the LDS rows
 // (the waits are counted: group u is processed while the rows of groups u+1.. are still in flight).
 template <int NB, int CPL, bool SUM, bool BF16, int SR>
-__device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, const WinGroupOffs& go, uint32_t gm_lo,
+__device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, bool first, const WinGroupOffs& go, uint32_t gm_lo,
                                           uint32_t gm_hi, const WinHit& rec, const WinRaw<SR, BF16 ? CPL / 2 : 1>& raw) {
   float4 tp[NB][4][CPL];
 #pragma unroll
@@ -506,7 +539,7 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, const W
       tp[u][3][c] = img[o_se + win_chunk_off<BF16>(c)];
     }
   }
-  if (g0 == 0) {  // the sub-chunk's rows (issued before these loads) have landed after this
+  if (first) {  // the sub-chunk's first batch: its rows (issued before these loads) have landed after this
     // the BUILTIN, not inline asm: the compiler's wait-count pass must see that the LDS-DMA has been
     // waited for, or it drains vmcnt before every later LDS read (each row's store waited for the last)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
@@ -558,9 +591,10 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, const W
 
 template <int CPL, bool SUM, bool BF16>
 __global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(SAF_WIN_WPE, SAF_WIN_WPE))) void
-fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int img_vecs,
+fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, int img_vecs,
                    unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
-                   const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc) {
+                   const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc,
+                   int xcd_order) {
   using Cfg = WinCfg<CPL>;
   constexpr int SR = Cfg::SR;
   // (s_setprio 1 / 3 here, ahead of the classification waves that share the SIMDs, changes nothing: 105.4 / 105.7 / 105.8 ms)
@@ -570,14 +604,14 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4* rows = reinterpret_cast<float4*>(s_dyn + Cfg::rows_off) + (size_t)wave * SR * CPL * 64;
   uint32_t* stage = reinterpret_cast<uint32_t*>(s_dyn + Cfg::stage_off) + (size_t)wave * 6 * kHitCap;
-  uint32_t* s_hf = stage;  // voxel lane (6 bits) | cell << 6 (16 bits) | frame of the window << 22 (6 bits)
+  uint32_t* s_hf = stage;  // voxel lane (6 bits) | cell << 6 (16 bits) | frame of the window << 22 (7 bits)
   int* s_hw = reinterpret_cast<int*>(stage + kHitCap);
   float* s_ha = reinterpret_cast<float*>(stage + 2 * kHitCap);
   float* s_hb = reinterpret_cast<float*>(stage + 3 * kHitCap);
   float* s_hgx = reinterpret_cast<float*>(stage + 4 * kHitCap);
   float* s_hgy = reinterpret_cast<float*>(stage + 5 * kHitCap);
-  uint32_t* s_tm = reinterpret_cast<uint32_t*>(s_dyn + Cfg::tm_off) + wave * kPiece * kMaskWords;
-  uint16_t* s_tv = reinterpret_cast<uint16_t*>(s_dyn + Cfg::tv_off) + wave * kPiece;
+  uint32_t* s_tm = reinterpret_cast<uint32_t*>(s_dyn + Cfg::tm_off) + wave * kUnitVox * kMaskWords;
+  uint16_t* s_tv = reinterpret_cast<uint16_t*>(s_dyn + Cfg::tv_off) + wave * kUnitVox;
   const float** s_rgb = reinterpret_cast<const float**>(s_dyn + Cfg::ptr_off);
   const float** s_lab = s_rgb + kWin;
   Cam* s_cam = reinterpret_cast<Cam*>(s_dyn + Cfg::cam_off);
@@ -593,10 +627,11 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
       if (b) atomicAdd(&stats[6], b);
     }
   }
+  static_assert(kWinThreads >= kWin, "one thread per frame loads the window's cameras");
   if (tid < wa.F) {
-    s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
-    s_rgb[tid] = wa.rgb[tid];
-    s_lab[tid] = wa.label_map[tid];
+    s_cam[tid] = load_cam(tab->pose[tid], tab->K[tid], wa.W, wa.H);
+    s_rgb[tid] = tab->rgb[tid];
+    s_lab[tid] = tab->label_map[tid];
   }
   __syncthreads();
   const int DV = v.D >> 2;
@@ -620,10 +655,36 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
   const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
   // The unit of work is a QUARTER of a piece (the voxels of 16 lanes): a column inside a wall carries
   // thousands of hits, and whoever draws it last decides when the kernel ends.
+  // Order of the units.  Linear (xcd_order == 0): one counter, units in index order -- the units in flight are a few whole
+  // x-planes.  XCD-compact (grids of 16 x 16-column tiles with nz a multiple of 256): workgroup i runs on XCD i % 8 (round-
+  // robin dispatch), every XCD draws from its own counter and walks its own tiles (tile t belongs to XCD t % 8) z-section by
+  // z-section, so the 256 units an XCD has in flight are one 16 x 16 x 64-voxel box: the map taps its L2 must hold are the
+  // few map positions that box sees in each frame.  An XCD that runs out of units helps the next one.
+  constexpr uint32_t kSplit = 1u << SAF_WIN_SPLIT_LOG2;
+  const uint32_t tiles_y = (uint32_t)v.ny / 16u, n_tiles = ((uint32_t)v.nx / 16u) * tiles_y;
+  const uint32_t zsecs = (uint32_t)v.nz / (kPiece / kSplit);  // units of a column
+  const uint32_t upt = 256u * zsecs;                            // units of a tile
+  uint32_t xcd = blockIdx.x & 7u, xcd_tries = 0;
   for (;;) {
     uint32_t unit = 0;
-    if (lane == 0) unit = atomicAdd(piece_ctr, 1u);
-    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    if (xcd_order) {
+      const uint32_t my_tiles = (n_tiles + 7u - xcd) / 8u;
+      uint32_t j = 0;
+      if (lane == 0) j = atomicAdd(piece_ctr + xcd, 1u);
+      j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+      if (j >= my_tiles * upt) {
+        if (++xcd_tries == 8u) break;
+        xcd = (xcd + 1u) & 7u;
+        continue;
+      }
+      const uint32_t tl = j / upt, within = j - tl * upt, zs = within >> 8, col = within & 255u;
+      const uint32_t t = tl * 8u + xcd, tx = t / tiles_y, ty = t - tx * tiles_y;
+      const uint32_t X = tx * 16u + (col >> 4), Y = ty * 16u + (col & 15u);
+      unit = (X * (uint32_t)v.ny + Y) * zsecs + zs;  // nz % 256 == 0: a column is zsecs / kSplit whole pieces
+    } else {
+      if (lane == 0) unit = atomicAdd(piece_ctr, 1u);
+      unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    }
     const uint32_t piece = unit >> SAF_WIN_SPLIT_LOG2;
     if (piece >= n_pieces) break;
     const bool mine = (uint32_t)(lane >> (6 - SAF_WIN_SPLIT_LOG2)) == (unit & ((1u << SAF_WIN_SPLIT_LOG2) - 1u));
@@ -636,8 +697,8 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
 #pragma unroll
       for (int w = 0; w < kMaskWords; ++w) {
         const uint32_t* mrow = hitmask + (size_t)w * mask_plane + nb;
-        if (w * 32 >= wa.F) {
-          mk4[0][w] = mk4[1][w] = mk4[2][w] = mk4[3][w] = 0u;  // a short window has no second plane
+        if (w * 32 >= wa.F || !mine) {
+          mk4[0][w] = mk4[1][w] = mk4[2][w] = mk4[3][w] = 0u;  // a short window has no such plane; other units' voxels
         } else if (nb + 3u < v.N) {
           const uint4 t = *reinterpret_cast<const uint4*>(mrow);
           mk4[0][w] = t.x; mk4[1][w] = t.y; mk4[2][w] = t.z; mk4[3][w] = t.w;
@@ -650,13 +711,16 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
     int T = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const bool touched = mine && (mk4[k][0] | mk4[k][1]) != 0u;
+      uint32_t any = 0u;
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) any |= mk4[k][w];
+      const bool touched = mine && any != 0u;
       const unsigned long long bal = __ballot(touched);
       if (touched) {
         const int slot = T + __popcll(bal & lt_mask);
         s_tv[slot] = (uint16_t)(lane * 4 + k);
-        s_tm[slot * kMaskWords] = mk4[k][0];
-        s_tm[slot * kMaskWords + 1] = mk4[k][1];
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) s_tm[slot * kMaskWords + w] = mk4[k][w];
       }
       T += __popcll(bal);
     }
@@ -667,9 +731,13 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
     while (pos < T) {
       const int cnt = min(64, T - pos);
       const uint32_t vl = lane < cnt ? s_tv[pos + lane] : 0u;
-      const uint32_t mk0 = lane < cnt ? s_tm[(pos + lane) * kMaskWords] : 0u;
-      const uint32_t mk1 = lane < cnt ? s_tm[(pos + lane) * kMaskWords + 1] : 0u;
-      const int h = __popc(mk0) + __popc(mk1);
+      uint32_t mk[kMaskWords];
+      int h = 0;
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) {
+        mk[w] = lane < cnt ? s_tm[(pos + lane) * kMaskWords + w] : 0u;
+        h += __popc(mk[w]);
+      }
       // inclusive prefix sum of h over the wave
       int incl = h;
 #pragma unroll
@@ -686,13 +754,16 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
       const int htot = __builtin_amdgcn_readlane(incl, m - 1);
       // ---- expand the masks into the hit list (frame order within a voxel)
       if (active) {
-        unsigned long long mm = (unsigned long long)mk0 | ((unsigned long long)mk1 << 32);
         int r = 0;
-        while (mm) {
-          const int fbit = __ffsll((long long)mm) - 1;
-          mm &= mm - 1ull;
-          s_hf[prefix + r] = (uint32_t)lane | ((uint32_t)fbit << 22);
-          ++r;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) {
+          uint32_t mm = mk[w];
+          while (mm) {
+            const int fbit = __ffs((int)mm) - 1 + 32 * w;
+            mm &= mm - 1u;
+            s_hf[prefix + r] = (uint32_t)lane | ((uint32_t)fbit << 22);
+            ++r;
+          }
         }
       }
       wave_lds_sync();
@@ -751,108 +822,125 @@ fuse_window_kernel(KVol v, WinArgs wa, const float* __restrict__ map_imgs, int i
       }
       wave_lds_sync();
       WT(3);
-      // ---- rows: sub-chunks of <= SR rows and <= 64 hits
+      // ---- rows: sub-chunks of <= SR rows and <= 64 hits; a single row with more than 64 hits (windows longer than 64
+      //      frames) is a sub-chunk of its own whose hits are applied in passes of 64 over the LDS-resident row
       int i0 = 0;
       while (i0 < m) {
         const int pbase = __builtin_amdgcn_readlane(prefix, i0);
         const unsigned long long okm = __ballot(lane >= i0 && lane < m && lane < i0 + SR && (incl - pbase) <= 64);
-        const int nrows = __popcll(okm);                                         // >= 1 (a voxel has <= 64 hits)
-        const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..64
-        // hit l of the sub-chunk (staging entry pbase + l) lives in lane l: its row, a, b and tap weights
-        const bool hit = lane < nh;
-        const uint32_t hfl = hit ? s_hf[pbase + lane] : 0xffffffffu;
-        const uint32_t key = hfl >> 6;  // frame << 16 | cell
-        WinHit rec;
-        rec.row = (int)(hfl & 63u) - i0;
-        rec.a = hit ? s_ha[pbase + lane] : 0.0f;
-        rec.b = hit ? s_hb[pbase + lane] : 0.0f;
-        {
-          const Bilin w = bilinear_setup(hit ? s_hgx[pbase + lane] : 0.0f, hit ? s_hgy[pbase + lane] : 0.0f, half_px, half_py);
-          rec.nw = w.nw; rec.ne = w.ne; rec.sw = w.sw; rec.se = w.se;
-        }
-        // (the staging reads above come BEFORE the LDS-DMA below: the compiler drains vmcnt ahead of any LDS
-        //  read that follows an LDS-DMA, which would expose the rows' whole latency right here)
-        // the rows, global -> LDS (one LDS-DMA moves a wave's 64 x 16 B = one 1 KiB piece of a row)
-        // A voxel of weight 0 has never been written: its row is all zeros by construction (rows are only
-        // written together with a weight increment, clipfusion.py:715-721), so it is not read -- in a fresh
-        // volume that is every row's first window.  (For the running mean the old row would be multiplied by
-        // b = 0 anyway.)  Zero rows are written to LDS first: an LDS store after an LDS-DMA makes the compiler
-        // drain vmcnt.
-        unsigned long long fmask = 0;  // frames with a hit in this sub-chunk
+        const int nrows = okm ? __popcll(okm) : 1;
+        const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..kWin
+        uint32_t fm[kMaskWords];  // frames with a hit in this sub-chunk
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) fm[w] = 0u;
         WinRaw<SR, UPL> raw;
-        uint32_t fresh = 0;  // bit r: row r of the sub-chunk is untouched so far
-#pragma unroll
-        for (int r = 0; r < SR; ++r) {
-          if (r < nrows && __builtin_amdgcn_readlane(w0, i0 + r) == 0) {
-            fresh |= 1u << r;
-            if (!BF16) {
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) rows[(r * CPL + c) * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < SR; ++r) {
-          if (r < nrows) {
-            const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
-            fmask |= (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mk0, i0 + r) |
-                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mk1, i0 + r) << 32);
-            if (fresh & (1u << r)) {
-              if (BF16) {
-#pragma unroll
-                for (int k = 0; k < UPL; ++k) raw.u[r * UPL + k] = make_uint4(0u, 0u, 0u, 0u);
-              }
-            } else if (BF16) {
-#pragma unroll
-              for (int k = 0; k < UPL; ++k) {
-                const float4 t = ld_stream(featb + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * (DV / 2) +
-                                           lane + k * 64);
-                raw.u[r * UPL + k] = make_uint4(__builtin_bit_cast(uint32_t, t.x), __builtin_bit_cast(uint32_t, t.y),
-                                                __builtin_bit_cast(uint32_t, t.z), __builtin_bit_cast(uint32_t, t.w));
-              }
-            } else {
-#pragma unroll
-              for (int c = 0; c < CPL; ++c)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + row + chs[c]),
-                                                 (__attribute__((address_space(3))) void*)(rows + (r * CPL + c) * 64),
-                                                 16, 0, 2);
-            }
-          }
-        }
         raw.nrows = nrows;
-        // groups = hits of one frame in one map cell, frames ascending (a row's hits stay in frame order);
-        // group g is kept in lane g: its key and the lane mask of its members
-        uint32_t gk = 0, gm_lo = 0, gm_hi = 0;
-        int G = 0;
-        while (fmask) {
-          const uint32_t f = (uint32_t)__ffsll((long long)fmask) - 1u;
-          fmask &= fmask - 1ull;
-          unsigned long long rem = __ballot(hit && (key >> 16) == f);
-          while (rem) {
-            const int l0 = __ffsll((long long)rem) - 1;
-            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, l0);
-            const unsigned long long mm = __ballot(hit && key == k0);
-            rem &= ~mm;
-            if (lane == G) {
-              gk = k0;
-              gm_lo = (uint32_t)mm;
-              gm_hi = (uint32_t)(mm >> 32);
-            }
-            ++G;
-          }
-        }
-        WT(4);
+#ifdef SAF_WIN_EMU  // experiment: SAF_WIN_EMU copies of the map images, pieces spread over them: the tap footprint of a longer window
+        const WinCtx<CPL> cx{imgs + (size_t)(piece % SAF_WIN_EMU) * kWin * img_vecs, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
+#else
         const WinCtx<CPL> cx{imgs, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
-        const WinGroupOffs go = win_group_offsets(cx, gk);
-        for (int g0 = 0; g0 < G; g0 += P) {
-          const int nb = min(P, G - g0);
-          switch (nb) {
-            case 1: win_batch<1, CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
-            case 2: win_batch<(P >= 2 ? 2 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
-            case 3: win_batch<(P >= 3 ? 3 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
-            case 4: win_batch<(P >= 4 ? 4 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
-            case 5: win_batch<(P >= 5 ? 5 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
-            default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM, BF16, SR>(cx, g0, go, gm_lo, gm_hi, rec, raw); break;
+#endif
+        for (int h0 = 0; h0 < nh; h0 += 64) {
+          // hit h0 + l of the sub-chunk (staging entry pbase + h0 + l) lives in lane l: its row, a, b and tap weights
+          const bool hit = h0 + lane < nh;
+          const int sj = pbase + h0 + lane;
+          const uint32_t hfl = hit ? s_hf[sj] : 0xffffffffu;
+          const uint32_t key = hfl >> 6;  // frame << 16 | cell
+          WinHit rec;
+          rec.row = (int)(hfl & 63u) - i0;
+          rec.a = hit ? s_ha[sj] : 0.0f;
+          rec.b = hit ? s_hb[sj] : 0.0f;
+          {
+            const Bilin w = bilinear_setup(hit ? s_hgx[sj] : 0.0f, hit ? s_hgy[sj] : 0.0f, half_px, half_py);
+            rec.nw = w.nw; rec.ne = w.ne; rec.sw = w.sw; rec.se = w.se;
+          }
+          if (h0 == 0) {
+            // (the staging reads above come BEFORE the LDS-DMA below: the compiler drains vmcnt ahead of any LDS
+            //  read that follows an LDS-DMA, which would expose the rows' whole latency right here)
+            // the rows, global -> LDS (one LDS-DMA moves a wave's 64 x 16 B = one 1 KiB piece of a row)
+            // A voxel of weight 0 has never been written: its row is all zeros by construction (rows are only
+            // written together with a weight increment, clipfusion.py:715-721), so it is not read -- in a fresh
+            // volume that is every row's first window.  (For the running mean the old row would be multiplied by
+            // b = 0 anyway.)  Zero rows are written to LDS first: an LDS store after an LDS-DMA makes the compiler
+            // drain vmcnt.
+            uint32_t fresh = 0;  // bit r: row r of the sub-chunk is untouched so far
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+              if (r < nrows && __builtin_amdgcn_readlane(w0, i0 + r) == 0) {
+                fresh |= 1u << r;
+                if (!BF16) {
+#pragma unroll
+                  for (int c = 0; c < CPL; ++c) rows[(r * CPL + c) * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+              if (r < nrows) {
+                const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
+#pragma unroll
+                for (int w = 0; w < kMaskWords; ++w) fm[w] |= (uint32_t)__builtin_amdgcn_readlane((int)mk[w], i0 + r);
+                if (fresh & (1u << r)) {
+                  if (BF16) {
+#pragma unroll
+                    for (int k = 0; k < UPL; ++k) raw.u[r * UPL + k] = make_uint4(0u, 0u, 0u, 0u);
+                  }
+                } else if (BF16) {
+#pragma unroll
+                  for (int k = 0; k < UPL; ++k) {
+                    const float4 t = ld_stream(featb + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * (DV / 2) +
+                                               lane + k * 64);
+                    raw.u[r * UPL + k] = make_uint4(__builtin_bit_cast(uint32_t, t.x), __builtin_bit_cast(uint32_t, t.y),
+                                                    __builtin_bit_cast(uint32_t, t.z), __builtin_bit_cast(uint32_t, t.w));
+                  }
+                } else {
+#pragma unroll
+                  for (int c = 0; c < CPL; ++c)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + row + chs[c]),
+                                                     (__attribute__((address_space(3))) void*)(rows + (r * CPL + c) * 64),
+                                                     16, 0, 2);
+                }
+              }
+            }
+          }
+          // groups = hits of one frame in one map cell, frames ascending (a row's hits stay in frame order);
+          // group g is kept in lane g: its key and the lane mask of its members
+          uint32_t gk = 0, gm_lo = 0, gm_hi = 0;
+          int G = 0;
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) {
+            uint32_t fw = fm[w];
+            while (fw) {
+              const uint32_t f = (uint32_t)__ffs((int)fw) - 1u + 32u * (uint32_t)w;
+              fw &= fw - 1u;
+              unsigned long long rem = __ballot(hit && (key >> 16) == f);
+              while (rem) {
+                const int l0 = __ffsll((long long)rem) - 1;
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, l0);
+                const unsigned long long mm = __ballot(hit && key == k0);
+                rem &= ~mm;
+                if (lane == G) {
+                  gk = k0;
+                  gm_lo = (uint32_t)mm;
+                  gm_hi = (uint32_t)(mm >> 32);
+                }
+                ++G;
+              }
+            }
+          }
+          WT(4);
+          const WinGroupOffs go = win_group_offsets(cx, gk);
+          for (int g0 = 0; g0 < G; g0 += P) {
+            const int nb = min(P, G - g0);
+            const bool first = g0 == 0 && h0 == 0;
+            switch (nb) {
+              case 1: win_batch<1, CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
+              case 2: win_batch<(P >= 2 ? 2 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
+              case 3: win_batch<(P >= 3 ? 3 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
+              case 4: win_batch<(P >= 4 ? 4 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
+              case 5: win_batch<(P >= 5 ? 5 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
+              default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
+            }
           }
         }
         // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
@@ -910,15 +998,19 @@ struct WinLayout {
 WinLayout win_layout(int64_t n_vox, int D, int P) {
   WinLayout w;
   w.img_bytes = ((size_t)D * (P + 1) * sizeof(float) + 255) & ~(size_t)255;
+#ifdef SAF_WIN_EMU
+  w.maps_bytes = (size_t)SAF_WIN_EMU * kWin * w.img_bytes;
+#else
   w.maps_bytes = (size_t)kWin * w.img_bytes;
+#endif
   w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
   w.total = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;
   return w;
 }
 
-using WinFn = void (*)(KVol, WinArgs, const float*, int, unsigned long long*, unsigned int*, const uint32_t*, uint32_t,
-                       const unsigned long long*);
+using WinFn = void (*)(KVol, WinArgs, const WinTable*, const float*, int, unsigned long long*, unsigned int*, const uint32_t*,
+                       uint32_t, const unsigned long long*, int);
 template <int CPL>
 WinFn pick_win(bool sum, bool bf16) {
   if (bf16) {
@@ -933,6 +1025,12 @@ WinFn pick_win(bool sum, bool bf16) {
 }  // namespace
 
 size_t window_workspace_bytes(int64_t n_vox, int D, int P) { return win_layout(n_vox, D, P).total; }
+
+// Frames per window: 128 (SAF_WINDOW_FRAMES) unless SAF_WIN_FRAMES=64 asks for the shorter form (read per call).
+int window_frames() {
+  const char* e = getenv("SAF_WIN_FRAMES");
+  return e && atoi(e) == 64 ? 64 : kWin;
+}
 
 bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
   static const bool enabled = !(getenv("SAF_WINDOW") && getenv("SAF_WINDOW")[0] == '0');
@@ -1002,12 +1100,16 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const int brick_tiles = (kv.nx / kBrickX) % 8 == 0 && (kv.ny / kBrickY) % 8 == 0 ? 1 : 0;
   static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kDmaxOff + 32 * sizeof(float) <= kClsAccOff,
                 "workspace header layout");
-  const int n_win = (n_frames + kWin - 1) / kWin;
+  const int wlen = window_frames();
+  const int n_win = (n_frames + wlen - 1) / wlen;
+  // units of the row kernel in XCD-compact order (see the kernel); SAF_WIN_XCD=0: linear order
+  const char* xcd_env = getenv("SAF_WIN_XCD");
+  const int xcd_order = !(xcd_env && xcd_env[0] == '0') && kv.nx % 16 == 0 && kv.ny % 16 == 0 && kv.nz % kPiece == 0 ? 1 : 0;
 
   // Two streams.  The classification (VALU-bound; TSDF, depth images, one mask plane per 32 frames) of window w + 1 runs
-  // on `cs` while the row kernel (memory-bound) of window w runs on the caller's stream: the row kernel leaves 18 KB of
-  // LDS and 112 registers per SIMD free (5-row sub-chunks, 197 VGPRs at two waves per SIMD), which is one classification
-  // workgroup per CU beside it.  Masks and header are double-buffered by window parity:
+  // on `cs` while the row kernel (memory-bound) of window w runs on the caller's stream: the row kernel leaves LDS and
+  // registers free (5-row sub-chunks, 2 tap groups in flight) for classification workgroups beside it.  Masks and header
+  // (counters, frame table) are double-buffered by window parity:
   //   classify(w) -> fuse(w)       event cls_done[w & 1]
   //   fuse(w) -> classify(w + 2)   event fuse_done[w & 1]  (same mask buffer and header)
   // Without `ov` everything is queued on the caller's stream in order.
@@ -1016,79 +1118,91 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (hipEventRecord(ov->fork, s) != hipSuccess || hipStreamWaitEvent(cs, ov->fork, 0) != hipSuccess)
       return fail(SAF_E_HIP, "windowed path: could not fork the classification stream");
   }
-  auto frame_args = [&](int w, WinArgs& wa, PrepArgs& pa) {
-    const int f0 = w * kWin;
-    const int F = n_frames - f0 < kWin ? n_frames - f0 : kWin;
-    wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
-    for (int k = 0; k < kWin; ++k) {
-      const saf_frame& fr = frames[f0 + (k < F ? k : 0)];
-      wa.depth[k] = fr.depth; wa.rgb[k] = fr.rgb; wa.pose[k] = fr.pose; wa.K[k] = fr.K; wa.label_map[k] = fr.label_map;
-      pa.feat_map[k] = fr.feat_map;
-    }
-    return F;
+  const bool trace = getenv("SAF_WIN_TRACE") != nullptr;  // development: host-side timeline of this call on stderr
+  const auto t_call = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what, int w) {
+    if (trace)
+      fprintf(stderr, "[win trace] %8.3f ms  %s %d\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), what, w);
   };
+  auto win_frames = [&](int w) { return n_frames - w * wlen < wlen ? n_frames - w * wlen : wlen; };
   auto classify = [&](int w) -> int {
-    WinArgs wa;
-    PrepArgs pa;
-    const int F = frame_args(w, wa, pa), f0 = w * kWin, par = w & 1;
+    const int F = win_frames(w), f0 = w * wlen, par = w & 1;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
     float* dmax = reinterpret_cast<float*>(hdr + kDmaxOff);
     unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
+    WinTable* tab = reinterpret_cast<WinTable*>(hdr + kTableOff);
+    mark("classify: begin", w);
     if (ov && w >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
-    // header: piece counter, dmax, the classification launches' counter shards
+    // header: unit counters, dmax, the classification launches' counter shards, the frame table
     if (hipMemsetAsync(hdr, 0, kHdrBytes, cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
-    for (int fb = 0; fb < F; fb += 32) {
-      const int fe = fb + 32 < F ? fb + 32 : F;
-      uint32_t* plane = masks + (size_t)(fb / 32) * wl.mask_plane;
+    mark("classify: header memset queued", w);
+    for (int fb = 0; fb < F; fb += kClsFrames) {
+      ClsArgs ca;
+      ca.n = fb + kClsFrames < F ? kClsFrames : F - fb;
+      ca.H = kf0.H; ca.W = kf0.W; ca.slot = fb;
+      for (int k = 0; k < kClsFrames; ++k) {
+        const saf_frame& fr = frames[f0 + fb + (k < ca.n ? k : 0)];
+        ca.depth[k] = fr.depth; ca.rgb[k] = fr.rgb; ca.pose[k] = fr.pose; ca.K[k] = fr.K; ca.label_map[k] = fr.label_map;
+        ca.feat_map[k] = fr.feat_map;
+      }
+      uint32_t* plane = masks + (size_t)(fb / kClsFrames) * wl.mask_plane;
       if (bricks) {  // the frames' largest depths feed the bricks' frame cull
-        if (hipMemsetAsync(dmax, 0, 32 * sizeof(float), cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(dmax)");
-        hipLaunchKernelGGL(depth_max_kernel, dim3(32, fe - fb), dim3(256), 0, cs, wa, fb, kf0.H * kf0.W,
-                           reinterpret_cast<int*>(dmax));
+        if (hipMemsetAsync(dmax, 0, kClsFrames * sizeof(float), cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(dmax)");
+        hipLaunchKernelGGL(depth_max_kernel, dim3(32, ca.n), dim3(256), 0, cs, ca, kf0.H * kf0.W, reinterpret_cast<int*>(dmax));
       }
       ScopedPair t(prof, 1, f0 + fb, cs);
       if (bricks) {
         if (sum)
-          hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(n_wgs), dim3(256), 0, cs, kv, wa, fb, fe, brick_tiles, dmax,
-                             plane, reinterpret_cast<unsigned long long*>(stats), cls_acc);
+          hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(n_wgs), dim3(256), 0, cs, kv, ca, brick_tiles, dmax, plane,
+                             reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
         else
-          hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(n_wgs), dim3(256), 0, cs, kv, wa, fb, fe, brick_tiles, dmax,
-                             plane, reinterpret_cast<unsigned long long*>(stats), cls_acc);
+          hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(n_wgs), dim3(256), 0, cs, kv, ca, brick_tiles, dmax, plane,
+                             reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
       } else if (sum) {
-        hipLaunchKernelGGL(classify_window_kernel<true>, dim3(n_wgs), dim3(256), 0, cs, kv, wa, fb, fe, tile, plane,
-                           reinterpret_cast<unsigned long long*>(stats), cls_acc);
+        hipLaunchKernelGGL(classify_window_kernel<true>, dim3(n_wgs), dim3(256), 0, cs, kv, ca, tile, plane,
+                           reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
       } else {
-        hipLaunchKernelGGL(classify_window_kernel<false>, dim3(n_wgs), dim3(256), 0, cs, kv, wa, fb, fe, tile, plane,
-                           reinterpret_cast<unsigned long long*>(stats), cls_acc);
+        hipLaunchKernelGGL(classify_window_kernel<false>, dim3(n_wgs), dim3(256), 0, cs, kv, ca, tile, plane,
+                           reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
       }
     }
     int r = check_launch("classify_window_kernel");
     if (r) return r;
+    mark("classify: launches queued", w);
     if (ov && hipEventRecord(ov->cls_done[par], cs) != hipSuccess) return fail(SAF_E_HIP, "hipEventRecord");
     return SAF_OK;
   };
   if ((rc = classify(0))) return rc;
   for (int w = 0; w < n_win && rc == SAF_OK; ++w) {
+    const int F = win_frames(w), f0 = w * wlen, par = w & 1;
     WinArgs wa;
-    PrepArgs pa;
-    const int F = frame_args(w, wa, pa), f0 = w * kWin, par = w & 1;
+    wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
+    const WinTable* tab = reinterpret_cast<const WinTable*>(hdr + kTableOff);
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
     if (ov && w + 1 < n_win && (rc = classify(w + 1))) break;  // queued now: it runs beside this window's row kernel
     if (ov && hipStreamWaitEvent(s, ov->cls_done[par], 0) != hipSuccess) { rc = fail(SAF_E_HIP, "hipStreamWaitEvent"); break; }
     {
       ScopedPair t(prof, 0, f0, s);
-      hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, pa, maps,
+      hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, maps,
                          (int)(wl.img_bytes / sizeof(float)), kv.D, P);
     }
+#ifdef SAF_WIN_EMU
+    for (int c = 1; c < SAF_WIN_EMU; ++c)
+      hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, maps + (size_t)c * kWin * (wl.img_bytes / sizeof(float)),
+                         (int)(wl.img_bytes / sizeof(float)), kv.D, P);
+#endif
     if ((rc = check_launch("prep_rows_kernel"))) break;
     {
       ScopedPair t(prof, 2, f0, s);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, maps, img_vecs,
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, tab, maps, img_vecs,
                          reinterpret_cast<unsigned long long*>(stats), reinterpret_cast<unsigned int*>(hdr), masks, wl.mask_plane,
-                         reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff));
+                         reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff), xcd_order);
     }
     if ((rc = check_launch("fuse_window_kernel"))) break;
+    mark("rows: queued", w);
     if (ov && hipEventRecord(ov->fuse_done[par], s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord"); break; }
     if (!ov && w + 1 < n_win) rc = classify(w + 1);
   }
