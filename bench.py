@@ -409,7 +409,18 @@ def main():
             roofline["rows_per_launch"] = round(uv, 1)
             roofline["tsdf_voxels_per_launch"] = round(ut, 1)
             roofline["hits_per_row"] = round(st["valid"] / max(1, st["window_rows"]), 3)
-            roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of 64 "
+            # SURVEY.md 8d's bytes of the SAME frames fused one launch per frame (U_v = Nv, U_t = Nt): what a design that
+            # moves every frame's rows to HBM and back could at best reach at the HBM peak
+            single = (nv_per * (2 * a.dim * esz + 2 * 12 + 2 * 4 + lab) + nt_per * 16
+                      + a.height * a.width * (16 + (4 if a.labels else 0)) + a.dim * npy * npx * 4)
+            roofline["frame_at_a_time"] = {
+                "algorithmic_bytes_per_frame": int(single),
+                "frames_per_s_at_hbm_peak": round(HBM_PEAK_GBS * 1e9 / single, 1),
+                "windowed_bytes_per_frame": int(frame_bytes),
+                "note": "the window form moves %.0f %% of the bytes a frame-at-a-time fusion must move (rows travel once per "
+                        "window of %d frames instead of once per frame): `frac` prices the bytes this kernel is left with, "
+                        "so it FALLS when a longer window removes bytes faster than time" % (100.0 * frame_bytes / single, WIN)}
+            roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of %d " % WIN +
                                 "frames (hits applied in frame order: bit-identical to frame-by-frame fusion); the NEXT window's "
                                 "classification + TSDF (classify kernels, kernel_breakdown.sweep_us per 32 frames) run beside it on "
                                 "a second stream, so this launch duration is that of a kernel sharing the chip: `isolated` is the "

@@ -648,7 +648,9 @@ class Clip(torch.nn.Module):
     reference (clipfusion.py:769-772).  The ViT GEMMs stay PyTorch-ROCm (hipBLASLt / MFMA).
     """
 
-    max_patch_batch_size = 64  # the reference caps at 8 (clipfusion.py:826)
+    # tiles per encode_image call.  The reference caps at 8 (clipfusion.py:826, sized for a 24 GB card); with 288 GB of HBM
+    # the ViT GEMMs are fed 1024 tiles at a time: 468 -> 870-1000 frames/s end to end with a bf16 ViT-B/32 (bench.py --end-to-end)
+    max_patch_batch_size = 1024
 
     def __init__(self, clip_model, pretraining, backbone=None, tokenizer=None):
         super().__init__()

@@ -59,7 +59,7 @@ if out:
         bj = json.loads(open(f"{src}/pmc_fetch.json").read().strip().splitlines()[-1])
         cfg = bj["config"]
         if "fuse_window_kernel" in out["FETCH_SIZE"]:  # the windowed path ran: per-window launches
-            wt = {"grid": cfg["grid"], "dim": cfg["feat_dim"], "dtype": bj.get("dtype", "f32"), "frames_per_launch": int(bj.get("roofline", {}).get("frames_per_launch", 128)),
+            wt = {"grid": cfg["grid"], "dim": cfg["feat_dim"], "dtype": bj.get("dtype", "f32"), "frames_per_launch": int(round(cfg["frames_per_rank"] / out["FETCH_SIZE"]["fuse_window_kernel"]["launches"])),
                   "depth_kind": "B" if "depth-B" in cfg["workload"] else "A",
                   "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one 512-frame job; "
                             "FETCH_SIZE x2 (gfx950 correction), KiB -> bytes"}
