@@ -417,7 +417,10 @@ def main():
                 "algorithmic_bytes_per_frame": int(single),
                 "frames_per_s_at_hbm_peak": round(HBM_PEAK_GBS * 1e9 / single, 1),
                 "windowed_bytes_per_frame": int(frame_bytes),
-                "note": "the window form moves %.0f %% of the bytes a frame-at-a-time fusion must move (rows travel once per "
+                "this_run_frames_per_s_per_gpu": round(a.frames * a.steps / dt, 1),
+                "frac_of_that_bound": round(a.frames * a.steps / dt * single / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "SURVEY.md 8d prices the fuse at these bytes (its '40 % target' = 0.4 x frames_per_s_at_hbm_peak); "
+                        "the window form moves %.0f %% of the bytes a frame-at-a-time fusion must move (rows travel once per "
                         "window of %d frames instead of once per frame): `frac` prices the bytes this kernel is left with, "
                         "so it FALLS when a longer window removes bytes faster than time" % (100.0 * frame_bytes / single, WIN)}
             roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of %d " % WIN +
@@ -764,7 +767,7 @@ def query_cpu_baseline(a, feats_shape, q):
 def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value):
     """The reference's own call pattern (clipfusion.py:1125-1133, clip_seem_fusion.py:303-313): ONE frame per
     integrate() call, here through integrate_features() (backbone outputs resident).  The deferred window queue
-    behind it (clipfusion._FusionVolumeMixin._fuse) copies each call's inputs into a staging ring and fuses 64
+    behind it (clipfusion._FusionVolumeMixin._fuse) copies each call's inputs into a staging ring and fuses 128
     frames at a time on the windowed path; a job = reset + n calls + the final flush, like a bulk step."""
     n = min(a.api_b1, depth.shape[0])
 

@@ -43,6 +43,11 @@ def lib():
                         f"{LIB_PATH} is missing: build it with `make -C {CSRC}` "
                         "(or __graft_entry__.build()); there is no CPU fallback for the fused path"
                     )
+                # torch first: it brings its own libamdhip64.so, and the library must bind to THAT runtime (same soname) --
+                # loaded before torch it would pull in /opt/rocm's copy, and two HIP runtimes in one process do not know
+                # each other's allocations (hipMemsetAsync on a torch tensor: invalid value)
+                import torch  # noqa: F401
+
                 l = C.CDLL(LIB_PATH)
                 _abi.declare(l)
                 got = l.saf_abi_version()

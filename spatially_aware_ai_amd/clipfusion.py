@@ -88,7 +88,7 @@ class _FusionVolumeMixin:
             self.register_buffer("xyz_world", xyz_world)
         self._workspace = None
         self._shard_range = None  # (first, count) while the volume holds only a reduce-scattered shard
-        self.__dict__.setdefault("defer_frames", True)  # queue small integrate() calls into 64-frame windows
+        self.__dict__.setdefault("defer_frames", True)  # queue small integrate() calls into 128-frame windows
         self.__dict__["_pending_n"] = 0
         self.__dict__["_stage"] = None
         self.__dict__["_feat_stale"] = False
@@ -180,9 +180,9 @@ class _FusionVolumeMixin:
     # -- the deferred window queue ---------------------------------------------------------------
     # The reference calls integrate() with ONE frame per DataLoader batch (clip_seem_fusion.py:303-313,
     # clipfusion.py:1120-1133).  One frame per C call would run the per-frame pipeline; the windowed path
-    # (saf_fuse_frames with 16+ frames: every touched feature row travels to HBM once per 64-frame window)
+    # (saf_fuse_frames with 16+ frames: every touched feature row travels to HBM once per 128-frame window)
     # needs many frames in one call.  Small calls are therefore queued -- their inputs copied into a staging ring
-    # of four windows (256 slots) -- and fused when the ring is full, when a window is complete and the device is idle,
+    # of four windows (512 slots) -- and fused when the ring is full, when a window is complete and the device is idle,
     # or when anything reads or replaces the
     # volume: the registered buffers (attribute access, state_dict, .to()), stats(), extract_mesh, the merge.
     # The two device paths are bit-identical, so a caller cannot tell -- except by speed.

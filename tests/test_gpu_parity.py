@@ -602,15 +602,16 @@ def test_full_size_properties_128():
 
 
 def test_full_size_windowed_equals_per_frame_256():
-    """BASELINE configs 3/4 grid at FULL size (256^3 x 512 fp32, 640x480): the windowed path (one call, 64-frame
-    windows, tile-ordered classification) against the per-frame pipeline (calls of 8 frames) -- every buffer
+    """BASELINE configs 3/4 grid at FULL size (256^3 x 512 fp32, 640x480): the windowed path (one call: windows of 128 +
+    128 + 24 frames, the second and third classified on the auxiliary stream beside their predecessor's row kernel,
+    double-buffered masks, XCD-compact unit order) against the per-frame pipeline (calls of 8 frames) -- every buffer
     of the 34 GB volume bit for bit -- plus the size-independent properties."""
     from spatially_aware_ai_amd import ClipFusion
 
     free, _ = torch.cuda.mem_get_info()
     if free < 90e9:
         pytest.skip("needs ~80 GB of device memory for two full-size volumes")
-    w, h, d, n_frames = 640, 480, 512, 72
+    w, h, d, n_frames = 640, 480, 512, 280
     npy, npx = syn.feature_map_shape(w, h)
     grid = syn.make_grid(256)
     frames = syn.make_frames(77, n_frames - 8, width=w, height=h, feat_dim=d, npy=npy, npx=npx, depth_kind="A")
