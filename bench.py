@@ -419,7 +419,7 @@ def main():
                 "windowed_bytes_per_frame": int(frame_bytes),
                 "this_run_frames_per_s_per_gpu": round(a.frames * a.steps / dt, 1),
                 "frac_of_that_bound": round(a.frames * a.steps / dt * single / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "SURVEY.md 8d prices the fuse at these bytes (its '40 % target' = 0.4 x frames_per_s_at_hbm_peak); "
+                "note": "SURVEY.md 8d prices the fuse at these bytes (its '40 %% target' = 0.4 x frames_per_s_at_hbm_peak); "
                         "the window form moves %.0f %% of the bytes a frame-at-a-time fusion must move (rows travel once per "
                         "window of %d frames instead of once per frame): `frac` prices the bytes this kernel is left with, "
                         "so it FALLS when a longer window removes bytes faster than time" % (100.0 * frame_bytes / single, WIN)}

@@ -656,7 +656,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
   // The unit of work is a QUARTER of a piece (the voxels of 16 lanes): a column inside a wall carries
   // thousands of hits, and whoever draws it last decides when the kernel ends.
   // Order of the units.  Linear (xcd_order == 0): one counter, units in index order -- the units in flight are a few whole
-  // x-planes.  XCD-compact (grids of 16 x 16-column tiles with nz a multiple of 256): workgroup i runs on XCD i % 8 (round-
+  // x-planes.  XCD-compact (grids of 16 x 16-column tiles with nz a multiple of 64): workgroup i runs on XCD i % 8 (round-
   // robin dispatch), every XCD draws from its own counter and walks its own tiles (tile t belongs to XCD t % 8) z-section by
   // z-section, so the 256 units an XCD has in flight are one 16 x 16 x 64-voxel box: the map taps its L2 must hold are the
   // few map positions that box sees in each frame.  An XCD that runs out of units helps the next one.
@@ -680,7 +680,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
       const uint32_t tl = j / upt, within = j - tl * upt, zs = within >> 8, col = within & 255u;
       const uint32_t t = tl * 8u + xcd, tx = t / tiles_y, ty = t - tx * tiles_y;
       const uint32_t X = tx * 16u + (col >> 4), Y = ty * 16u + (col & 15u);
-      unit = (X * (uint32_t)v.ny + Y) * zsecs + zs;  // nz % 256 == 0: a column is zsecs / kSplit whole pieces
+      unit = (X * (uint32_t)v.ny + Y) * zsecs + zs;  // nz % 64 == 0: a column is zsecs whole units
     } else {
       if (lane == 0) unit = atomicAdd(piece_ctr, 1u);
       unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
@@ -1104,7 +1104,8 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const int n_win = (n_frames + wlen - 1) / wlen;
   // units of the row kernel in XCD-compact order (see the kernel); SAF_WIN_XCD=0: linear order
   const char* xcd_env = getenv("SAF_WIN_XCD");
-  const int xcd_order = !(xcd_env && xcd_env[0] == '0') && kv.nx % 16 == 0 && kv.ny % 16 == 0 && kv.nz % kPiece == 0 ? 1 : 0;
+  const int xcd_order = !(xcd_env && xcd_env[0] == '0') && kv.nx % 16 == 0 && kv.ny % 16 == 0 && kv.nz % kUnitVox == 0 &&
+                                kv.N % kPiece == 0 ? 1 : 0;
 
   // Two streams.  The classification (VALU-bound; TSDF, depth images, one mask plane per 32 frames) of window w + 1 runs
   // on `cs` while the row kernel (memory-bound) of window w runs on the caller's stream: the row kernel leaves LDS and
