@@ -1,14 +1,15 @@
 #!/bin/bash
-# Development probe (run on a GPU box): the row kernel's unit order (SAF_WIN_XCD=0 linear / 1 XCD-compact) with the real
-# map footprint and with the doubled one (-DSAF_WIN_EMU128: what a 128-frame window would ask of L2), classification
-# overlap off so that the row kernel is timed alone.  Same box, same process order.
-# Usage: bash tools/xcd_variants.sh <outdir>
+# Development probe (run on a GPU box): builds variants of saf_window.hip (compile-time knobs without the SAF_WIN_ prefix,
+# e.g. EMU=2: two copies of the map images with the pieces spread over them = the tap footprint of a window twice as long)
+# and times the default bench.py with each, for the unit orders in XS (SAF_WIN_XCD=0 linear / 1 XCD-compact) and the
+# classification overlap settings in OVS.  Same box, same process order.
+# Usage: VARIANTS="base EMU=2" XS="0 1" OVS="0 1" bash tools/xcd_variants.sh <outdir>
 OUT=${1:-gpurun_out/xcdv}
 mkdir -p $OUT
 C=spatially_aware_ai_amd/csrc
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wno-unused-function"
 OTHERS=$(ls $C/*.o | grep -v saf_window.o | tr "\n" " ")
-for v in ${VARIANTS:-base EMU128=1}; do
+for v in ${VARIANTS:-base EMU=2}; do
   tag=$(echo $v | tr '+=' '__')
   def=""; [ "$v" != base ] && def=$(echo $v | sed 's/^/-DSAF_WIN_/; s/+/ -DSAF_WIN_/g')
   /opt/rocm/bin/hipcc $FLAGS $def -c $C/saf_window.hip -o /tmp/win_$tag.o && \
