@@ -443,6 +443,55 @@ def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_
         _assert_same(vol, win, seem)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_windowed_path_random_shapes_equal_the_sequential_path(seed):
+    """Seeded random grids / frame counts / dims through both device paths: every buffer bit for bit.  The shapes are
+    drawn so that the XCD-compact unit order (16 x 16-column tiles, nz a multiple of 64; fewer tiles than XCDs,
+    more tiles than XCDs), the linear order, brick and piece classification, short and multi-pass windows all occur."""
+    from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
+
+    rng = np.random.RandomState(4000 + seed)
+    nvox = [(48, 32, 64), (16, 16, 128), (64, 48, 64), (33, 30, 41), (32, 32, 192), (20, 36, 64), (16, 144, 64),
+            (40, 24, 56), (80, 16, 64), (17, 16, 64), (32, 16, 256), (96, 96, 64)][seed]
+    dim = int(rng.choice([256, 512]))
+    seem = bool(rng.randint(2))
+    n_frames = int(rng.choice([16, 31, 64, 65, 127, 128, 129, 200, 257]))
+    w, h = 64, 48
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid(nvox, side=2.56 * nvox[0] / max(nvox))
+    kind = "B" if rng.randint(2) else "A"
+    frames = syn.make_frames(5000 + seed, n_frames, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind=kind,
+                             missing_depth_frac=0.05)
+    if rng.randint(2):  # a camera at rest: rows with many hits in one window
+        a, b = sorted(rng.choice(n_frames, 2, replace=False))
+        for i in range(a + 1, b):
+            frames[i] = dict(frames[i], depth=frames[a]["depth"], pose=frames[a]["pose"], K=frames[a]["K"])
+
+    def build(defer):
+        clip, seg = FakeClip(dim), FakeSeg()
+        if seem:
+            return ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, 10, 10, clip, seg,
+                                  keep_xyz_world=False, defer_frames=defer).cuda()
+        return ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, 10, 10,
+                          keep_xyz_world=False, defer_frames=defer).cuda()
+
+    cat = lambda k, fs: torch.cat([f[k] for f in fs]).cuda()
+    labs = lambda fs: [f["labels"].float().cuda() for f in fs] if seem else None
+    one = build(False)
+    for s0 in range(0, n_frames, 7):  # calls of 7 frames, no queue: the per-frame pipeline
+        fs = frames[s0:s0 + 7]
+        one.integrate_features(cat("depth", fs), cat("rgb", fs), cat("pose", fs), cat("K", fs), cat("feat", fs), labs(fs))
+    win = build(True)
+    win.integrate_features(cat("depth", frames), cat("rgb", frames), cat("pose", frames), cat("K", frames),
+                           cat("feat", frames), labs(frames))
+    s1, s2 = one.stats(), win.stats()
+    assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0
+    s1.pop("window_tsdf_voxels"), s2.pop("window_tsdf_voxels")
+    assert s1 == s2, (s1, s2)
+    for name in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat") + (("labels_one_hot",) if seem else ()):
+        assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs (nvox {nvox}, {n_frames} frames, D {dim})"
+
+
 def test_sum_mode_and_finalize(oracle):
     """SAF_SUM accumulation + saf_merge_finalize == running mean, and mean_to_sum
     is its inverse."""
