@@ -41,13 +41,18 @@ __device__ __forceinline__ void st_stream(float4* p, const float4 x) {
 // (NaN stays NaN).  The oracle uses the same integer arithmetic.
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// f32 -> bf16, round to nearest even, NaN quieted ((u >> 16) | 0x40): gfx950 has the conversion in hardware
+// (v_cvt_pk_bf16_f32: two values per instruction), bit for bit the software sequence
+//   (u + 0x7fff + ((u >> 16) & 1)) >> 16
+// on every f32 pattern tried (tools/bf16_cvt_test.hip: all NaNs, infinities, the denormal range, 70 M strided patterns).
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-  const uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // quiet NaN
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)f);
 }
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // n / d for n < 2^31 by multiply-shift (exact; see saf_fuse.hip make_fastdiv).

@@ -497,7 +497,6 @@ struct WinRaw {
   uint4 u[SR * UPL];
   int nrows;
 };
-__device__ __forceinline__ float bf16_round(float x) { return bf16_lo(f32_to_bf16_bits(x)); }
 
 // Lane g: the float4 offsets of group g's four map rows (frame image + tap position, or the image's zero row).
 struct WinGroupOffs {
@@ -584,7 +583,8 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, bool fi
         const float4 sv = lerp_taps(tp[u][0][c], tp[u][1][c], tp[u][2][c], tp[u][3][c], w);
         float4 nv = blend(sv, *rp, a, b, SUM);
         if (BF16) {  // the per-frame path stores bf16 after every hit: round to nearest even, keep as f32
-          nv.x = bf16_round(nv.x); nv.y = bf16_round(nv.y); nv.z = bf16_round(nv.z); nv.w = bf16_round(nv.w);
+          const uint32_t p01 = pack_bf16(nv.x, nv.y), p23 = pack_bf16(nv.z, nv.w);  // two hardware conversions
+          nv.x = bf16_lo(p01); nv.y = bf16_hi(p01); nv.z = bf16_lo(p23); nv.w = bf16_hi(p23);
         }
         *rp = nv;
       }
