@@ -498,7 +498,8 @@ struct WinRaw {
   int nrows;
 };
 
-// Lane g: the float4 offsets of group g's four map rows (frame image + tap position, or the image's zero row).
+// Per lane: the float4 offsets of the four map rows of the lane's hit (frame image + tap position, or the zero row);
+// read at a group's first lane.
 struct WinGroupOffs {
   int nw, ne, sw, se;
 };
@@ -519,19 +520,20 @@ __device__ __forceinline__ WinGroupOffs win_group_offsets(const WinCtx<CPL>& cx,
   return o;
 }
 
-// NB groups: request the four map rows of every group, then blend group after group into the LDS rows
-// (the waits are counted: group u is processed while the rows of groups u+1.. are still in flight).
+// NB groups (runs of lanes hl[u] .. hl[u + 1] - 1 of hits in group order): request the four map rows of every group, then
+// blend group after group into the LDS rows (the waits are counted: group u is processed while the rows of groups
+// u+1.. are still in flight).
 template <int NB, int CPL, bool SUM, bool BF16, int SR>
-__device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, bool first, const WinGroupOffs& go, uint32_t gm_lo,
-                                          uint32_t gm_hi, const WinHit& rec, const WinRaw<SR, BF16 ? CPL / 2 : 1>& raw) {
+__device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, const int (&hl)[NB + 1], bool first, const WinGroupOffs& go,
+                                          const WinHit& rec, const WinRaw<SR, BF16 ? CPL / 2 : 1>& raw) {
   float4 tp[NB][4][CPL];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
     // the group's four map rows as float4 offsets into the window's images (computed lane-parallel by
     // win_group_offsets: the row kernel issues as many scalar as vector instructions, this keeps the
     // per-group address arithmetic off the scalar unit)
-    const int o_nw = __builtin_amdgcn_readlane(go.nw, g0 + u), o_ne = __builtin_amdgcn_readlane(go.ne, g0 + u);
-    const int o_sw = __builtin_amdgcn_readlane(go.sw, g0 + u), o_se = __builtin_amdgcn_readlane(go.se, g0 + u);
+    const int o_nw = __builtin_amdgcn_readlane(go.nw, hl[u]), o_ne = __builtin_amdgcn_readlane(go.ne, hl[u]);
+    const int o_sw = __builtin_amdgcn_readlane(go.sw, hl[u]), o_se = __builtin_amdgcn_readlane(go.se, hl[u]);
     const float4* img = cx.imgs + (BF16 ? 2 * cx.lane : cx.lane);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -563,11 +565,7 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, int g0, bool fi
   }
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
-    unsigned long long mm = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)gm_lo, g0 + u) |
-                            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)gm_hi, g0 + u) << 32);
-    while (mm) {
-      const int l = __ffsll((long long)mm) - 1;
-      mm &= mm - 1ull;
+    for (int l = hl[u]; l < hl[u + 1]; ++l) {  // the group's hits: lanes hl[u] .. hl[u + 1] - 1
       const int r = __builtin_amdgcn_readlane(rec.row, l);
       const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.a), l));
       const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.b), l));
@@ -833,9 +831,6 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         const unsigned long long okm = __ballot(lane >= i0 && lane < m && lane < i0 + SR && (incl - pbase) <= 64);
         const int nrows = okm ? __popcll(okm) : 1;
         const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..kWin
-        uint32_t fm[kMaskWords];  // frames with a hit in this sub-chunk
-#pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) fm[w] = 0u;
         WinRaw<SR, UPL> raw;
         raw.nrows = nrows;
 #ifdef SAF_WIN_EMU  // experiment: SAF_WIN_EMU copies of the map images, pieces spread over them: the tap footprint of a longer window
@@ -857,6 +852,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
             const Bilin w = bilinear_setup(hit ? s_hgx[sj] : 0.0f, hit ? s_hgy[sj] : 0.0f, half_px, half_py);
             rec.nw = w.nw; rec.ne = w.ne; rec.sw = w.sw; rec.se = w.se;
           }
+          int rank = 0;
           if (h0 == 0) {
             // (the staging reads above come BEFORE the LDS-DMA below: the compiler drains vmcnt ahead of any LDS
             //  read that follows an LDS-DMA, which would expose the rows' whole latency right here)
@@ -867,6 +863,11 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
             // b = 0 anyway.)  Zero rows are written to LDS first: an LDS store after an LDS-DMA makes the compiler
             // drain vmcnt.
             uint32_t fresh = 0;  // bit r: row r of the sub-chunk is untouched so far
+            const uint32_t fwd = (key >> 16) >> 5, fbit = (key >> 16) & 31u;  // the hit's frame: mask word and bit
+            uint32_t low[kMaskWords];                                        // the frames before it
+#pragma unroll
+            for (int w = 0; w < kMaskWords; ++w)
+              low[w] = (uint32_t)w < fwd ? 0xffffffffu : ((uint32_t)w == fwd ? (1u << fbit) - 1u : 0u);
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
               if (r < nrows && __builtin_amdgcn_readlane(w0, i0 + r) == 0) {
@@ -881,8 +882,18 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
             for (int r = 0; r < SR; ++r) {
               if (r < nrows) {
                 const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
+                // the hit's place in (frame, row) order, from the rows' frame masks: hits of earlier frames in this row,
+                // plus this frame's hit of it if the row comes first
+                {
+                  uint32_t m[kMaskWords], at_f = 0u;
 #pragma unroll
-                for (int w = 0; w < kMaskWords; ++w) fm[w] |= (uint32_t)__builtin_amdgcn_readlane((int)mk[w], i0 + r);
+                  for (int w = 0; w < kMaskWords; ++w) {
+                    m[w] = (uint32_t)__builtin_amdgcn_readlane((int)mk[w], i0 + r);
+                    rank += __popc(m[w] & low[w]);
+                    at_f = fwd == (uint32_t)w ? m[w] : at_f;
+                  }
+                  rank += (r < rec.row && ((at_f >> fbit) & 1u)) ? 1 : 0;
+                }
                 if (fresh & (1u << r)) {
                   if (BF16) {
 #pragma unroll
@@ -906,44 +917,54 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
               }
             }
           }
-          // groups = hits of one frame in one map cell, frames ascending (a row's hits stay in frame order);
-          // group g is kept in lane g: its key and the lane mask of its members
-          uint32_t gk = 0, gm_lo = 0, gm_hi = 0;
-          int G = 0;
+          WT(4);
+          // Groups = hits of one frame in one map cell (they blend the same four map rows, loaded once per group), frames
+          // ascending, so that a row's hits stay in frame order.  The hits are brought into (frame, row) order by a
+          // permutation computed lane-parallel from the rows' frame masks (`rank`; a single row's hits are in frame order
+          // already) -- a group is then a run of lanes with one key, found with one neighbour compare and a ballot.  (The
+          // earlier form walked the frames with ballots, one serial scalar round trip per group: 11 % of the kernel.)
+          WinHit srt = rec;
+          uint32_t skey = key;
+          if (nrows > 1) {
+            const int to = (hit ? rank : lane) * 4;  // lanes without a hit keep their place
+            srt.row = __builtin_amdgcn_ds_permute(to, rec.row);
+            srt.a = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, rec.a)));
+            srt.b = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, rec.b)));
+            srt.nw = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, rec.nw)));
+            srt.ne = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, rec.ne)));
+            srt.sw = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, rec.sw)));
+            srt.se = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, rec.se)));
+            skey = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)key);
+          }
+          const uint32_t prev_key = (uint32_t)__shfl_up((int)skey, 1);
+          unsigned long long heads = __ballot(hit && (lane == 0 || skey != prev_key));  // `hit` lanes are lanes 0 .. n - 1
+          const int n_pass = nh - h0 < 64 ? nh - h0 : 64;
+          WT(5);
+          const WinGroupOffs go = win_group_offsets(cx, skey);
+          bool first = h0 == 0;
+          while (heads) {
+            int hl[P + 1];
+            int nb = 0;
 #pragma unroll
-          for (int w = 0; w < kMaskWords; ++w) {
-            uint32_t fw = fm[w];
-            while (fw) {
-              const uint32_t f = (uint32_t)__ffs((int)fw) - 1u + 32u * (uint32_t)w;
-              fw &= fw - 1u;
-              unsigned long long rem = __ballot(hit && (key >> 16) == f);
-              while (rem) {
-                const int l0 = __ffsll((long long)rem) - 1;
-                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, l0);
-                const unsigned long long mm = __ballot(hit && key == k0);
-                rem &= ~mm;
-                if (lane == G) {
-                  gk = k0;
-                  gm_lo = (uint32_t)mm;
-                  gm_hi = (uint32_t)(mm >> 32);
-                }
-                ++G;
+            for (int u = 0; u < P; ++u) {
+              if (heads) {
+                hl[u] = __ffsll((long long)heads) - 1;
+                heads &= heads - 1ull;
+                nb = u + 1;
+              } else {
+                hl[u] = n_pass;
               }
             }
-          }
-          WT(4);
-          const WinGroupOffs go = win_group_offsets(cx, gk);
-          for (int g0 = 0; g0 < G; g0 += P) {
-            const int nb = min(P, G - g0);
-            const bool first = g0 == 0 && h0 == 0;
+            hl[P] = heads ? __ffsll((long long)heads) - 1 : n_pass;
             switch (nb) {
-              case 1: win_batch<1, CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
-              case 2: win_batch<(P >= 2 ? 2 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
-              case 3: win_batch<(P >= 3 ? 3 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
-              case 4: win_batch<(P >= 4 ? 4 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
-              case 5: win_batch<(P >= 5 ? 5 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
-              default: win_batch<(P >= 6 ? 6 : 1), CPL, SUM, BF16, SR>(cx, g0, first, go, gm_lo, gm_hi, rec, raw); break;
+              case 1: { const int h1[2] = {hl[0], hl[1]}; win_batch<1, CPL, SUM, BF16, SR>(cx, h1, first, go, srt, raw); break; }
+              case 2: if constexpr (P >= 2) { const int h2[3] = {hl[0], hl[1], hl[2]}; win_batch<2, CPL, SUM, BF16, SR>(cx, h2, first, go, srt, raw); } break;
+              case 3: if constexpr (P >= 3) { const int h3[4] = {hl[0], hl[1], hl[2], hl[3]}; win_batch<3, CPL, SUM, BF16, SR>(cx, h3, first, go, srt, raw); } break;
+              case 4: if constexpr (P >= 4) { const int h4[5] = {hl[0], hl[1], hl[2], hl[3], hl[4]}; win_batch<4, CPL, SUM, BF16, SR>(cx, h4, first, go, srt, raw); } break;
+              case 5: if constexpr (P >= 5) { const int h5[6] = {hl[0], hl[1], hl[2], hl[3], hl[4], hl[5]}; win_batch<5, CPL, SUM, BF16, SR>(cx, h5, first, go, srt, raw); } break;
+              default: if constexpr (P >= 6) { const int h6[7] = {hl[0], hl[1], hl[2], hl[3], hl[4], hl[5], hl[6]}; win_batch<6, CPL, SUM, BF16, SR>(cx, h6, first, go, srt, raw); } break;
             }
+            first = false;
           }
         }
         // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
@@ -1220,7 +1241,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_win_t), sizeof(t)) == hipSuccess) {
       unsigned long long tot = 0;
       for (int k = 0; k < 8; ++k) tot += t[k];
-      fprintf(stderr, "[win timing] masks %.1f%% expand %.1f%% project %.1f%% scalars %.1f%% records+groups+row issue %.1f%% - %.1f%% tap batches %.1f%% row store %.1f%% (total %.3g wave-cycles)\n",
+      fprintf(stderr, "[win timing] masks %.1f%% expand %.1f%% project %.1f%% scalars %.1f%% records + row issue %.1f%% groups %.1f%% tap batches %.1f%% row store %.1f%% (total %.3g wave-cycles)\n",
               100.0 * t[0] / tot, 100.0 * t[1] / tot, 100.0 * t[2] / tot, 100.0 * t[3] / tot, 100.0 * t[4] / tot,
               100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, (double)tot);
       memset(t, 0, sizeof(t));
