@@ -480,10 +480,16 @@ struct WinHit {
 };
 template <int CPL>
 struct WinCtx {
-  const float4* imgs;
+  __amdgpu_buffer_rsrc_t maps;  // the window's map images as a buffer: a load beyond its end returns zeros and moves nothing
   int img_vecs, DV, npx, npy, zero_row, lane;
   float4* rows;
 };
+typedef unsigned int win_v4u __attribute__((vector_size(16)));
+constexpr uint32_t kTapOutside = 0x80000000u;  // byte offset of a tap outside the map: beyond any buffer
+__device__ __forceinline__ float4 win_tap_load(__amdgpu_buffer_rsrc_t maps, uint32_t byte_off) {
+  const win_v4u v = __builtin_amdgcn_raw_buffer_load_b128(maps, (int)byte_off, 0, 0);
+  return __builtin_bit_cast(float4, v);
+}
 // Channel chunk c of a lane (a float4 of the D-channel map row).  f32 volume: lane + 64 c.  bf16 volume:
 // a lane's 16-byte row unit holds 8 channels = chunks 2 (lane + 64 (c / 2)) + c % 2.
 template <bool BF16>
@@ -498,7 +504,7 @@ struct WinRaw {
   int nrows;
 };
 
-// Per lane: the float4 offsets of the four map rows of the lane's hit (frame image + tap position, or the zero row);
+// Per lane: the byte offsets of the four map rows of the lane's hit (frame image + tap position, or "outside");
 // read at a group's first lane.
 struct WinGroupOffs {
   int nw, ne, sw, se;
@@ -508,15 +514,15 @@ __device__ __forceinline__ WinGroupOffs win_group_offsets(const WinCtx<CPL>& cx,
   const int fb = (int)(k >> 16), x0 = (int)(k & 255u) - 2, y0 = (int)((k >> 8) & 255u) - 2;
   const bool x0ok = x0 >= 0 && x0 < cx.npx, x1ok = x0 + 1 >= 0 && x0 + 1 < cx.npx;
   const bool y0ok = y0 >= 0 && y0 < cx.npy, y1ok = y0 + 1 >= 0 && y0 + 1 < cx.npy;
-  const int base = fb * cx.img_vecs;  // < 2^31: kWin images of (P + 1) * D / 4 float4 each
-  // taps outside the map read zeros: ALL of them from image 0's zero row (17 % of the taps of a 5 x 7 map: one row that
-  // stays in the CU's L1 instead of one row per frame from L2)
-  const int zero = cx.zero_row * cx.DV;
+  const int base = fb * cx.img_vecs;  // < 2^27: kWin images of (P + 1) * D / 4 float4 each
+  // BYTE offsets into the buffer of map images.  A tap outside the map (zeros padding; 17 % of the taps of a 5 x 7 map)
+  // gets an offset beyond the buffer: the hardware's range check returns zeros without a request to L1 / L2 -- and the
+  // L1's miss queue is what bounds this kernel.
   WinGroupOffs o;
-  o.nw = (x0ok && y0ok) ? base + (y0 * cx.npx + x0) * cx.DV : zero;
-  o.ne = (x1ok && y0ok) ? base + (y0 * cx.npx + x0 + 1) * cx.DV : zero;
-  o.sw = (x0ok && y1ok) ? base + ((y0 + 1) * cx.npx + x0) * cx.DV : zero;
-  o.se = (x1ok && y1ok) ? base + ((y0 + 1) * cx.npx + x0 + 1) * cx.DV : zero;
+  o.nw = (x0ok && y0ok) ? (base + (y0 * cx.npx + x0) * cx.DV) * 16 : (int)kTapOutside;
+  o.ne = (x1ok && y0ok) ? (base + (y0 * cx.npx + x0 + 1) * cx.DV) * 16 : (int)kTapOutside;
+  o.sw = (x0ok && y1ok) ? (base + ((y0 + 1) * cx.npx + x0) * cx.DV) * 16 : (int)kTapOutside;
+  o.se = (x1ok && y1ok) ? (base + ((y0 + 1) * cx.npx + x0 + 1) * cx.DV) * 16 : (int)kTapOutside;
   return o;
 }
 
@@ -534,13 +540,14 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, const int (&hl)
     // per-group address arithmetic off the scalar unit)
     const int o_nw = __builtin_amdgcn_readlane(go.nw, hl[u]), o_ne = __builtin_amdgcn_readlane(go.ne, hl[u]);
     const int o_sw = __builtin_amdgcn_readlane(go.sw, hl[u]), o_se = __builtin_amdgcn_readlane(go.se, hl[u]);
-    const float4* img = cx.imgs + (BF16 ? 2 * cx.lane : cx.lane);
+    const uint32_t lane_off = (uint32_t)(BF16 ? 2 * cx.lane : cx.lane) * 16u;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      tp[u][0][c] = img[o_nw + win_chunk_off<BF16>(c)];
-      tp[u][1][c] = img[o_ne + win_chunk_off<BF16>(c)];
-      tp[u][2][c] = img[o_sw + win_chunk_off<BF16>(c)];
-      tp[u][3][c] = img[o_se + win_chunk_off<BF16>(c)];
+      const uint32_t off = lane_off + (uint32_t)win_chunk_off<BF16>(c) * 16u;
+      tp[u][0][c] = win_tap_load(cx.maps, (uint32_t)o_nw + off);
+      tp[u][1][c] = win_tap_load(cx.maps, (uint32_t)o_ne + off);
+      tp[u][2][c] = win_tap_load(cx.maps, (uint32_t)o_sw + off);
+      tp[u][3][c] = win_tap_load(cx.maps, (uint32_t)o_se + off);
     }
   }
   if (first) {  // the sub-chunk's first batch: its rows (issued before these loads) have landed after this
@@ -644,7 +651,8 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
   constexpr int UPL = BF16 ? CPL / 2 : 1;  // 16-byte units of a bf16 row per lane
   float4* feat = reinterpret_cast<float4*>(v.feat);
   float4* featb = reinterpret_cast<float4*>(v.feat);  // bf16 volume: D / 8 units of 16 bytes per row
-  const float4* imgs = reinterpret_cast<const float4*>(map_imgs);
+  const __amdgpu_buffer_rsrc_t maps_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(map_imgs), 0, (int)((size_t)wa.F * img_vecs * sizeof(float4)), 0x00020000);
   KFrame kf;  // per-hit view of a frame for the scalar side
   kf.H = wa.H; kf.W = wa.W; kf.npy = wa.npy; kf.npx = wa.npx; kf.rgb_bilinear = wa.rgb_bilinear;
   kf.depth = nullptr; kf.pose = nullptr; kf.K = nullptr;
@@ -833,11 +841,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..kWin
         WinRaw<SR, UPL> raw;
         raw.nrows = nrows;
-#ifdef SAF_WIN_EMU  // experiment: SAF_WIN_EMU copies of the map images, pieces spread over them: the tap footprint of a longer window
-        const WinCtx<CPL> cx{imgs + (size_t)(piece % SAF_WIN_EMU) * kWin * img_vecs, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
-#else
-        const WinCtx<CPL> cx{imgs, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
-#endif
+        const WinCtx<CPL> cx{maps_rsrc, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
         for (int h0 = 0; h0 < nh; h0 += 64) {
           // hit h0 + l of the sub-chunk (staging entry pbase + h0 + l) lives in lane l: its row, a, b and tap weights
           const bool hit = h0 + lane < nh;
@@ -1022,11 +1026,7 @@ struct WinLayout {
 WinLayout win_layout(int64_t n_vox, int D, int P) {
   WinLayout w;
   w.img_bytes = ((size_t)D * (P + 1) * sizeof(float) + 255) & ~(size_t)255;
-#ifdef SAF_WIN_EMU
-  w.maps_bytes = (size_t)SAF_WIN_EMU * kWin * w.img_bytes;
-#else
   w.maps_bytes = (size_t)kWin * w.img_bytes;
-#endif
   w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
   w.total = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;
@@ -1214,11 +1214,6 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, maps,
                          (int)(wl.img_bytes / sizeof(float)), kv.D, P);
     }
-#ifdef SAF_WIN_EMU
-    for (int c = 1; c < SAF_WIN_EMU; ++c)
-      hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, maps + (size_t)c * kWin * (wl.img_bytes / sizeof(float)),
-                         (int)(wl.img_bytes / sizeof(float)), kv.D, P);
-#endif
     if ((rc = check_launch("prep_rows_kernel"))) break;
     {
       ScopedPair t(prof, 2, f0, s);
