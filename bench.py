@@ -190,15 +190,16 @@ def main():
     fdt = torch.bfloat16 if a.feat_dtype == "bf16" else torch.float32
     esz = 2 if a.feat_dtype == "bf16" else 4
 
-    def new_volume(nvox=None, index_offset=(0, 0, 0)):
+    def new_volume(nvox=None, index_offset=(0, 0, 0), x_planes=None):
         nvox = grid.nvox if nvox is None else nvox
         if a.labels:
             fz = ClipSeemFusion(grid.origin, grid.voxel_size, nvox, grid.trunc, False, a.height // 3,
                                 a.height // 6, ResidentFeatures(), None, keep_xyz_world=False, feat_dtype=fdt,
-                                index_offset=index_offset)
+                                index_offset=index_offset, x_planes=x_planes)
         else:
             fz = ClipFusion(grid.origin, grid.voxel_size, nvox, grid.trunc, False, ResidentFeatures(), None,
-                            a.height // 3, a.height // 6, keep_xyz_world=False, feat_dtype=fdt, index_offset=index_offset)
+                            a.height // 3, a.height // 6, keep_xyz_world=False, feat_dtype=fdt, index_offset=index_offset,
+                            x_planes=x_planes)
         return fz.to(device)
 
     # N > 1 keeps two volumes: the second one lets job k+1 fuse while job k's merge drains (second timed
@@ -813,33 +814,65 @@ def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value)
 
 
 def bench_voxel_sharded(a, dist, sdist, grid, fusions, tensors, new_volume, world, rank, device, L, stream, npy, npx):
-    """The same job with VOXELS sharded instead of frames: rank k owns the x-slab k of the volume
-    and fuses ALL world * frames_per_rank frames into it; the only exchange is the frames (an all-gather of 5 MB per
-    frame, inside the timed region -- every rank starts with its own frames only), there is no merge, and the volume ends
-    sharded the way the sharded query reads it.  Untimed check: the slab equals, bit for bit, the same x-range of a
-    full-size volume fused on this rank alone from the same frames in the same order."""
+    """The same job with VOXELS sharded instead of frames: rank k owns a slab of x-planes of the
+    volume (blocks of 16 planes, an outer block paired with an inner one: cameras look at the middle of the scene) and
+    fuses ALL world * frames_per_rank frames into it.  The only exchange is the frames -- 5 MB per frame instead of the
+    34 GB of a volume merge -- all-gathered SEGMENT BY SEGMENT on a side stream while the previous segment is being fused
+    (every rank starts with its own frames only; the exchange is inside the timed step); there is no merge, and the job
+    ends voxel-sharded.  Frame order of the job: segment-major, ranks ascending within a segment.  Untimed check: the slab
+    equals, bit for bit, the same x-planes of a full-size volume fused on this rank alone from the same frames in the same
+    order."""
     nx, ny, nz = (int(v) for v in grid.nvox)
-    first_x, cnt = sdist.slab_of_rank(nx, rank, world)
-    slab = new_volume(torch.tensor([cnt, ny, nz], dtype=torch.int32), (first_x, 0, 0))
+    planes = sdist.slab_planes_of_rank(nx, rank, world)
+    cnt = int(planes.numel())
+    slab = new_volume(torch.tensor([cnt, ny, nz], dtype=torch.int32), x_planes=planes)
     ws = slab._get_workspace(npy, npx)
     stats = slab._buffers["fuse_stats"]
     uniq = tensors[0].shape[0]
-    gathered = sdist.gather_frames(tensors)  # the receive buffers persist: their frame descriptors are built once
-    arr_all, keep, _, _ = slab._make_frames(*gathered[:5], gathered[5], a.labels)
-    n_all = world * uniq
-    frames_all = (_abi.SafFrame * (world * a.frames))()
-    for r in range(world):
-        for i in range(a.frames):
-            frames_all[r * a.frames + i] = arr_all[r * uniq + i % uniq]
+    # segments of `seg` frames per rank: at least two windows per fuse call, so that classification and rows overlap inside it
+    seg = max(64, 2 * WIN // world)
+    while uniq % seg != 0 or a.frames % seg != 0:
+        seg //= 2
+        if seg < 16:
+            seg = uniq  # one segment: the exchange in front of the fusion
+            break
+    n_seg = uniq // seg
+    recv = [[None if t is None else torch.empty((world * seg,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in tensors]
+            for _ in range(n_seg)]
+    descs = []
+    for r in recv:
+        arr, keep, _, _ = slab._make_frames(*r[:5], r[5], a.labels)
+        descs.append((arr, keep))
+    calls = [k % n_seg for k in range(a.frames // seg)]  # a.frames > uniq: the unique frames again (their buffers are resident)
+    comm = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    nccl = dist.get_backend() == "nccl"
+
+    def exchange(k):
+        for t, dst in zip(tensors, recv[k]):
+            if t is None:
+                continue
+            src = t[k * seg:(k + 1) * seg].contiguous()
+            if nccl:
+                dist.all_gather_into_tensor(dst, src)
+            else:
+                dist.all_gather(list(dst.split(seg)), src)
 
     def job():
         slab.reset()
-        for dst, src in zip(gathered, sdist.gather_frames(tensors)):  # the exchange of this job's inputs
-            if dst is not None and dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
+        free = main.record_event()  # the receive buffers are free once the previous job's fuse calls are done
+        comm.wait_event(free)
+        arrived = []
+        with torch.cuda.stream(comm):
+            for k in range(n_seg):
+                exchange(k)
+                arrived.append(comm.record_event())
         vol = slab._c_volume(for_fuse=True)
-        check(L.saf_fuse_frames_profiled(C.byref(vol), frames_all, world * a.frames, ws.data_ptr(), ws.numel(),
-                                         stats.data_ptr(), None, stream), "saf_fuse_frames (slab)")
+        for i, k in enumerate(calls):
+            if i < n_seg:
+                main.wait_event(arrived[k])
+            check(L.saf_fuse_frames_profiled(C.byref(vol), descs[k][0], world * seg, ws.data_ptr(), ws.numel(), stats.data_ptr(), None,
+                                             stream), "saf_fuse_frames (slab)")
         slab.flush()
 
     def barrier():
@@ -861,12 +894,12 @@ def bench_voxel_sharded(a, dist, sdist, grid, fusions, tensors, new_volume, worl
     st = slab.stats()
     assert st["frames"] == world * a.frames * a.steps
     assert int(slab.weight.sum(dtype=torch.int64)) * a.steps == st["valid"]
-    # untimed: a full-size volume fused here from a few of the same frames must agree with the slab on its x-range
-    c = min(max(1, a.check_frames), uniq)
+    # untimed: a full-size volume fused here from a few of the same frames must agree with the slab on its x-planes
+    c = min(max(1, a.check_frames), seg)
     sub = (_abi.SafFrame * (world * c))()
     for r in range(world):
         for i in range(c):
-            sub[r * c + i] = arr_all[r * uniq + i]
+            sub[r * c + i] = descs[0][0][r * seg + i]
     full = fusions[1]
     full.reset(lazy=False)  # (a handful of frames: the per-frame pipeline reads the rows it updates)
     wsf = full._get_workspace(npy, npx)
@@ -877,20 +910,25 @@ def bench_voxel_sharded(a, dist, sdist, grid, fusions, tensors, new_volume, worl
     vols = slab._c_volume(for_fuse=True)
     check(L.saf_fuse_frames_profiled(C.byref(vols), sub, world * c, ws.data_ptr(), ws.numel(), stats.data_ptr(), None, stream),
           "check (slab)")
-    lo, hi = first_x * ny * nz, (first_x + cnt) * ny * nz
-    same = all(bool(torch.equal(getattr(slab, n), getattr(full, n)[lo:hi])) for n in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat"))
+    pl = planes.to(device)
+    mine_of = lambda t: t.view(nx, ny * nz, -1).index_select(0, pl).reshape(cnt * ny * nz, -1)
+    same = all(bool(torch.equal(getattr(slab, n).view(cnt * ny * nz, -1), mine_of(getattr(full, n))))
+               for n in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat"))
     flag = torch.tensor([int(same), int((slab.weight > 0).sum())], device=device, dtype=torch.int64)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    assert int(flag[0]) == 1, "voxel-sharded check: a slab differs from the same x-range of the full-size volume"
+    assert int(flag[0]) == 1, "voxel-sharded check: a slab differs from the same x-planes of the full-size volume"
     assert int(flag[1]) > 0, "voxel-sharded check: a slab was not touched by the check frames"
-    del slab, gathered
+    del slab, recv, descs
     torch.cuda.empty_cache()
     total = world * a.frames * a.steps
     return {"value": round(total / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "slab_voxels": cnt * ny * nz, "frames_fused_per_rank_per_step": world * a.frames, "collective": "all_gather of the frames",
+            "slab_voxels": cnt * ny * nz, "x_planes": "blocks of 16, outer paired with inner" if cnt and int(planes[-1] - planes[0]) + 1 != cnt else "contiguous",
+            "frames_fused_per_rank_per_step": world * a.frames, "collective": "all_gather of the frames",
+            "segments": n_seg, "frames_per_rank_per_segment": seg,
             "slab_equals_full_volume_range": True,
-            "note": "every rank fuses all frames of the job into its x-slab of the volume: no merge, one all-gather of the frames "
-                    "(inside the timed step), the volume stays voxel-sharded; NOT BASELINE config 4's layout (that is `value`)"}
+            "note": "every rank fuses all frames of the job into its slab of x-planes: no merge; the frames are all-gathered "
+                    "segment by segment on a side stream beside the fusion of the previous segment (inside the timed step); "
+                    "the volume stays voxel-sharded; NOT BASELINE config 4's layout (that is `value`)"}
 
 
 def check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, tensors, c, world, rank, device):

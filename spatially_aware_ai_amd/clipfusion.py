@@ -33,14 +33,19 @@ assert C.sizeof(_abi.SafFrame) == 72 and _abi.SafFrame.depth.offset == 8 and _ab
 # --------------------------------------------------------------------------------------------
 
 
-def _axis_tables(origin, voxel_size, nvox, index_offset=(0, 0, 0)):
+def _axis_tables(origin, voxel_size, nvox, index_offset=(0, 0, 0), x_planes=None):
     """Per-axis voxel-centre coordinates, element for element what the reference computes as
     ``xyz_idx * voxel_size + origin`` (clipfusion.py:617-622): int64 index * python float -> f32
     product, + f32 origin.  ``index_offset``: the module holds the sub-grid that starts at this voxel index of the grid
-    anchored at ``origin`` (a slab of a voxel-sharded volume): the same expression on the same indices, bit for bit."""
+    anchored at ``origin`` (a slab of a voxel-sharded volume): the same expression on the same indices, bit for bit.
+    ``x_planes``: the x indices the module holds, in its own order (a slab made of several blocks of x-planes)."""
     origin = torch.as_tensor(origin).detach().cpu()
-    return [((torch.arange(int(nvox[a])) + int(index_offset[a])) * voxel_size + origin[a]).to(torch.float32).contiguous()
-            for a in range(3)]
+    idx = [torch.arange(int(nvox[a])) + int(index_offset[a]) for a in range(3)]
+    if x_planes is not None:
+        idx[0] = torch.as_tensor(x_planes, dtype=torch.int64).detach().cpu()
+        if idx[0].dim() != 1 or idx[0].numel() != int(nvox[0]):
+            raise ValueError("x_planes must list nvox[0] x indices")
+    return [(idx[a] * voxel_size + origin[a]).to(torch.float32).contiguous() for a in range(3)]
 
 
 _VOLUME_BUFFERS = frozenset(("tsdf", "rgb", "clip_feat", "weight", "tsdf_weight", "labels_one_hot", "fuse_stats"))
@@ -50,7 +55,7 @@ class _FusionVolumeMixin:
     """Buffers, workspace and the C-ABI call shared by both fusion modules."""
 
     def _init_volume(self, origin, voxel_size, nvox, trunc, feat_dim, n_classes=0, keep_xyz_world=True,
-                     feat_dtype=torch.float32, index_offset=(0, 0, 0)):
+                     feat_dtype=torch.float32, index_offset=(0, 0, 0), x_planes=None):
         nvox = torch.as_tensor(nvox)
         n = int(torch.prod(nvox.long()))
         self.origin = origin
@@ -69,7 +74,8 @@ class _FusionVolumeMixin:
         if n_classes:
             self.register_buffer("labels_one_hot", torch.zeros((n, n_classes), dtype=torch.int32))
         self.index_offset = tuple(int(v) for v in index_offset)
-        ax = _axis_tables(origin, voxel_size, nvox, self.index_offset)
+        self.x_planes = None if x_planes is None else torch.as_tensor(x_planes, dtype=torch.int64).detach().cpu().clone()
+        ax = _axis_tables(origin, voxel_size, nvox, self.index_offset, self.x_planes)
         # not in the reference's state_dict: derived tables the sweep kernel reads instead of xyz_world
         self.register_buffer("axis_x", ax[0], persistent=False)
         self.register_buffer("axis_y", ax[1], persistent=False)
@@ -824,7 +830,7 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_model, clip_pretraining,
                  clip_patch_size, clip_patch_stride, keep_xyz_world=True, feat_dtype=torch.float32, defer_frames=True,
-                 index_offset=(0, 0, 0)):
+                 index_offset=(0, 0, 0), x_planes=None):
         super().__init__()
         self.__dict__["defer_frames"] = bool(defer_frames)
         if isinstance(clip_model, str):
@@ -836,7 +842,8 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
         self.clip_patch_size = clip_patch_size
         self.clip_patch_stride = clip_patch_stride
         self.scale_patches_by_depth = scale_patches_by_depth
-        self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, 0, keep_xyz_world, feat_dtype, index_offset)
+        self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, 0, keep_xyz_world, feat_dtype, index_offset,
+                          x_planes)
 
     def integrate(self, depth_imgs, rgb_imgs, poses, K):
         """Fuse a batch of frames (reference clipfusion.py:627-721).  Batch elements are folded in

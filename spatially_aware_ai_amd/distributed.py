@@ -104,6 +104,21 @@ def slab_of_rank(nx: int, rank: int, world: int):
     return first, base + (1 if rank < rem else 0)
 
 
+def slab_planes_of_rank(nx: int, rank: int, world: int, block: int = 16):
+    """The x-planes rank owns in the voxel-sharded job, BALANCED: cameras look at the middle of the scene, so a contiguous
+    middle slab sees half again as many hits as an outer one (measured 111 vs 73 ms per job at 8 ranks).  The grid is cut
+    into blocks of ``block`` x-planes (16: the tile of the row kernel's unit order and four bricks of the classification)
+    and block b goes to rank (b mod B/2) mod world: a rank's block in the left half is as far out as its block in the right
+    half is far in.  Falls back to the contiguous slab of ``slab_of_rank`` when the blocks do not divide evenly.  Returns
+    the x indices, ascending."""
+    nb = nx // block
+    if nx % block != 0 or nb % (2 * world) != 0:
+        first, cnt = slab_of_rank(nx, rank, world)
+        return torch.arange(first, first + cnt)
+    mine = [b for b in range(nb) if (b % (nb // 2)) % world == rank]
+    return torch.cat([torch.arange(b * block, (b + 1) * block) for b in mine])
+
+
 def gather_frames(tensors, group=None):
     """The exchange step of the voxel-sharded job: every rank contributes its frames (depth, rgb, poses, K, feature maps,
     [label maps]) and receives everybody's, in rank order -- 5 MB per 640x480 frame instead of the 34 GB of a volume merge.

@@ -192,3 +192,19 @@ def test_voxel_sharded_job_exchanges_frames_in_rank_order(tmp_path):
     for nx, w in ((256, 8), (33, 3), (5, 8)):
         slabs = [sdist.slab_of_rank(nx, r, w) for r in range(w)]
         assert sum(c for _, c in slabs) == nx and all(slabs[i][0] + slabs[i][1] == slabs[i + 1][0] for i in range(w - 1))
+
+
+def test_balanced_planes_partition_the_grid():
+    """slab_planes_of_rank: every x-plane belongs to exactly one rank, ranks hold equally many, in whole blocks of 16, and
+    a rank's blocks mirror each other (as far out on one side as far in on the other); odd shapes fall back to slabs."""
+    from spatially_aware_ai_amd import distributed as sdist
+
+    for nx, world in ((256, 1), (256, 2), (256, 4), (256, 8), (64, 2), (128, 4)):
+        parts = [sdist.slab_planes_of_rank(nx, r, world) for r in range(world)]
+        assert sorted(torch.cat(parts).tolist()) == list(range(nx))
+        assert len({p.numel() for p in parts}) == 1
+        for p in parts:
+            assert torch.equal(p, torch.sort(p).values) and all(int(v) % 16 == 0 for v in p[::16])
+            centre = (nx - 1) / 2
+            assert abs(float((p.double() - centre).mean())) < 16 * world, "blocks of a rank do not mirror each other"
+    assert sdist.slab_planes_of_rank(33, 1, 3).tolist() == list(range(11, 22))  # no blocks of 16: the contiguous slab

@@ -3,7 +3,7 @@ x-slab (256 / W x 256 x 256 voxels); no exchange is timed.  Prints ms per job an
 import ctypes as C, sys, time, torch
 sys.path.insert(0, ".")
 import bench
-from spatially_aware_ai_amd import ClipFusion, _abi, synthetic as syn
+from spatially_aware_ai_amd import ClipFusion, _abi, distributed as sdist, synthetic as syn
 from spatially_aware_ai_amd._lib import check, lib
 class R: feature_dim = 512
 g = syn.make_grid(256)
@@ -12,10 +12,11 @@ dev = torch.device("cuda", 0)
 depth, rgb, poses, ks, feat = bench.gen_frames_gpu(512, 640, 480, 512, npy, npx, "A", 1000, dev)
 L = lib()
 for W in (int(x) for x in (sys.argv[1:] or ["1", "2", "4", "8"])):
-    for rank in sorted({0, W // 2}):
-        cnt = 256 // W
+    for rank in sorted({0, W // 2, W - 1}):
+        planes = sdist.slab_planes_of_rank(256, rank, W)  # balanced blocks of 16 x-planes (contiguous: slab_of_rank)
+        cnt = planes.numel()
         slab = ClipFusion(g.origin, g.voxel_size, torch.tensor([cnt, 256, 256], dtype=torch.int32), g.trunc, False, R(), None, 160, 80,
-                          keep_xyz_world=False, index_offset=(rank * cnt, 0, 0)).to(dev)
+                          keep_xyz_world=False, x_planes=planes).to(dev)
         arr, keep, _, _ = slab._make_frames(depth, rgb, poses, ks, feat, None, False)
         frames = (_abi.SafFrame * (W * 512))()
         for i in range(W * 512):
