@@ -7,23 +7,28 @@ Workload (BASELINE.json metric / configs[3]): per rank 512 synthetic 640x480 RGB
 random poses (SURVEY.md §8d, depth distribution A) fused into a per-rank 256^3 x 512 fp32 grid;
 ranks shard frames and merge their grids with one RCCL reduction at the end of the job.
 
-A *step* is one whole job per rank: zero the volume, fuse this rank's frames (prep + sweep + fuse
-kernels per frame, one C-ABI call, no host sync), and -- for N > 1 -- the single merge
-(reduce-scatter of the per-rank SUM volumes + local divide).  Inputs are resident in HBM before
-the timed region.  value = N * frames_per_rank * K / max-over-ranks wall time of the K steps.
+A *step* is one whole job per rank: reset the volume, fuse this rank's frames in ONE C-ABI call with no host sync (the
+windowed path: per window of 128 frames four classification launches and one row kernel, the next window classified beside
+the row kernel), finish the deferred clear, and -- for N > 1 -- the single merge (reduce-scatter of the per-rank SUM volumes
++ local divide).  Inputs are resident in HBM before the timed region.  value = N * frames_per_rank * K / max-over-ranks
+wall time of the K steps.
 
 N > 1: when WORLD_SIZE is not set, `python bench.py --gpus N` starts the N ranks itself (a child
 `python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches the GPU), forwards
 rank 0's JSON line and exits non-zero if any rank fails.  The headline `value` of an N > 1 run is the SERIAL-merge
 job (fuse, then the RCCL merge, nothing overlapped: BASELINE config 4 is one job); the same K steps are then timed
-again with each job's merge overlapped with the next job's fusion (`overlapped_merge`).  After the timed regions an
-untimed integrity pass proves the merge: weight sums against the kernels' valid counts, and the merged voxel shard
-of a small sharded job against a single-rank fusion of all its frames (`merge_check`).
+again with each job's merge overlapped with the next job's fusion (`overlapped_merge`), and a third time with the VOXELS
+sharded instead of the frames (`voxel_sharded`: balanced slabs, the frames all-gathered in segments beside the fusion, no
+merge).  After the timed regions an untimed integrity pass proves the merge: weight sums against the kernels' valid counts,
+and the merged voxel shard of a small sharded job against a single-rank fusion of all its frames (`merge_check`).
+
+Other passes: --query (BASELINE config 5: the text-query scans), --api-b1 N (one frame per integrate() call through the
+deferred window queue), --end-to-end N (a ViT-B/32-shaped backbone in front), --depth-kind B, --labels, --feat-dtype bf16.
 
 Extra objects on the JSON line:
-  roofline     : the dominant kernel (fuse_kernel): algorithmic bytes per launch (from the Nv
-                 counters the kernels emit, SURVEY.md §8d formula) / its average launch duration,
-                 measured with HIP events on the launch stream inside the timed region.
+  roofline     : the dominant kernel (fuse_window_kernel): algorithmic bytes per launch (from the row / voxel counters
+                 the kernels emit, SURVEY.md §8d formula) / its average launch duration, measured with HIP events on the
+                 launch stream inside the timed region; `isolated`, `warm_volume`, `frame_at_a_time` beside it.
   cpu_baseline : the CPU oracle (a parity-checked port of the reference's algorithm, OpenMP over
                  the host cores of this box) on a bounded sample of the same frames, rank 0, N=1.
 """
