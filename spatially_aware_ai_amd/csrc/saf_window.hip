@@ -1072,7 +1072,9 @@ bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
       return false;
   }
   if (f0.npx + 3 > 255 || f0.npy + 3 > 255) return false;  // a hit's map cell travels as two bytes
-  return workspace_bytes >= win_layout(kv.N, kv.D, f0.npy * f0.npx).total;
+  const WinLayout wl = win_layout(kv.N, kv.D, f0.npy * f0.npx);
+  if (wl.maps_bytes >= (size_t)kTapOutside) return false;  // the taps are buffer loads with 31-bit byte offsets
+  return workspace_bytes >= wl.total;
 }
 
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, uint64_t* stats,
