@@ -492,6 +492,42 @@ def test_windowed_path_random_shapes_equal_the_sequential_path(seed):
         assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs (nvox {nvox}, {n_frames} frames, D {dim})"
 
 
+@pytest.mark.parametrize("env", [{"SAF_WIN_FRAMES": "64"}, {"SAF_WIN_XCD": "0"}, {"SAF_WIN_OVERLAP": "0"},
+                                 {"SAF_WIN_FRAMES": "64", "SAF_WIN_XCD": "0", "SAF_WIN_OVERLAP": "0"}])
+def test_windowed_path_settings_are_bit_identical(env, monkeypatch):
+    """The per-call settings of the windowed path (64-frame windows, linear unit order, no classification overlap) change
+    the schedule, never the result: every buffer equals the default configuration's, bit for bit."""
+    from spatially_aware_ai_amd import ClipSeemFusion
+
+    dim, n_frames, nvox, w, h = 256, 300, (64, 48, 64), 64, 48
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid(nvox, side=2.56)
+    frames = syn.make_frames(611, n_frames, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="B", missing_depth_frac=0.05)
+    for i in range(40, 130):  # a camera at rest: rows with more than 64 hits
+        frames[i] = dict(frames[i], depth=frames[39]["depth"], pose=frames[39]["pose"], K=frames[39]["K"])
+    cat = lambda k: torch.cat([f[k] for f in frames]).cuda()
+    args = [cat(k) for k in ("depth", "rgb", "pose", "K", "feat")] + [[f["labels"].float().cuda() for f in frames]]
+
+    def run():
+        fz = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, 10, 10, FakeClip(dim), FakeSeg(),
+                            keep_xyz_world=False).cuda()
+        fz.integrate_features(*args)
+        st = fz.stats()
+        assert st["window_rows"] > 0
+        return fz, st
+
+    ref, st_ref = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt, st_alt = run()
+    if env.get("SAF_WIN_FRAMES") == "64":
+        assert st_alt.pop("window_rows") > st_ref.pop("window_rows"), "shorter windows touch more rows in total"
+        st_alt.pop("window_tsdf_voxels"), st_ref.pop("window_tsdf_voxels")
+    assert st_alt == st_ref
+    for name in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat", "labels_one_hot"):
+        assert torch.equal(getattr(ref, name), getattr(alt, name)), (env, name)
+
+
 def test_sum_mode_and_finalize(oracle):
     """SAF_SUM accumulation + saf_merge_finalize == running mean, and mean_to_sum
     is its inverse."""
