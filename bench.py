@@ -534,6 +534,7 @@ def main():
                 for s0 in range(0, nfr, bs):
                     sl = slice(s0, min(nfr, s0 + bs))
                     fz.integrate(depth[sl], rgb[sl], poses[sl], ks[sl])
+                fz.flush()  # small calls are queued (frames and backbone): the job ends when the volume is up to date
 
         run_e2e()
         torch.cuda.synchronize()
@@ -553,8 +554,10 @@ def main():
             "backbone": "ViT-B/32 image tower, seeded random weights (no CLIP weights offline), 35 tiles/frame, "
                         + a.e2e_dtype,
             "backbone_only_frames_per_s": round(nfr / d2, 1),
-            "note": "Clip.img_inference_tiled (PyTorch-ROCm) + saf_fuse_frames through ClipFusion.integrate; "
-                    "kMaX is not part of this pass",
+            "backbone_deferred_to_flush": bool(bs <= fz._DEFER_MAX_BATCH),
+            "note": "Clip.img_inference_tiled (PyTorch-ROCm) + saf_fuse_frames through ClipFusion.integrate; calls of up to 15 "
+                    "frames are queued and the ViT runs on all queued frames when the queue is flushed (128 frames x 35 tiles, "
+                    "1024 tiles per encode_image call); kMaX is not part of this pass",
         }
 
     # ---- the reference's call pattern: one frame per integrate() call (clipfusion.py:1125-1133) ----

@@ -135,7 +135,8 @@ int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_fr
 /* Copy one frame's inputs (depth, rgb, pose, K, feature map, label map -- all f32) from `src` into the buffers `dst`
  * points to, in ONE launch: the host queue behind integrate() keeps the frames of small calls in a staging ring until a
  * window is full.  The source feature map is addressed through element strides (Clip.img_inference_tiled returns a
- * permuted view); feat_channels = channels to copy; everything else is contiguous. */
+ * permuted view); feat_channels = channels to copy; everything else is contiguous.  src->feat_map may be NULL (the queue
+ * computes the feature maps later, in one backbone batch per flush): nothing is copied for it. */
 int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_stride_c, int64_t feat_stride_y,
                     int64_t feat_stride_x, const saf_frame* dst, void* stream);
 

@@ -17,7 +17,7 @@ import torch
 
 from . import _abi
 from ._lib import SafError, check, current_stream_ptr, lib, require_cuda
-from .clipfusion import _FusionVolumeMixin, _query_scan
+from .clipfusion import _FusionVolumeMixin, _lazy_clip_features, _query_scan
 
 N_PANOPTIC_SLOTS = 133 + 10  # clip_seem_fusion.py:655 -- 133 COCO panoptic classes, null = 133, spare slots
 
@@ -36,9 +36,10 @@ class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_patch_size, clip_patch_stride,
                  clip_model, seg_model, keep_xyz_world=True, feat_dtype=torch.float32, defer_frames=True,
-                 index_offset=(0, 0, 0), x_planes=None):
+                 index_offset=(0, 0, 0), x_planes=None, defer_backbone=True):
         super().__init__()
         self.__dict__["defer_frames"] = bool(defer_frames)
+        self.__dict__["defer_backbone"] = bool(defer_backbone)
         self.clip = clip_model
         self.clip_patch_size = clip_patch_size
         self.clip_patch_stride = clip_patch_stride
@@ -58,6 +59,10 @@ class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
                 rgb_chw, depth_imgs, K, patch_stride=self.clip_patch_stride
             )
         else:
+            lazy = _lazy_clip_features(self, rgb_imgs)
+            if lazy is not None:  # the ViT runs when the queue is flushed, on all queued frames at once
+                label_maps = [self.segmentation_model.run_on_image(rgb_chw[i]).float().contiguous() for i in range(len(rgb_imgs))]
+                return self._fuse(depth_imgs, rgb_imgs, poses, K, None, label_maps, True, lazy_feat=lazy)
             clip_feat_img = self.clip.img_inference_tiled(
                 rgb_chw, patch_size=self.clip_patch_size, patch_stride=self.clip_patch_stride
             )

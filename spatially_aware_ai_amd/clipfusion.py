@@ -197,35 +197,54 @@ class _FusionVolumeMixin:
     # window is flushed earlier when the device has finished the previous flush and would otherwise idle
     _QUEUE_FRAMES = 4 * _abi.SAF_WINDOW_FRAMES
 
-    def _defer_ok(self, bsz, feat):
+    def _defer_ok(self, bsz, npy, npx):
         if not self.__dict__.get("defer_frames", True) or bsz > self._DEFER_MAX_BATCH:
             return False
         d = int(self.n_clip_feats)
         bf16 = self._buffers["clip_feat"].dtype == torch.bfloat16
         # the shapes saf_fuse_frames takes on the windowed path (include/saf.h); others gain nothing from a queue
-        return d <= 1024 and d % (512 if bf16 else 256) == 0 and feat.shape[2] + 3 <= 255 and feat.shape[3] + 3 <= 255
+        return d <= 1024 and d % (512 if bf16 else 256) == 0 and npy + 3 <= 255 and npx + 3 <= 255
 
-    def _fuse(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False):
+    def _fuse(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False, lazy_feat=None):
+        """``lazy_feat`` = (fn, (C, npy, npx)) instead of ``clip_feat_img``: the feature maps of these frames are
+        ``fn(rgb[n,H,W,3]) -> [n,C,npy,npx]`` and may be computed later -- when the queue is flushed, for all queued frames in
+        one backbone batch (the reference feeds its ViT 35 tiles per call; a flush feeds it 128 x 35)."""
         bsz = int(depth_imgs.shape[0])
-        if clip_feat_img.dim() != 4 or not self._defer_ok(bsz, clip_feat_img):
-            self._flush_pending()
-            return self._fuse_now(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
+        f32 = torch.float32
+        if clip_feat_img is None:
+            fn, fshape = lazy_feat
+            lazy_ok = self._defer_ok(bsz, fshape[1], fshape[2]) and all(
+                t.is_cuda and t.dtype == f32 and t.is_contiguous() for t in (depth_imgs, rgb_imgs, poses, K)) and (
+                label_maps is None or all(m.is_cuda and m.dtype == f32 and m.is_contiguous() for m in label_maps))
+            if not lazy_ok:
+                return self._fuse(depth_imgs, rgb_imgs, poses, K, fn(rgb_imgs), label_maps, rgb_bilinear)
+            # the backbone runs at flush time: under the autocast state of THIS call
+            lazy = (fn, bool(torch.is_autocast_enabled("cuda")), torch.get_autocast_dtype("cuda"))
+        else:
+            lazy = None
+            if clip_feat_img.dim() != 4 or not self._defer_ok(bsz, int(clip_feat_img.shape[2]), int(clip_feat_img.shape[3])):
+                self._flush_pending()
+                return self._fuse_now(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
+            fshape = tuple(int(v) for v in clip_feat_img.shape[1:])
         h, w = int(depth_imgs.shape[1]), int(depth_imgs.shape[2])
         if tuple(rgb_imgs.shape) != (bsz, h, w, 3):
             raise ValueError(f"rgb_imgs must be [B,H,W,3], got {tuple(rgb_imgs.shape)}")
         if tuple(poses.shape) != (bsz, 4, 4) or tuple(K.shape) != (bsz, 3, 3):
             raise ValueError("poses must be [B,4,4] and K [B,3,3]")
-        if clip_feat_img.shape[0] != bsz or clip_feat_img.shape[1] < self.n_clip_feats:
+        if lazy is None and (clip_feat_img.shape[0] != bsz or clip_feat_img.shape[1] < self.n_clip_feats):
             raise ValueError(f"feature map must be [B,D>={self.n_clip_feats},npy,npx], got {tuple(clip_feat_img.shape)}")
-        for t, name in ((depth_imgs, "depth_imgs"), (rgb_imgs, "rgb_imgs"), (poses, "poses"), (K, "K"),
-                        (clip_feat_img, "clip feature map")):
+        if fshape[0] < self.n_clip_feats:
+            raise ValueError(f"the backbone yields {fshape[0]} channels, the volume holds {self.n_clip_feats}")
+        for t, name in ((depth_imgs, "depth_imgs"), (rgb_imgs, "rgb_imgs"), (poses, "poses"), (K, "K")) + (
+                () if lazy is not None else ((clip_feat_img, "clip feature map"),)):
             require_cuda(t, name)
         if label_maps is not None:
             for m in label_maps:
                 require_cuda(m, "label map")
                 if tuple(m.shape) != (h, w):
                     raise ValueError("label map must be [H,W]")
-        key = (h, w, tuple(int(v) for v in clip_feat_img.shape[1:]), label_maps is not None, bool(rgb_bilinear))
+        # frames queued together share the shapes and, for deferred features, the backbone call and its autocast state
+        key = (h, w, tuple(fshape), label_maps is not None, bool(rgb_bilinear), None if lazy is None else (id(lazy[0]),) + lazy[1:])
         st = self.__dict__.get("_stage")
         if st is None or st["key"] != key:
             self._flush_pending()
@@ -234,7 +253,8 @@ class _FusionVolumeMixin:
             mk = lambda *shape: torch.empty((n,) + shape, dtype=torch.float32, device=dev)
             st = {"key": key, "depth": mk(h, w), "rgb": mk(h, w, 3), "pose": mk(4, 4), "K": mk(3, 3),
                   "feat": mk(*key[2]), "labels": mk(h, w) if label_maps is not None else None, "event": None,
-                  "stream": None, "src": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0),
+                  "stream": None, "lazy": lazy,
+                  "src": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0),
                   "dst": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0)}
             # base addresses and byte strides of the ring's slots (no tensor views per call)
             st["base"] = tuple(st[k].data_ptr() if st[k] is not None else 0 for k in ("depth", "rgb", "pose", "K", "feat", "labels"))
@@ -247,20 +267,21 @@ class _FusionVolumeMixin:
             stream = torch.cuda.current_stream(dev)
             if st["event"] is not None and st["stream"] != stream.cuda_stream:
                 stream.wait_event(st["event"])  # the last flush may still be reading the staging ring on its stream
-            f32 = torch.float32
-            fast = all(t.dtype == f32 for t in (depth_imgs, rgb_imgs, poses, K, clip_feat_img)) and depth_imgs.is_contiguous() \
-                and rgb_imgs.is_contiguous() and poses.is_contiguous() and K.is_contiguous() and \
-                (label_maps is None or all(m.dtype == f32 and m.is_contiguous() for m in label_maps))
+            fast = lazy is not None or (
+                all(t.dtype == f32 for t in (depth_imgs, rgb_imgs, poses, K, clip_feat_img)) and depth_imgs.is_contiguous()
+                and rgb_imgs.is_contiguous() and poses.is_contiguous() and K.is_contiguous() and
+                (label_maps is None or all(m.dtype == f32 and m.is_contiguous() for m in label_maps)))
             src, dst, base, step = st["src"], st["dst"], st["base"], st["step"]
             raw_stream = stream.cuda_stream
             if fast:
-                fs = clip_feat_img.stride()
-                sp = (depth_imgs.data_ptr(), rgb_imgs.data_ptr(), poses.data_ptr(), K.data_ptr(), clip_feat_img.data_ptr())
+                fs = (0, 0, 0, 0) if lazy is not None else clip_feat_img.stride()
+                sp = (depth_imgs.data_ptr(), rgb_imgs.data_ptr(), poses.data_ptr(), K.data_ptr(),
+                      0 if lazy is not None else clip_feat_img.data_ptr())
             for i in range(bsz):
                 k = self.__dict__["_pending_n"]
                 if fast:  # one launch per frame (saf_stage_frame); addresses by arithmetic: no tensor views, no new descriptors
                     src.depth, src.rgb, src.pose = sp[0] + i * step[0], sp[1] + i * step[1], sp[2] + i * 64
-                    src.K, src.feat_map = sp[3] + i * 36, sp[4] + i * fs[0] * 4
+                    src.K, src.feat_map = sp[3] + i * 36, (None if lazy is not None else sp[4] + i * fs[0] * 4)
                     dst.depth, dst.rgb, dst.pose = base[0] + k * step[0], base[1] + k * step[1], base[2] + k * step[2]
                     dst.K, dst.feat_map = base[3] + k * step[3], base[4] + k * step[4]
                     if label_maps is not None:
@@ -280,7 +301,7 @@ class _FusionVolumeMixin:
                                                    (st["event"] is None or st["event"].query())):
                     self._flush_pending()
             if fast:  # the sources are read asynchronously on this stream
-                for t in (depth_imgs, rgb_imgs, poses, K, clip_feat_img) + tuple(label_maps or ()):
+                for t in (depth_imgs, rgb_imgs, poses, K) + (() if lazy is not None else (clip_feat_img,)) + tuple(label_maps or ()):
                     t.record_stream(stream)
 
     def flush(self):
@@ -307,7 +328,14 @@ class _FusionVolumeMixin:
         self.__dict__["_pending_n"] = 0  # first: the buffer accesses below must not re-enter
         st = self.__dict__["_stage"]
         labs = None if st["labels"] is None else st["labels"][:n]
-        self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], st["feat"][:n], labs, st["key"][4])
+        feat = st["feat"][:n]
+        if st.get("lazy") is not None:  # the queued frames' feature maps, in one backbone batch
+            fn, ac_on, ac_dtype = st["lazy"]
+            with torch.no_grad(), torch.autocast("cuda", dtype=ac_dtype, enabled=ac_on):
+                feat = fn(st["rgb"][:n])
+            if tuple(feat.shape) != (n,) + tuple(st["key"][2]):
+                raise SafError(f"the backbone returned {tuple(feat.shape)} for {n} frames, expected {(n,) + tuple(st['key'][2])}")
+        self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], feat, labs, st["key"][4])
         dev = self._buffers["tsdf"].device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)
@@ -817,6 +845,26 @@ IMAGENET_PROMPT_TEMPLATES = _imagenet_templates()
 # --------------------------------------------------------------------------------------------
 
 
+def _lazy_clip_features(fusion, rgb_imgs):
+    """(fn, (C, npy, npx)) if the CLIP feature maps of ``rgb_imgs`` [B,H,W,3] may be computed later, in one backbone batch
+    with the other frames queued behind ``integrate()``: only for this package's own ``Clip`` (a pure function of the image;
+    an injected object may depend on when it is called), and only if the tiling fits (else the call raises now, as the
+    reference does).  ``defer_backbone=False`` in the constructor switches it off."""
+    clip = fusion.clip
+    if not isinstance(clip, Clip) or not fusion.__dict__.get("defer_backbone", True) or not fusion.__dict__.get("defer_frames", True):
+        return None
+    ps, stride = int(fusion.clip_patch_size), int(fusion.clip_patch_stride)
+    h, w = int(rgb_imgs.shape[1]), int(rgb_imgs.shape[2])
+    if rgb_imgs.dim() != 4 or h < ps or w < ps or (h - ps) % stride != 0 or (w - ps) % stride != 0:
+        return None
+    fn = fusion.__dict__.get("_lazy_fn")
+    if fn is None or fn[1:] != (ps, stride, id(clip)):
+        f = lambda rgb_nhwc: clip.img_inference_tiled(rgb_nhwc.permute(0, 3, 1, 2), patch_size=ps, patch_stride=stride)
+        fn = (f, ps, stride, id(clip))
+        fusion.__dict__["_lazy_fn"] = fn  # one function object per configuration: the queue's key compares its id
+    return fn[0], (int(clip.feature_dim), 1 + (h - ps) // stride, 1 + (w - ps) // stride)
+
+
 class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
     """Dense voxel volume with projective running-average fusion (reference clipfusion.py:575-763).
 
@@ -830,9 +878,10 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_model, clip_pretraining,
                  clip_patch_size, clip_patch_stride, keep_xyz_world=True, feat_dtype=torch.float32, defer_frames=True,
-                 index_offset=(0, 0, 0), x_planes=None):
+                 index_offset=(0, 0, 0), x_planes=None, defer_backbone=True):
         super().__init__()
         self.__dict__["defer_frames"] = bool(defer_frames)
+        self.__dict__["defer_backbone"] = bool(defer_backbone)
         if isinstance(clip_model, str):
             self.clip = Clip(clip_model, clip_pretraining)
             self.clip.requires_grad_(False)
@@ -854,6 +903,9 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
                 rgb_imgs.permute(0, 3, 1, 2), depth_imgs, K, patch_stride=self.clip_patch_stride
             )
         else:
+            lazy = _lazy_clip_features(self, rgb_imgs)
+            if lazy is not None:
+                return self._fuse(depth_imgs, rgb_imgs, poses, K, None, None, False, lazy_feat=lazy)
             clip_feat_img = self.clip.img_inference_tiled(
                 rgb_imgs.permute(0, 3, 1, 2), patch_size=self.clip_patch_size, patch_stride=self.clip_patch_stride
             )

@@ -435,16 +435,16 @@ int saf_clear_unwritten_rows(const saf_volume* vol, int64_t first_voxel, int64_t
 
 int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_stride_c, int64_t feat_stride_y,
                     int64_t feat_stride_x, const saf_frame* dst, void* stream) {
-  if (!src || !dst || !src->depth || !src->rgb || !src->pose || !src->K || !src->feat_map || !dst->depth || !dst->rgb ||
-      !dst->pose || !dst->K || !dst->feat_map || src->height <= 0 || src->width <= 0 || feat_channels <= 0 || src->npy <= 0 ||
-      src->npx <= 0 || (src->label_map && !dst->label_map))
+  if (!src || !dst || !src->depth || !src->rgb || !src->pose || !src->K || !dst->depth || !dst->rgb || !dst->pose || !dst->K ||
+      src->height <= 0 || src->width <= 0 || (src->label_map && !dst->label_map) ||
+      (src->feat_map && (!dst->feat_map || feat_channels <= 0 || src->npy <= 0 || src->npx <= 0)))
     return fail(SAF_E_INVALID, "stage_frame: bad arguments");
   StageArgs a;
   const int hw = src->height * src->width;
   const float* s[6] = {src->depth, src->rgb, src->pose, src->K, src->feat_map, src->label_map};
   float* d[6] = {const_cast<float*>(dst->depth), const_cast<float*>(dst->rgb), const_cast<float*>(dst->pose),
                  const_cast<float*>(dst->K), const_cast<float*>(dst->feat_map), const_cast<float*>(dst->label_map)};
-  const int n[6] = {hw, 3 * hw, 16, 9, feat_channels * src->npy * src->npx, src->label_map ? hw : 0};
+  const int n[6] = {hw, 3 * hw, 16, 9, src->feat_map ? feat_channels * src->npy * src->npx : 0, src->label_map ? hw : 0};
   for (int k = 0; k < 6; ++k) { a.src[k] = s[k]; a.dst[k] = d[k]; a.n[k] = n[k]; }
   a.fs0 = feat_stride_c; a.fs1 = feat_stride_y; a.fs2 = feat_stride_x; a.f1 = src->npy; a.f2 = src->npx;
   const int blocks = (3 * hw + 256 * 8 - 1) / (256 * 8);
