@@ -574,12 +574,16 @@ def test_backbone_deferred_to_the_flush_is_invisible(seem):
             if seem:
                 fz.segmentation_model.cur = f["labels"].cuda()
             bufs = [f[k].cuda().clone() for k in ("depth", "rgb", "pose", "K")]
-            fz.integrate(*bufs)
+            if i in (57, 58, 140):  # calls that bring their own feature maps, in between: another kind of queue entry
+                fmap = fz.clip.img_inference_tiled(bufs[1].permute(0, 3, 1, 2), 32, 32)
+                fz.integrate_features(*bufs, fmap, [f["labels"].float().cuda()] if seem else None)
+            else:
+                fz.integrate(*bufs)
             for b in bufs:
                 b.fill_(float("nan"))  # the caller reuses its buffers
         if i == 100:
             assert later.pending_frames > 0 and int(later._buffers["weight"].sum()) < int(now.weight.sum())
-    assert later.pending_frames == n_frames % 128 or later.pending_frames == n_frames - 128
+    assert 0 < later.pending_frames < n_frames
     s1, s2 = now.stats(), later.stats()
     for k in ("window_rows", "window_tsdf_voxels"):  # how the calls fell into windows may differ: flushes are timing dependent
         assert s1.pop(k) > 0 and s2.pop(k) > 0
