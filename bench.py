@@ -429,6 +429,18 @@ def main():
                         "the window form moves %.0f %% of the bytes a frame-at-a-time fusion must move (rows travel once per "
                         "window of %d frames instead of once per frame): `frac` prices the bytes this kernel is left with, "
                         "so it FALLS when a longer window removes bytes faster than time" % (100.0 * frame_bytes / single, WIN)}
+            try:  # what the kernel is actually bound by: L2 -> L1 gathers (map taps), from the committed PMC pass
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "rowpath_pmc.json")))
+                if a.grid == 256 and a.dim == 512 and a.depth_kind == "A" and a.feat_dtype == "f32" and not a.labels and WIN == 128:
+                    gb = pj["TCP_TCC_READ_REQ_sum"] * 128.0
+                    roofline["l2_gather"] = {
+                        "bytes_per_launch": int(gb), "launch_us": round(pj["us_pass_d"], 1),
+                        "achieved_TBps": round(gb / pj["us_pass_d"] / 1e6, 2), "ceiling_TBps": [16.8, 18.8],
+                        "source": "profiles/r02/rowpath_pmc.json (rocprofv3 --pmc TCP_TCC_READ_REQ_sum x 128 B over the kernel's "
+                                  "duration in that pass: one fresh 128-frame window, earlier box); ceiling = "
+                                  "MI355X_MICROARCH.md, gathers of L2-resident rows"}
+            except Exception:
+                pass
             roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of %d " % WIN +
                                 "frames (hits applied in frame order: bit-identical to frame-by-frame fusion); the NEXT window's "
                                 "classification + TSDF (classify kernels, kernel_breakdown.sweep_us per 32 frames) run beside it on "
