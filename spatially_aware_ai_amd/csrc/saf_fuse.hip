@@ -739,7 +739,7 @@ int launch_fuse(const KVol& kv, const KFrame& kf, const WsLayout& w, const float
   // ONE per CU is launched so that the other half of the registers, ~80 KB of LDS and 16 wave slots
   // stay free for four sweep blocks of the next frame: both kernels are then resident on every CU
   // and neither can starve the other at dispatch.
-  static const int grid_env = getenv("SAF_FUSE_GRID") ? atoi(getenv("SAF_FUSE_GRID")) : 0;
+  const int grid_env = getenv("SAF_FUSE_GRID") ? atoi(getenv("SAF_FUSE_GRID")) : 0;
   // one workgroup per CU is enough in-flight rows to saturate HBM (alone: 276 us with 208..256
   // workgroups, 286 us with 512); in the pipeline 13/16 of the CUs (208 on MI355X) measured best
   int grid = grid_env > 0 ? grid_env : (shared_cus ? (device_cus() * 13) / 16 : device_cus());
@@ -953,7 +953,7 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
   // counters and the completion counter start at zero; afterwards every sweep zeroes its successor's set
   if (hipMemsetAsync(ws, 0, kHdrBytes, s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
   // SAF_PIPELINE=0 keeps everything on the caller's stream (debugging / per-kernel timing)
-  static const bool pipeline = !(getenv("SAF_PIPELINE") && getenv("SAF_PIPELINE")[0] == '0');
+  const bool pipeline = !(getenv("SAF_PIPELINE") && getenv("SAF_PIPELINE")[0] == '0');
   if (n_frames == 1 || !pipeline) {
     for (int32_t i = 0; i < n_frames; ++i) {
       FrameJob job;

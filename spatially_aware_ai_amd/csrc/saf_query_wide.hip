@@ -758,7 +758,7 @@ int launch_wide2_nf(const Wide2Args& wa, hipStream_t s) {
 // SAF_WIDE_ROWS=32 / 64 in the environment picks the geometry (development; the default is the measured-faster one)
 template <int FT, int OT, int KS, int EPI>
 int launch_wide2(const Wide2Args& wa, hipStream_t s) {
-  static const int rows_env = getenv("SAF_WIDE_ROWS") ? atoi(getenv("SAF_WIDE_ROWS")) : 0;
+  const int rows_env = getenv("SAF_WIDE_ROWS") ? atoi(getenv("SAF_WIDE_ROWS")) : 0;
   if (rows_env == 64) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
   if (rows_env == 32) return launch_wide2_nf<FT, OT, KS, EPI, 1, 512>(wa, s);
   // measured at config 5 (ms, 32 vs 64 rows per wave): heat maps 27.5 / 31.4, best query per voxel 19.3 / 20.4, raw scores

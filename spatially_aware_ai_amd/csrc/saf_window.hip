@@ -1057,12 +1057,12 @@ int window_frames() {
 }
 
 bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
-  static const bool enabled = !(getenv("SAF_WINDOW") && getenv("SAF_WINDOW")[0] == '0');
+  const bool enabled = !(getenv("SAF_WINDOW") && getenv("SAF_WINDOW")[0] == '0');
   if (!enabled || n_frames < kWinMinFrames || kv.D % 256 != 0 || kv.D > 1024) return false;
   // bf16 volumes: the rows are half the bytes, the map taps are not, so the gain is smaller than for f32
   // (4253 vs 3916 frames/s, 3935 vs 3586 with labels, 4544 vs 3976 on the coherent scene);
   // SAF_WINDOW_BF16=0 keeps them on the per-frame pipeline
-  static const bool bf16_on = !(getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '0');
+  const bool bf16_on = !(getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '0');
   if (kv.bf16 && (!bf16_on || kv.D % 512 != 0)) return false;  // a lane moves 8 bf16 channels: 512 per wave
   const saf_frame& f0 = frames[0];
   for (int32_t i = 0; i < n_frames; ++i) {
@@ -1106,12 +1106,12 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", win_lds, hipGetErrorString(e));
   }
   float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
-  static const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
+  const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
   uint32_t grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : 2);
   const uint32_t n_pieces = (uint32_t)(((int64_t)kv.N + kPiece - 1) / kPiece);
   const uint32_t n_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
   if (grid > n_wgs) grid = n_wgs;
-  static const int tile_env = getenv("SAF_WIN_TILE") ? atoi(getenv("SAF_WIN_TILE")) : -1;
+  const int tile_env = getenv("SAF_WIN_TILE") ? atoi(getenv("SAF_WIN_TILE")) : -1;
   int tile = tile_env >= 0 ? tile_env : 32;
   {
     const int64_t plane = (int64_t)kv.ny * kv.nz;
@@ -1121,7 +1121,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (tile < 8) tile = 0;  // linear order
   }
   // grids that tile into 4 x 4 x 16 bricks classify brick by brick (SAF_WIN_BRICKS=0: always the linear pieces)
-  static const bool bricks_on = !(getenv("SAF_WIN_BRICKS") && getenv("SAF_WIN_BRICKS")[0] == '0');
+  const bool bricks_on = !(getenv("SAF_WIN_BRICKS") && getenv("SAF_WIN_BRICKS")[0] == '0');
   const bool bricks = bricks_on && kv.nx % kBrickX == 0 && kv.ny % kBrickY == 0 && kv.nz % kBrickZ == 0;
   const int brick_tiles = (kv.nx / kBrickX) % 8 == 0 && (kv.ny / kBrickY) % 8 == 0 ? 1 : 0;
   static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kDmaxOff + 32 * sizeof(float) <= kClsAccOff,
