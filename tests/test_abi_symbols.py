@@ -97,3 +97,26 @@ def test_frame_descriptors_built_by_columns_match_the_struct(monkeypatch):
                 assert f.label_map == keep[5][0][i].data_ptr()
             else:
                 assert f.label_map == keep[5][i].data_ptr()
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line committed under profiles/ (what `python bench.py` printed on an MI355X) carries every field of the
+    driver's contract, the roofline and cpu_baseline objects included."""
+    import json
+
+    path = os.path.join(ROOT, "profiles", "r02", "bench_n1.json")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference")
+    assert abs(d["value"] - d["config"]["frames_per_rank"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
