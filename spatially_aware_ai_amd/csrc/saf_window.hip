@@ -836,12 +836,61 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
       int i0 = 0;
       while (i0 < m) {
         const int pbase = __builtin_amdgcn_readlane(prefix, i0);
-        const unsigned long long okm = __ballot(lane >= i0 && lane < m && lane < i0 + SR && (incl - pbase) <= 64);
-        const int nrows = okm ? __popcll(okm) : 1;
-        const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..kWin
+        // up to SR rows and kSubHits hits (a voxel has at most kWin <= kSubHits): more than 64 hits are applied in passes
+        constexpr int kSubHits = 128;
+        static_assert(kSubHits >= kWin && kSubHits <= kHitCap && kSubHits <= 128, "two blocks of 64 hits at most");
+        const unsigned long long okm = __ballot(lane >= i0 && lane < m && lane < i0 + SR && (incl - pbase) <= kSubHits);
+        const int nrows = __popcll(okm);  // >= 1
+        const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..kSubHits
         WinRaw<SR, UPL> raw;
         raw.nrows = nrows;
         const WinCtx<CPL> cx{maps_rsrc, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
+        // Several rows with more than 64 hits between them (coherent scenes: ~15 hits per row): the staging entries of the
+        // sub-chunk are brought into (frame, row) order first -- ranks from the rows' frame masks as below, for both blocks
+        // of 64 hits, every staging field permuted through the free s_hw array -- and the passes then find them sorted.
+        const bool presorted = nrows > 1 && nh > 64;
+        if (presorted) {
+          int rk[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int j = pbase + 64 * q + lane;
+            const bool hq = 64 * q + lane < nh;
+            const uint32_t hf = hq ? s_hf[j] : 0u;
+            const int my_row = (int)(hf & 63u) - i0;
+            const uint32_t f = hf >> 22, fwd = f >> 5, fbit = f & 31u;
+            int r_ = 0;
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+              if (r < nrows) {
+                uint32_t at_f = 0u;
+#pragma unroll
+                for (int w = 0; w < kMaskWords; ++w) {
+                  const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)mk[w], i0 + r);
+                  const uint32_t low = (uint32_t)w < fwd ? 0xffffffffu : ((uint32_t)w == fwd ? (1u << fbit) - 1u : 0u);
+                  r_ += __popc(mw & low);
+                  at_f = fwd == (uint32_t)w ? mw : at_f;
+                }
+                r_ += (r < my_row && ((at_f >> fbit) & 1u)) ? 1 : 0;
+              }
+            }
+            rk[q] = hq ? r_ : 64 * q + lane;  // entries past the end keep their place
+          }
+          uint32_t* fields[5] = {s_hf, reinterpret_cast<uint32_t*>(s_ha), reinterpret_cast<uint32_t*>(s_hb),
+                                 reinterpret_cast<uint32_t*>(s_hgx), reinterpret_cast<uint32_t*>(s_hgy)};
+          uint32_t* tmp = reinterpret_cast<uint32_t*>(s_hw);
+#pragma unroll
+          for (int fi = 0; fi < 5; ++fi) {
+            const uint32_t v0 = fields[fi][pbase + lane];
+            const uint32_t v1 = 64 + lane < nh ? fields[fi][pbase + 64 + lane] : 0u;
+            wave_lds_sync();
+            tmp[rk[0]] = v0;
+            if (64 + lane < nh) tmp[rk[1]] = v1;
+            wave_lds_sync();
+            fields[fi][pbase + lane] = tmp[lane];
+            if (64 + lane < nh) fields[fi][pbase + 64 + lane] = tmp[64 + lane];
+            wave_lds_sync();
+          }
+        }
         for (int h0 = 0; h0 < nh; h0 += 64) {
           // hit h0 + l of the sub-chunk (staging entry pbase + h0 + l) lives in lane l: its row, a, b and tap weights
           const bool hit = h0 + lane < nh;
@@ -929,7 +978,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
           // earlier form walked the frames with ballots, one serial scalar round trip per group: 11 % of the kernel.)
           WinHit srt = rec;
           uint32_t skey = key;
-          if (nrows > 1) {
+          if (nrows > 1 && !presorted) {
             const int to = (hit ? rank : lane) * 4;  // lanes without a hit keep their place
             srt.row = __builtin_amdgcn_ds_permute(to, rec.row);
             srt.a = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, rec.a)));
