@@ -594,6 +594,34 @@ def test_backbone_deferred_to_the_flush_is_invisible(seem):
     assert float(now.clip_feat.abs().max()) > 0
 
 
+def test_deferred_backbone_runs_under_the_callers_autocast_state():
+    """Frames queued inside torch.autocast are encoded under autocast when the queue is flushed later, outside of it (and
+    the other way round): the flush re-enters the state of the call that queued them."""
+    from spatially_aware_ai_amd import ClipFusion
+    from spatially_aware_ai_amd.clipfusion import Clip
+
+    w, h, nvox, n_frames = 96, 64, (32, 32, 64), 40
+    grid = syn.make_grid(nvox, side=2.56)
+    frames = syn.make_frames(812, n_frames, width=w, height=h, feat_dim=8, npy=2, npx=3, depth_kind="B")
+
+    def run(defer_backbone, autocast_at_call):
+        clip = Clip("stub", None, backbone=_TileStatsBackbone(), tokenizer=None)
+        fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, clip, None, 32, 32, keep_xyz_world=False,
+                        defer_backbone=defer_backbone).cuda()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast_at_call):
+            for f in frames:
+                fz.integrate(f["depth"].cuda(), f["rgb"].cuda(), f["pose"].cuda(), f["K"].cuda())
+            if not defer_backbone:
+                fz.flush()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not autocast_at_call):
+            return fz.clip_feat.clone()  # the deferred form flushes here, under the OTHER state
+
+    for ac in (True, False):
+        per_call, deferred = run(False, ac), run(True, ac)
+        torch.testing.assert_close(deferred, per_call, rtol=1e-5, atol=1e-6)
+    assert not torch.allclose(run(True, True), run(True, False), rtol=1e-4, atol=1e-5), "autocast made no difference: weak test"
+
+
 def test_sum_mode_and_finalize(oracle):
     """SAF_SUM accumulation + saf_merge_finalize == running mean, and mean_to_sum
     is its inverse."""
