@@ -56,6 +56,7 @@ def bench_mesh(a):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.iters):
+        del out  # (1.5 GB of vertex features: the allocator reuses the block instead of asking the driver for a second one)
         out = fz.extract_mesh()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.iters * 1e3
