@@ -546,15 +546,16 @@ class _TileStatsBackbone(torch.nn.Module):
         return blocks @ self.proj
 
 
-@pytest.mark.parametrize("seem", [False, True])
-def test_backbone_deferred_to_the_flush_is_invisible(seem):
+@pytest.mark.parametrize("seem,n_frames", [(False, 150), (True, 150), (False, 1100)])
+def test_backbone_deferred_to_the_flush_is_invisible(seem, n_frames):
     """integrate() with this package's Clip queues the FRAMES and runs the ViT when the queue is flushed, on all queued
     frames at once (the reference feeds it one frame's 35 tiles per call).  Same volume as with the backbone run per call;
     the caller may overwrite its tensors after every call."""
     from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
     from spatially_aware_ai_amd.clipfusion import Clip
 
-    w, h, nvox, n_frames = 96, 64, (32, 32, 64), 150
+    # (1100 one-frame calls: the staging ring of 512 slots is filled and flushed several times)
+    w, h, nvox = 96, 64, (32, 32, 64)
     grid = syn.make_grid(nvox, side=2.56)
     frames = syn.make_frames(811, n_frames, width=w, height=h, feat_dim=8, npy=2, npx=3, depth_kind="B", missing_depth_frac=0.05)
 
