@@ -1,0 +1,799 @@
+// saf_brick.hip -- the brick form of the windowed path's row kernel (clipfusion.py:699-721,
+// clip_seem_fusion.py:752-822 for a window of up to 128 frames at once).
+//
+// The frame-ordered row kernel (saf_window.hip) pulls the four map rows of EVERY hit from L2 through the CU's L1:
+// 8 KB per hit, 4.6 x the kernel's HBM bytes, and it runs at the L2's gather rate.  The taps of a hit depend only on
+// (frame, map cell), and a compact brick of voxels sees one or two cells of a frame: here a workgroup owns a brick of
+// 4 x 4 x 4 voxels, keeps an accumulator for ALL its touched rows in LDS -- a slab of up to 256 channels at a time -- and
+// walks the brick's hits grouped by (frame, map cell): a group's four map rows are loaded ONCE per slab and blended
+// into every member row.
+//
+//   per brick     the voxels' frame masks (left by the classification) -> hits in frame-major order (LDS bit matrix
+//                 frame x voxel built with LDS atomics, prefix sums over frames); per hit: projection, map cell,
+//                 bilinear weights, rgb sample, label count; per voxel, in frame order: the rgb running mean and the
+//                 weight (exactly the per-frame arithmetic); hit records sorted by (frame, cell) in windows of 64 and
+//                 a table of the groups (tap offsets, first hit) built once;
+//   per slab      four WALKER waves take batches of groups round-robin: a lane owns CPL consecutive channels, the tap rows
+//                 of a batch are requested one batch ahead (two register buffers), every hit's sample sum(w_t tap_t)
+//                 goes into the LDS accumulator; four MOVER waves hold the rows' old pieces in registers (requested one
+//                 slab ahead) and after the walk write old * b + acc * a and clear the accumulator.  Only the movers have
+//                 row traffic in flight: a wave's vector-memory operations retire in order, so a walker's tap loads never
+//                 queue behind row loads and stores.
+//
+// Arithmetic: a row's new value is (w0 old + sum of its samples) / (w0 + k) -- the running mean of clipfusion.py:715-721
+// with the k updates of the window folded into one (order-free within fp32 rounding); weights, rgb,
+// labels and which voxels are touched are exactly those of the frame-ordered kernels.
+//
+// The sum of a row's samples is kept in 32-bit FIXED POINT.  gfx950's LDS adds floats atomically at about three lanes
+// per clock (ds_add_f32: 193 cycles per wave instruction, tools/lds_atomic_bench.hip -- the first form of this kernel
+// spent 70 % of its time there) and integers at full rate (ds_add_u32: 7 cycles).  A sample is a convex combination of
+// map values, so with M = the largest magnitude of the slab's channels in the window's maps (chan_max_kernel) and k_max =
+// the most hits any row of the brick takes in this round, |sum| <= k_max M: every sample is scaled by the power of two
+// 2^(30 - ceil(log2 k_max) - ceil(log2 M)) (exact; folded into the bilinear weights), rounded to the nearest integer (the
+// only error: half a unit of M 2^-28 at k_max = 4, of M 2^-23 at 128 -- no more than the rounding of an fp32 running mean
+// of values near M) and added with ds_add_u32.  Integer adds commute: the result does not depend on the order in which
+// the walkers' adds arrive and is reproducible bit for bit.  A window whose maps hold a non-finite value (no number to
+// scale by) takes float atomics instead: slow, NaN / inf propagate as in the reference.  SAF_WIN_FORM=rows selects the
+// frame-ordered kernel (bit-identical to fusing frame after frame).
+#include "saf_window_dev.h"
+
+namespace saf {
+namespace {
+
+constexpr int kBX = 4, kBY = 4, kBZ = 4;   // brick shape (voxels); a thread of wave 0 owns one voxel
+constexpr int kBV = kBX * kBY * kBZ;       // 64
+static_assert(kBV == 64, "one wave of voxel threads, one 64-bit word of the bit matrix per frame");
+constexpr int kWalkers = 4, kMovers = 4;   // waves 0 .. 3 walk, waves 4 .. 7 move rows (a quarter of the rows each: their
+                                           // old pieces must fit a wave's registers at 4 waves per SIMD: two workgroups of 8
+                                           // waves per CU, two waves of each on every SIMD; workgroups of 6 waves at 3 per
+                                           // SIMD never ran two to a CU)
+constexpr int kBWaves = kWalkers + kMovers;
+constexpr int kBThreads = kBWaves * 64;
+constexpr int kHitThreads = kWalkers * 64;
+constexpr int kWindows = 4;                // 64-hit windows of a round, sorted one by one
+constexpr int kHC = kWindows * 64;         // hit records of one round (a brick with more hits takes its frames in rounds)
+static_assert(kHC >= kBV, "a frame's hits fit a round");
+#ifndef SAF_BRICK_P
+#define SAF_BRICK_P 2
+#endif
+constexpr int kP = SAF_BRICK_P;            // groups of one batch: 4 tap loads each, two batches in flight
+
+#ifdef SAF_BRICK_TIMING  // development aid: per-phase wave cycles, by role, printed by the host after every launch
+__device__ unsigned long long g_brick_t[32];
+#define BT_DECL unsigned long long bt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, bt_last_ = __builtin_readcyclecounter()
+#define BT(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); bt_[k] += n_ - bt_last_; bt_last_ = n_; } while (0)
+#define BT_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_brick_t[(wave >= kWalkers ? 16 : 0) + k_], bt_[k_]); } while (0)
+#else
+#define BT_DECL
+#define BT(k)
+#define BT_FLUSH
+#endif
+
+constexpr int kCamFloats = 21;  // the per-frame part of Cam: pose[:3,:4], K (the image-size terms are launch-uniform)
+
+template <int CPL>
+struct alignas(16) BrickLds {
+  int acc[kBV * 64 * CPL];       // [row][channel of the lane][lane]; during the build it stages the hits' rgb samples
+  uint4 grp_off[kHC + 1];        // a group's four map rows: byte offsets into the window's images (slab 0, lane 0)
+  float2 rec_g[kHC];             // a hit's bilinear fractions (wx, wy)
+  uint32_t rec_k[kHC];           // row (7) | cell x (8) << 7 | cell y (8) << 15 | frame (7) << 23
+  uint16_t grp_start[kHC + 8];   // first hit of a group; [G] = number of hits
+  uint32_t mf[kWin * 2];         // bit matrix: frame x voxel
+  uint16_t off[kWin + 8];        // exclusive prefix of the frames' hit counts
+  uint8_t vrow[kBV];             // voxel -> row of this round
+  uint8_t rowfresh[kBV];         // row was never written (weight 0): nothing to read
+  float rowA[kBV], rowB[kBV];    // new = old * b + acc * a
+  uint32_t rown[kBV];            // flat voxel index of a row
+  uint32_t misc[32];
+};
+static_assert(sizeof(BrickLds<4>) <= 76 * 1024, "two workgroups per CU and room for the classification beside them");
+static_assert(kHC * 3 * sizeof(float) <= sizeof(int) * kBV * 64, "the rgb staging lives in the accumulator");
+
+// LDS-only barrier: the walkers' tap loads and the movers' row traffic stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float rl_f(float x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+// floor(x + 0.5) as an integer (one instruction; v_rndne + v_cvt would be two)
+__device__ __forceinline__ int cvt_rpi(float x) {
+  int q;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(x));
+  return q;
+}
+
+__device__ __forceinline__ Cam cam_from(const float* __restrict__ c, const Cam& u) {
+  Cam r = u;
+  r.r00 = c[0]; r.r01 = c[1]; r.r02 = c[2]; r.tx = c[3];
+  r.r10 = c[4]; r.r11 = c[5]; r.r12 = c[6]; r.ty = c[7];
+  r.r20 = c[8]; r.r21 = c[9]; r.r22 = c[10]; r.tz = c[11];
+  r.k00 = c[12]; r.k01 = c[13]; r.k02 = c[14]; r.k10 = c[15]; r.k11 = c[16]; r.k12 = c[17];
+  r.k20 = c[18]; r.k21 = c[19]; r.k22 = c[20];
+  return r;
+}
+
+// position of voxel t's hit among the hits of a frame (voxel order): the set bits of the frame's row below bit t
+__device__ __forceinline__ int rank_in_frame(const uint32_t* __restrict__ mf_row, int t) {
+  int r = __popc(mf_row[t >> 5] & ((1u << (t & 31)) - 1u));
+  if (t >= 32) r += __popc(mf_row[0]);
+  return r;
+}
+
+// CPL consecutive channels of a map row
+template <int CPL>
+struct TapVec {
+  float v[CPL];
+};
+template <int CPL>
+__device__ __forceinline__ TapVec<CPL> tap_load(__amdgpu_buffer_rsrc_t maps, uint32_t byte_off) {
+  TapVec<CPL> t;
+  if constexpr (CPL == 1) {
+    t.v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(maps, (int)byte_off, 0, 0));
+  } else if constexpr (CPL == 2) {
+    // (the whole vector is bit-cast: element access r[i] on the builtin's result makes hipcc 7.2 load ONE dword and use it for
+    //  every element)
+    const float2 f = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(maps, (int)byte_off, 0, 0));
+    t.v[0] = f.x; t.v[1] = f.y;
+  } else {
+    const float4 f = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(maps, (int)byte_off, 0, 0));
+    t.v[0] = f.x; t.v[1] = f.y; t.v[2] = f.z; t.v[3] = f.w;
+  }
+  return t;
+}
+
+// ---- the walk of one slab: batches of kP consecutive groups, handed out round-robin to the walkers
+struct WalkBatch {
+  int hl[kP + 1];  // first hit of each group of the batch; hl[kP] = the batch's end
+};
+struct WalkCtx {
+  __amdgpu_buffer_rsrc_t maps;
+  int G, lane;
+  uint32_t lane_off;  // slab * (256 CPL) + lane * (4 CPL) bytes
+};
+
+template <int CPL>
+__device__ __forceinline__ void walk_issue(const BrickLds<CPL>& L, const WalkCtx& cx, int batch, WalkBatch& b,
+                                           TapVec<CPL> (&tp)[kP][4]) {
+  const int g0 = batch * kP;
+  const int hs = (int)L.grp_start[min(g0 + min(cx.lane, kP), cx.G)];  // lanes 0 .. kP: the groups' first hits ([G] = the end)
+#pragma unroll
+  for (int u = 0; u <= kP; ++u) b.hl[u] = __builtin_amdgcn_readlane(hs, u);
+#pragma unroll
+  for (int u = 0; u < kP; ++u) {
+    const uint4 o = L.grp_off[min(g0 + u, cx.G)];  // entry G: four offsets beyond the buffer (no such group: nothing moves)
+    tp[u][0] = tap_load<CPL>(cx.maps, o.x + cx.lane_off);
+    tp[u][1] = tap_load<CPL>(cx.maps, o.y + cx.lane_off);
+    tp[u][2] = tap_load<CPL>(cx.maps, o.z + cx.lane_off);
+    tp[u][3] = tap_load<CPL>(cx.maps, o.w + cx.lane_off);
+  }
+}
+
+// FX: fixed-point accumulation (`scale` is folded into the weights); otherwise float atomics
+template <int CPL, bool FX>
+__device__ __forceinline__ void walk_process(BrickLds<CPL>& L, const WalkCtx& cx, const WalkBatch& b,
+                                             const TapVec<CPL> (&tp)[kP][4], float scale) {
+  for (int c0 = b.hl[0]; c0 < b.hl[kP]; c0 += 64) {  // (one round trip unless the batch has more than 64 hits)
+    const int slot = min(c0 + cx.lane, b.hl[kP] - 1);
+    const uint32_t key = L.rec_k[slot];
+    const float2 g = L.rec_g[slot];
+    // the bilinear weights (bilinear_setup's products), times the slab's fixed-point scale (a power of two: exact)
+    const float ex = 1.0f - g.x, sy = 1.0f - g.y;
+    const float w_nw = (sy * ex) * scale, w_ne = (sy * g.x) * scale, w_sw = (g.y * ex) * scale, w_se = (g.y * g.x) * scale;
+    const int rowbase = (int)(key & 127u) * (64 * CPL) + cx.lane;
+    // the records are here before the loops start: without this (the BUILTIN: the wait-count pass must see it) the pass puts
+    // an lgkmcnt(0) at the head of the per-hit loop, where it waits for the previous hit's ds_add every time round
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt, expcnt untouched
+    const int c1 = c0 + 64;
+#pragma unroll
+    for (int u = 0; u < kP; ++u) {
+      const int l0 = max(b.hl[u], c0), l1 = min(b.hl[u + 1], c1);
+      for (int l = l0; l < l1; ++l) {
+        const int li = l - c0;
+        const float wnw = rl_f(w_nw, li), wne = rl_f(w_ne, li), wsw = rl_f(w_sw, li), wse = rl_f(w_se, li);
+        const int idx = __builtin_amdgcn_readlane(rowbase, li) - li + cx.lane;  // the hit's row, this lane
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          float s = tp[u][0].v[c] * wnw;
+          s = __builtin_fmaf(tp[u][1].v[c], wne, s);
+          s = __builtin_fmaf(tp[u][2].v[c], wsw, s);
+          s = __builtin_fmaf(tp[u][3].v[c], wse, s);
+          if (FX) {
+            __hip_atomic_fetch_add(&L.acc[idx + c * 64], cvt_rpi(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            __hip_atomic_fetch_add(reinterpret_cast<float*>(&L.acc[idx + c * 64]), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int CPL, bool FX>
+__device__ __forceinline__ void walk_slab(BrickLds<CPL>& L, const WalkCtx& wc, int wave, float scale) {
+  const int n_batch = (wc.G + kP - 1) / kP;
+  WalkBatch bA, bB;
+  TapVec<CPL> tpA[kP][4], tpB[kP][4];
+  int batch = wave;
+  if (batch >= n_batch) return;
+  walk_issue<CPL>(L, wc, batch, bA, tpA);
+  for (;;) {
+    const bool hasB = batch + kWalkers < n_batch;
+    if (hasB) walk_issue<CPL>(L, wc, batch + kWalkers, bB, tpB);
+    walk_process<CPL, FX>(L, wc, bA, tpA, scale);
+    if (!hasB) break;
+    batch += 2 * kWalkers;
+    const bool hasA = batch < n_batch;
+    if (hasA) walk_issue<CPL>(L, wc, batch, bA, tpA);
+    walk_process<CPL, FX>(L, wc, bB, tpB, scale);
+    if (!hasA) break;
+  }
+}
+
+// The fixed-point scale of a slab: 2^e with e = 30 - kexp - ceil(log2 M), M = the largest magnitude of its channels in the
+// window's maps (bits of |x|), so that k_max samples of magnitude <= M sum to less than 2^31.  Returned as the exponent.
+__device__ __forceinline__ int scale_exp(uint32_t mbits, int kexp) {
+  const int ex = (int)(mbits >> 23) - 127 + ((mbits & 0x7fffffu) ? 1 : 0);  // M <= 2^ex (denormals: ex = -127 or -126)
+  const int e = 30 - kexp - ex;
+  return min(max(e, -96), 96);  // (a slab of values below 2^-66 is resolved to 2^-96; an all-zero slab to anything)
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (uint32_t)(e + 127) << 23); }
+template <int CPL>
+__device__ __forceinline__ uint32_t slab_max_bits(const uint32_t* __restrict__ cmax, int D, int p) {
+  uint32_t m = 0u;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) m = max(m, cmax[D + p * CPL + j]);
+  return m;
+}
+
+template <int CPL, bool SUM, bool BF16>
+__global__ __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fuse_brick_kernel(
+    KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, uint32_t img_bytes,
+    unsigned long long* __restrict__ stats, unsigned int* __restrict__ ctr, const uint32_t* __restrict__ hitmask,
+    uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc, const uint32_t* __restrict__ cmax,
+    const float* __restrict__ cams) {
+  using Lds = BrickLds<CPL>;
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  Lds& L = *reinterpret_cast<Lds*>(s_dyn);
+  // (values read from LDS or derived from the thread index are divergent to the compiler: what is wave-uniform is said
+  //  so with readfirstlane -- scalar branches, loop counters in SGPRs)
+  const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+  const int F = wa.F;
+  constexpr int kSlabCh = 64 * CPL;
+
+  if (stats && blockIdx.x == 0 && tid < kClsShards) {  // the classification launches' sharded counters (cls_accumulate)
+    unsigned long long a = cls_acc[2 * tid], b = cls_acc[2 * tid + 1];
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    if (tid == 0) {
+      if (a) atomicAdd(&stats[1], a);
+      if (b) atomicAdd(&stats[6], b);
+    }
+  }
+  const Cam ucam = load_cam(tab->pose[0], tab->K[0], wa.W, wa.H);  // its image-size terms are the same for every frame
+  const int n_pass = v.D / kSlabCh;
+  const float half_px = (float)wa.npx / 2.0f, half_py = (float)wa.npy / 2.0f;
+  float4* feat = reinterpret_cast<float4*>(v.feat);
+  const __amdgpu_buffer_rsrc_t maps_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(map_imgs), 0, (int)((size_t)F * img_bytes), 0x00020000);
+  const uint32_t row_bytes = (uint32_t)v.D * 4u;
+  KFrame kf;
+  kf.H = wa.H; kf.W = wa.W; kf.npy = wa.npy; kf.npx = wa.npx; kf.rgb_bilinear = wa.rgb_bilinear;
+  kf.depth = nullptr; kf.pose = nullptr; kf.K = nullptr;
+  unsigned long long hits_done = 0, rows_done = 0;
+  // fixed-point accumulation unless a map value of this window is not finite (chan_max_kernel leaves the largest |x| of all
+  // channels behind the per-channel and per-64-channel maxima)
+  const bool fx = rfl((int)(cmax[v.D + v.D / 64] < 0x7f800000u)) != 0;
+  BT_DECL;
+
+  // Bricks are handed out XCD by XCD: workgroup i runs on XCD i % 8 (round-robin dispatch), every XCD draws from its own
+  // counter and walks its own tiles of 4 x 4 brick columns (tile t belongs to XCD t % 8) in sections of 4 bricks along z,
+  // so the 64 bricks an XCD has in flight are one 16 x 16 x 16-voxel box whose map taps stay in its L2.  An XCD that
+  // runs out helps the next one.  Bricks beyond a ragged grid's edge are skipped, voxels beyond it masked.
+  const uint32_t nbx = ((uint32_t)v.nx + kBX - 1) / kBX, nby = ((uint32_t)v.ny + kBY - 1) / kBY, nbz = ((uint32_t)v.nz + kBZ - 1) / kBZ;
+  const uint32_t tiles_y = (nby + 3u) / 4u, n_tiles = ((nbx + 3u) / 4u) * tiles_y;
+  const uint32_t zsecs = (nbz + 3u) / 4u, upt = zsecs * 64u;
+  uint32_t xcd = blockIdx.x & 7u, xcd_tries = 0;
+
+  // voxel of this thread within a brick (wave 0)
+  const int lx = (tid >> 4) & 3, ly = (tid >> 2) & 3, lz = tid & 3;
+  const bool vth = tid < kBV;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  for (;;) {
+    if (tid == 0) {
+      uint32_t code = 0xffffffffu;
+      while (xcd_tries < 8u) {
+        const uint32_t my_tiles = (n_tiles + 7u - xcd) / 8u;
+        const uint32_t j = atomicAdd(ctr + xcd, 1u);
+        if (j >= my_tiles * upt) {
+          ++xcd_tries;
+          xcd = (xcd + 1u) & 7u;
+          continue;
+        }
+        const uint32_t tl = j / upt, within = j - tl * upt, zs = within >> 6, k = within & 63u;
+        const uint32_t t = tl * 8u + xcd, tx = t / tiles_y, ty = t - tx * tiles_y;
+        const uint32_t bx = tx * 4u + ((k >> 2) & 3u), by = ty * 4u + (k & 3u), bz = zs * 4u + (k >> 4);
+        if (bx >= nbx || by >= nby || bz >= nbz) continue;
+        code = bx | (by << 10) | (bz << 20);
+        break;
+      }
+      L.misc[0] = code;
+    }
+    lds_barrier();
+    const uint32_t code = (uint32_t)rfl((int)L.misc[0]);
+    if (code == 0xffffffffu) break;
+    const int bx = (int)(code & 1023u), by = (int)((code >> 10) & 1023u), bz = (int)(code >> 20);
+    const int ix = bx * kBX + lx, iy = by * kBY + ly, iz = bz * kBZ + lz;
+    const bool inb = vth && ix < v.nx && iy < v.ny && iz < v.nz;
+    const uint32_t n = ((uint32_t)ix * (uint32_t)v.ny + (uint32_t)iy) * (uint32_t)v.nz + (uint32_t)iz;
+    uint32_t mk[kMaskWords];
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) mk[w] = (inb && w * 32 < F) ? hitmask[(size_t)w * mask_plane + n] : 0u;
+    uint32_t any = 0u;
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) any |= mk[w];
+    // (the zeroing of the bit matrix rides on this barrier)
+    if (tid < kWin * 2) L.mf[tid] = 0u;
+    if (wave == 0) {
+      const unsigned long long wany = __ballot(any != 0u);
+      if (lane == 0) L.misc[4] = wany != 0ull ? 1u : 0u;
+    }
+    lds_barrier();
+    BT(0);
+    if (rfl((int)L.misc[4]) == 0) continue;
+    int w_cur = 0;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (any) {
+      w_cur = v.weight[n];
+      const float* src = v.rgb + (int64_t)n * 3;
+      o0 = src[0]; o1 = src[1]; o2 = src[2];
+      rows_done += 1ull;
+      // ---- bit matrix frame x voxel
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) {
+        uint32_t mm = mk[w];
+        while (mm) {
+          const int f = __ffs((int)mm) - 1 + 32 * w;
+          mm &= mm - 1u;
+          atomicOr(&L.mf[f * 2 + (tid >> 5)], 1u << (tid & 31));
+        }
+      }
+    }
+    lds_barrier();
+    // ---- hits per frame and their exclusive prefix (frames beyond F have none)
+    {
+      int cf = 0;
+      if (tid < kWin) cf = __popc(L.mf[tid * 2]) + __popc(L.mf[tid * 2 + 1]);
+      int incl = cf;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      if (tid == 63) L.misc[1] = (uint32_t)incl;
+      lds_barrier();
+      if (tid < kWin) {
+        const int add = wave == 1 ? rfl((int)L.misc[1]) : 0;
+        L.off[tid] = (uint16_t)(incl - cf + add);
+        if (tid == kWin - 1) L.off[kWin] = (uint16_t)(incl + add);
+      }
+      lds_barrier();
+    }
+    if (tid == 0) hits_done += (unsigned long long)L.off[kWin];
+    BT(1);
+
+    // ---- rounds: consecutive frames whose hits fit the record arrays
+    int f0 = 0;
+    while (f0 < F) {
+      const int base = rfl((int)L.off[f0]);
+      int f1 = F;
+      if (rfl((int)L.off[F]) - base > kHC) {
+        int lo = f0 + 1, hi = F;  // a single frame has at most kBV <= kHC hits
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (rfl((int)L.off[mid]) - base <= kHC) lo = mid; else hi = mid - 1;
+        }
+        f1 = lo;
+      }
+      const int nh = rfl((int)L.off[f1]) - base;
+      if (nh == 0) break;  // only when nothing is left
+      // ---- the voxels' hits of this round: rows, record slots
+      uint32_t rm[kMaskWords];
+      int k_v = 0;
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) {
+        const int lo_b = f0 - 32 * w, hi_b = f1 - 32 * w;  // bits [lo_b, hi_b) of word w
+        const uint32_t m_lo = lo_b <= 0 ? 0xffffffffu : (lo_b >= 32 ? 0u : ~((1u << lo_b) - 1u));
+        const uint32_t m_hi = hi_b <= 0 ? 0u : (hi_b >= 32 ? 0xffffffffu : ((1u << hi_b) - 1u));
+        rm[w] = mk[w] & m_lo & m_hi;
+        k_v += __popc(rm[w]);
+      }
+      const bool touched = k_v > 0;
+      const unsigned long long bal = __ballot(touched);
+      if (wave == 0) {
+        int km = k_v;  // the most hits any row takes in this round (bounds the fixed-point sums)
+        for (int o = 32; o > 0; o >>= 1) km = max(km, __shfl_xor(km, o));
+        if (lane == 0) { L.misc[2] = (uint32_t)__popcll(bal); L.misc[8] = (uint32_t)km; }
+        const int row = __popcll(bal & lt_mask);
+        if (touched) {
+          L.vrow[tid] = (uint8_t)row;
+          L.rown[row] = n;
+          L.rowfresh[row] = w_cur == 0 ? 1 : 0;  // never written: all zeros by construction, not read
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) {
+            uint32_t mm = rm[w];
+            while (mm) {
+              const int f = __ffs((int)mm) - 1 + 32 * w;
+              mm &= mm - 1u;
+              const int slot = (int)L.off[f] - base + rank_in_frame(&L.mf[f * 2], tid);
+              L.rec_k[slot] = (uint32_t)tid | ((uint32_t)f << 8);
+            }
+          }
+        }
+      }
+      lds_barrier();
+      const int R = rfl((int)L.misc[2]);
+      const int k_max = rfl((int)L.misc[8]);
+      const int kexp = k_max <= 1 ? 0 : 32 - __builtin_clz((unsigned)(k_max - 1));  // ceil(log2 k_max)
+      BT(2);
+
+      if (wave < kWalkers) {
+        // ---- walkers: per hit: projection, map cell, bilinear fractions, the frame's rgb sample and label count
+        //      (clipfusion.py:647-659, :701-713; clip_seem_fusion.py:786-822)
+        float* stage = reinterpret_cast<float*>(L.acc);
+        for (int j = tid; j < nh; j += kHitThreads) {
+          const uint32_t vf = L.rec_k[j];
+          const int tv = (int)(vf & 127u), f = (int)(vf >> 8);
+          const int hx = bx * kBX + ((tv >> 4) & 3), hy = by * kBY + ((tv >> 2) & 3), hz = bz * kBZ + (tv & 3);
+          const uint32_t hn = ((uint32_t)hx * (uint32_t)v.ny + (uint32_t)hy) * (uint32_t)v.nz + (uint32_t)hz;
+          const Cam cam = cam_from(cams + f * kCamFloats, ucam);
+          const Proj p = project(cam, v.ax[hx], v.ay[hy], v.az[hz]);
+          const Bilin bw = bilinear_setup(p.gx, p.gy, half_px, half_py);
+          // the fractions bilinear_setup built its weights from (nw = (1 - wy)(1 - wx), ...), recomputed the same way
+          const float ux = unnormalize(p.gx, half_px), uy = unnormalize(p.gy, half_py);
+          const float wx = ux - __builtin_floorf(ux), wy = uy - __builtin_floorf(uy);
+          const int cx = min(max(bw.x0, -2), wa.npx) + 2, cy = min(max(bw.y0, -2), wa.npy) + 2;
+          L.rec_g[j] = make_float2(wx, wy);
+          L.rec_k[j] = (uint32_t)L.vrow[tv] | ((uint32_t)cx << 7) | ((uint32_t)cy << 15) | ((uint32_t)f << 23);
+          kf.rgb = tab->rgb[f];
+          kf.label_map = tab->label_map[f];
+          float s0, s1, s2;
+          const int pix = sample_rgb_lane(kf, cam, p.gx, p.gy, s0, s1, s2);
+          stage[j * 3] = s0;
+          stage[j * 3 + 1] = s1;
+          stage[j * 3 + 2] = s2;
+          count_label_lane<true>(v, kf, hn, pix, stats);
+        }
+      }
+      lds_barrier();
+      BT(3);
+      // ---- per voxel, in frame order: the rgb running mean and the weight, exactly as frame after frame
+      //      (clipfusion.py:715-721); the row's coefficients for the folded update of the feature row
+      if (wave == 0 && touched) {
+        const float* stage = reinterpret_cast<const float*>(L.acc);
+        const int row = (int)L.vrow[tid];
+        int r = 0;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) {
+          uint32_t mm = rm[w];
+          while (mm) {
+            const int f = __ffs((int)mm) - 1 + 32 * w;
+            mm &= mm - 1u;
+            const int slot = (int)L.off[f] - base + rank_in_frame(&L.mf[f * 2], tid);
+            const int wi = w_cur + r;
+            const float a = 1.0f / (float)(wi + 1), b = (float)wi * a;
+            o0 = blend(stage[slot * 3], o0, a, b, SUM);
+            o1 = blend(stage[slot * 3 + 1], o1, a, b, SUM);
+            o2 = blend(stage[slot * 3 + 2], o2, a, b, SUM);
+            ++r;
+          }
+        }
+        const float a = SUM ? 1.0f : 1.0f / (float)(w_cur + k_v);
+        L.rowA[row] = a;
+        L.rowB[row] = SUM ? 1.0f : (float)w_cur * a;
+        w_cur += k_v;
+      }
+      lds_barrier();
+      BT(4);
+      // ---- everybody clears the accumulator (the staging is done with); the walkers sort their window of 64 hits by
+      //      (frame, cell): a group = a run of hits that blend the same four map rows
+      {
+        int4* acc4 = reinterpret_cast<int4*>(L.acc);
+        for (int i = tid; i < R * (kSlabCh / 4); i += kBThreads) acc4[i] = make_int4(0, 0, 0, 0);
+      }
+      if (wave < kWalkers) {
+        for (int win = wave; win < kWindows; win += kWalkers) {
+          const int wb = win * 64, cnt = min(64, nh - wb);  // (cnt <= 0: no such window)
+          const bool hv = lane < cnt;
+          const uint32_t key = hv ? L.rec_k[wb + lane] : 0xffffffffu;
+          const float2 g = L.rec_g[wb + lane];
+          const uint32_t sk = key >> 7;
+          int rank = 0;
+          if (cnt > 0) {
+            for (int j = 0; j < 64; ++j) {
+              const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)sk, j);
+              rank += (kj < sk || (kj == sk && j < lane)) ? 1 : 0;
+            }
+          }
+          wave_lds_sync();
+          if (hv) {
+            L.rec_k[wb + rank] = key;
+            L.rec_g[wb + rank] = g;
+          }
+          wave_lds_sync();
+          const uint32_t skey = hv ? L.rec_k[wb + lane] : 0xffffffffu;
+          const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
+          const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
+          if (lane == 0) L.misc[16 + win] = (uint32_t)__popcll(heads);
+        }
+      }
+      lds_barrier();
+      // ---- the table of groups: first hit, and the four map rows as byte offsets into the window's images; a tap outside
+      //      the map (zeros padding) gets an offset beyond the buffer: the range check returns zero and moves nothing
+      const int g_w0 = rfl((int)L.misc[16]), g_w1 = rfl((int)L.misc[17]), g_w2 = rfl((int)L.misc[18]), g_w3 = rfl((int)L.misc[19]);
+      const int G = g_w0 + g_w1 + g_w2 + g_w3;
+      if (wave < kWalkers) {
+        for (int win = wave; win < kWindows; win += kWalkers) {
+          const int wb = win * 64, cnt = min(64, nh - wb);
+          const bool hv = lane < cnt;
+          const uint32_t skey = hv ? L.rec_k[wb + lane] : 0xffffffffu;
+          const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
+          const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
+          const int gbase = win == 0 ? 0 : (win == 1 ? g_w0 : (win == 2 ? g_w0 + g_w1 : g_w0 + g_w1 + g_w2));
+          if ((heads >> lane) & 1ull) {
+            const int gi = gbase + __popcll(heads & lt_mask);
+            const int fb = (int)(skey >> 23), x0 = (int)((skey >> 7) & 255u) - 2, y0 = (int)((skey >> 15) & 255u) - 2;
+            const bool x0ok = x0 >= 0 && x0 < wa.npx, x1ok = x0 + 1 >= 0 && x0 + 1 < wa.npx;
+            const bool y0ok = y0 >= 0 && y0 < wa.npy, y1ok = y0 + 1 >= 0 && y0 + 1 < wa.npy;
+            const uint32_t ib = (uint32_t)fb * img_bytes;
+            uint4 o;
+            o.x = (x0ok && y0ok) ? ib + (uint32_t)(y0 * wa.npx + x0) * row_bytes : kTapOutside;
+            o.y = (x1ok && y0ok) ? ib + (uint32_t)(y0 * wa.npx + x0 + 1) * row_bytes : kTapOutside;
+            o.z = (x0ok && y1ok) ? ib + (uint32_t)((y0 + 1) * wa.npx + x0) * row_bytes : kTapOutside;
+            o.w = (x1ok && y1ok) ? ib + (uint32_t)((y0 + 1) * wa.npx + x0 + 1) * row_bytes : kTapOutside;
+            L.grp_off[gi] = o;
+            L.grp_start[gi] = (uint16_t)(wb + lane);
+          }
+        }
+        if (tid == 0) {
+          L.grp_off[G] = make_uint4(kTapOutside, kTapOutside, kTapOutside, kTapOutside);
+          L.grp_start[G] = (uint16_t)nh;
+        }
+      }
+      lds_barrier();
+      BT(5);
+
+      // ---- slabs of 64 CPL channels.  The two roles run different code between the same barriers (their registers --
+      //      the movers' row pieces, the walkers' two tap batches -- are never live together).
+      if (wave >= kWalkers) {
+        // A mover's 16-byte piece: PPR pieces per row slab, RPI rows per iteration, the movers take rows alternately.
+        constexpr int kEB = BF16 ? 2 : 4;                 // bytes per stored channel
+        constexpr int kPPR = kSlabCh * kEB / 16;          // pieces per row slab (4 .. 64)
+        constexpr int kRPI = 64 / kPPR;                   // rows per iteration and mover (1 .. 16)
+        constexpr int kMI = ((kBV + kMovers - 1) / kMovers + kRPI - 1) / kRPI;  // iterations
+        constexpr int kCPP = 16 / kEB;                    // channels per piece
+        const int row_vecs = v.D * kEB / 16;              // 16-byte units of a row
+        float4 old[kMI];
+        // (opaque to the optimiser: the iterations' row numbers, LDS offsets and row pointers would otherwise be computed once
+        //  at the top of the kernel and kept -- a hundred spilled registers)
+        int m_sub = lane / kPPR, m_pc = lane % kPPR;
+        asm volatile("" : "+v"(m_sub), "+v"(m_pc));
+        // the first slab's old pieces: they arrive during the first walk
+#pragma unroll
+        for (int i = 0; i < kMI; ++i) {
+          const int mr = (i * kRPI + m_sub) * kMovers + (wave - kWalkers);
+          old[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i * kRPI * kMovers < R && mr < R && !L.rowfresh[mr]) old[i] = ld_stream(feat + (int64_t)L.rown[mr] * row_vecs + m_pc);
+        }
+        int* acc = L.acc;
+        for (int p = 0; p < n_pass; ++p) {
+          lds_barrier();  // the walkers have added this slab's samples
+          BT(6);
+          asm volatile("" : "+v"(m_sub), "+v"(m_pc));
+          const float inv = fx ? pow2f(-scale_exp(slab_max_bits<CPL>(cmax, v.D, p), kexp)) : 1.0f;
+          // new = old * b + acc * a.  The old pieces were requested a whole walk ago: one explicit wait (the BUILTIN, which
+          // the wait-count pass sees) -- left to itself the pass puts a vmcnt(0) into every conditional iteration, where it
+          // waits for the store of the iteration before: a memory round trip per iteration
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+          for (int i = 0; i < kMI; ++i) {
+            const int mr = (i * kRPI + m_sub) * kMovers + (wave - kWalkers);
+            if (i * kRPI * kMovers < R && mr < R) {
+              const float a = L.rowA[mr], b = L.rowB[mr];
+              // channel ch of the slab lives in lane ch / CPL, slot ch % CPL of the walkers' layout
+              float sm[kCPP];
+#pragma unroll
+              for (int j = 0; j < kCPP; ++j) {
+                const int ch = m_pc * kCPP + j;
+                int* ap = &acc[mr * kSlabCh + (ch % CPL) * 64 + ch / CPL];
+                const int raw = *ap;
+                *ap = 0;
+                sm[j] = (fx ? (float)raw * inv : __builtin_bit_cast(float, raw)) * a;
+              }
+              float4* gp = feat + (int64_t)L.rown[mr] * row_vecs + (int64_t)p * kPPR + m_pc;
+              float4 o;
+              if constexpr (BF16) {
+                const uint32_t ox = __builtin_bit_cast(uint32_t, old[i].x), oy = __builtin_bit_cast(uint32_t, old[i].y);
+                const uint32_t oz = __builtin_bit_cast(uint32_t, old[i].z), ow = __builtin_bit_cast(uint32_t, old[i].w);
+                o.x = __builtin_bit_cast(float, pack_bf16(bf16_lo(ox) * b + sm[0], bf16_hi(ox) * b + sm[1]));
+                o.y = __builtin_bit_cast(float, pack_bf16(bf16_lo(oy) * b + sm[2], bf16_hi(oy) * b + sm[3]));
+                o.z = __builtin_bit_cast(float, pack_bf16(bf16_lo(oz) * b + sm[4], bf16_hi(oz) * b + sm[5]));
+                o.w = __builtin_bit_cast(float, pack_bf16(bf16_lo(ow) * b + sm[6], bf16_hi(ow) * b + sm[7]));
+              } else {
+                o.x = old[i].x * b + sm[0]; o.y = old[i].y * b + sm[1];
+                o.z = old[i].z * b + sm[2]; o.w = old[i].w * b + sm[3];
+              }
+              st_stream(gp, o);
+            }
+          }
+          // (a loop of its own: behind each store, a load would make the wait-count pass drain the queue in every
+          //  iteration; here the first use of `old` in the next slab finds them all arrived)
+          if (p + 1 < n_pass) {
+#pragma unroll
+            for (int i = 0; i < kMI; ++i) {
+              const int mr = (i * kRPI + m_sub) * kMovers + (wave - kWalkers);
+              if (i * kRPI * kMovers < R && mr < R && !L.rowfresh[mr])
+                old[i] = ld_stream(feat + (int64_t)L.rown[mr] * row_vecs + (int64_t)(p + 1) * kPPR + m_pc);
+            }
+          }
+          BT(7);
+          lds_barrier();  // the accumulator is clear again
+          BT(8);
+        }
+      } else {
+        WalkCtx wc;
+        wc.maps = maps_rsrc; wc.G = G; wc.lane = lane;
+        for (int p = 0; p < n_pass; ++p) {
+          wc.lane_off = (uint32_t)p * (kSlabCh * 4u) + (uint32_t)lane * (4u * CPL);
+          if (fx)
+            walk_slab<CPL, true>(L, wc, wave, pow2f(scale_exp(slab_max_bits<CPL>(cmax, v.D, p), kexp)));
+          else
+            walk_slab<CPL, false>(L, wc, wave, 1.0f);
+          BT(6);
+          lds_barrier();  // this slab's samples are in the accumulator
+          BT(7);
+          lds_barrier();  // the movers have written the slab and cleared the accumulator
+          BT(8);
+        }
+      }
+      if (f1 < F) {
+        // Another round follows: its rows may be read by a different mover than the one that has just written them, and
+        // nothing orders two waves' accesses to one address -- every mover's stores are in L2 before anybody goes on
+        // (the loads are nontemporal: served by L2, never by the CU's L1).
+        if (wave >= kWalkers) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        lds_barrier();
+      }
+      f0 = f1;
+    }
+    if (any) {
+      float* dst = v.rgb + (int64_t)n * 3;
+      dst[0] = o0; dst[1] = o1; dst[2] = o2;
+      v.weight[n] = w_cur;
+    }
+    BT(9);
+  }
+  BT(10);
+  BT_FLUSH;
+  if (stats) {
+    for (int o = 32; o > 0; o >>= 1) rows_done += __shfl_xor(rows_done, o);
+    if (lane == 0 && rows_done) atomicAdd(&stats[5], rows_done);  // rows read-modify-written by this window
+    if (tid == 0 && hits_done) atomicAdd(&stats[0], hits_done);
+  }
+}
+
+using BrickFn = void (*)(KVol, WinArgs, const WinTable*, const float*, uint32_t, unsigned long long*, unsigned int*,
+                         const uint32_t*, uint32_t, const unsigned long long*, const uint32_t*, const float*);
+
+// cmax[c] = bits of the largest |x| of channel c over the window's pixel-major map images, cmax[D + c / 64] = of every
+// group of 64 channels, cmax[D + D / 64] = of all channels (non-negative floats order like their bit patterns; NaN > inf >
+// every finite value)
+__global__ __launch_bounds__(256) void chan_max_kernel(const float* __restrict__ imgs, int img_floats, int D, int P, int F,
+                                                       uint32_t* __restrict__ cmax) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  uint32_t m = 0u;
+  if (c < D) {
+    const int f1 = min(F, (int)(blockIdx.y + 1) * 8);
+    for (int f = blockIdx.y * 8; f < f1; ++f)
+      for (int p = 0; p < P; ++p) m = max(m, __builtin_bit_cast(uint32_t, imgs[(size_t)f * img_floats + (size_t)p * D + c]) & 0x7fffffffu);
+    if (m) atomicMax(&cmax[c], m);
+  }
+  uint32_t w = m;
+  for (int o = 32; o > 0; o >>= 1) w = max(w, (uint32_t)__shfl_xor((int)w, o));
+  if ((threadIdx.x & 63) == 0 && w && c < D) {  // (D is a multiple of 64: a wave is one group)
+    atomicMax(&cmax[D + c / 64], w);
+    atomicMax(&cmax[D + D / 64], w);
+  }
+}
+
+// the per-frame part of the window's cameras: pose[:3, :4] and K, 21 floats per frame
+__global__ __launch_bounds__(128) void cam_table_kernel(const WinTable* __restrict__ tab, int F, float* __restrict__ cams) {
+  const int f = threadIdx.x;
+  if (f >= F) return;
+  const float* __restrict__ pose = tab->pose[f];
+  const float* __restrict__ K = tab->K[f];
+  float* o = cams + f * kCamFloats;
+  for (int i = 0; i < 12; ++i) o[i] = pose[i];
+  for (int i = 0; i < 9; ++i) o[12 + i] = K[i];
+}
+
+size_t cmax_words(int D) { return (size_t)D + (size_t)D / 64 + 1; }
+size_t cmax_bytes(int D) { return (cmax_words(D) * sizeof(uint32_t) + 255) & ~(size_t)255; }
+
+template <int CPL>
+BrickFn pick_brick(bool sum, bool bf16) {
+  if (bf16) return sum ? fuse_brick_kernel<CPL, true, true> : fuse_brick_kernel<CPL, false, true>;
+  return sum ? fuse_brick_kernel<CPL, true, false> : fuse_brick_kernel<CPL, false, false>;
+}
+
+}  // namespace
+
+// The brick form takes every grid shape (partial bricks are masked) and every feat_dim that is a multiple of 64;
+// SAF_WIN_FORM=rows (read per call) keeps the frame-ordered row kernel.
+bool brick_form_ok(const KVol& kv) {
+  const char* e = getenv("SAF_WIN_FORM");
+  if (e && e[0] == 'r') return false;
+  if (kv.D % 64 != 0 || kv.D > 8192) return false;
+  const uint32_t nbx = ((uint32_t)kv.nx + kBX - 1) / kBX, nby = ((uint32_t)kv.ny + kBY - 1) / kBY, nbz = ((uint32_t)kv.nz + kBZ - 1) / kBZ;
+  return nbx < 1024u && nby < 1024u && nbz < 1024u;  // the brick code of a workgroup is three 10-bit fields
+}
+
+size_t brick_aux_bytes(int D) { return cmax_bytes(D) + (((size_t)kWin * kCamFloats * sizeof(float) + 255) & ~(size_t)255); }
+
+int launch_fuse_bricks(const KVol& kv, const WinArgs& wa, const WinTable* tab, const float* map_imgs, size_t img_bytes,
+                       unsigned long long* stats, unsigned int* ctr, const uint32_t* hitmask, uint32_t mask_plane,
+                       const unsigned long long* cls_acc, void* aux, hipStream_t s) {
+  uint32_t* cmax = static_cast<uint32_t*>(aux);
+  float* cams = reinterpret_cast<float*>(static_cast<unsigned char*>(aux) + cmax_bytes(kv.D));
+  // the channels' largest magnitudes over this window's maps (the scales of the fixed-point sums) and the cameras
+  if (hipMemsetAsync(cmax, 0, cmax_bytes(kv.D), s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(channel maxima)");
+  hipLaunchKernelGGL(chan_max_kernel, dim3((kv.D + 255) / 256, (wa.F + 7) / 8), dim3(256), 0, s, map_imgs,
+                     (int)(img_bytes / sizeof(float)), kv.D, wa.npy * wa.npx, wa.F, cmax);
+  hipLaunchKernelGGL(cam_table_kernel, dim3(1), dim3(128), 0, s, tab, wa.F, cams);
+  const bool sum = kv.accum == SAF_SUM, bf16 = kv.bf16 != 0;
+  BrickFn fn;
+  size_t lds;
+  if (kv.D % 256 == 0) {
+    fn = pick_brick<4>(sum, bf16); lds = sizeof(BrickLds<4>);
+  } else if (kv.D % 128 == 0) {
+    fn = pick_brick<2>(sum, bf16); lds = sizeof(BrickLds<2>);
+  } else {
+    fn = pick_brick<1>(sum, bf16); lds = sizeof(BrickLds<1>);
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
+  const int wgs_env = getenv("SAF_BRICK_WGS") ? atoi(getenv("SAF_BRICK_WGS")) : 0;
+  const uint32_t grid = (uint32_t)device_cus() * (uint32_t)(wgs_env > 0 ? wgs_env : 2);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBThreads), lds, s, kv, wa, tab, map_imgs, (uint32_t)img_bytes, stats, ctr, hitmask,
+                     mask_plane, cls_acc, cmax, cams);
+#ifdef SAF_BRICK_TIMING
+  {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), kBThreads, lds);
+    fprintf(stderr, "[brick timing] occupancy: %d workgroups of %d threads per CU (LDS %zu bytes each)\n", nb, kBThreads, lds);
+    (void)hipStreamSynchronize(s);
+    unsigned long long t[32];
+    if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_brick_t), sizeof(t)) == hipSuccess) {
+      const char* names[11] = {"fetch+masks", "bit matrix+prefix", "rows+scatter", "hit records|prefetch", "scalar side", "sort+table",
+                               "walk|wait walk", "wait|combine", "wait combine|wait", "tail", "end"};
+      for (int role = 0; role < 2; ++role) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 11; ++k) tot += t[role * 16 + k];
+        fprintf(stderr, "[brick timing] %s:", role ? "movers " : "walkers");
+        for (int k = 0; k < 11; ++k) fprintf(stderr, " %s %.1f%%", names[k], 100.0 * t[role * 16 + k] / (double)(tot ? tot : 1));
+        fprintf(stderr, " (total %.3g wave-cycles)\n", (double)tot);
+      }
+      memset(t, 0, sizeof(t));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_brick_t), t, sizeof(t));
+    }
+  }
+#endif
+  return check_launch("fuse_brick_kernel");
+}
+
+}  // namespace saf

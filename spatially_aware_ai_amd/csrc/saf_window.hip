@@ -4,20 +4,15 @@
 // saf_fuse.hip; selected by saf_fuse_frames for calls of 16 or more frames of one shape.
 #include <chrono>
 
-#include "saf_fuse_dev.h"
+#include "saf_window_dev.h"
 
 namespace saf {
 namespace {
 
-constexpr size_t kHdrBytes = 8192;   // one workspace header (unit counters, dmax, counter shards, the window's frame table)
-constexpr size_t kHdrTotal = 2 * kHdrBytes;  // two of them, and two mask buffers: window w + 1 is classified while window w's rows are fused
 
 // Pixel-major image for the windowed path, whose taps are read from global memory (L2): row p holds
 // the D channels of map position p contiguously (a wave's tap load is one contiguous D*4 bytes), row P
 // is the zero row of the taps outside the map.
-struct WinTable;
-__global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restrict__ tab, float* __restrict__ imgs,
-                                                        int img_floats, int D, int P);
 
 // ------------------------------------------------------------------------------------------
 // fuse, voxel-major over a WINDOW of up to 64 frames (saf_fuse_frames with many frames).
@@ -42,10 +37,6 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restri
 //   which are loaded from the window's map images (L2) ONCE per group, P groups in flight -- each hit
 //   updates its row in LDS, and the rows are streamed back.
 // ------------------------------------------------------------------------------------------
-constexpr int kWin = SAF_WINDOW_FRAMES;  // frames of the longest window: four 32-bit mask words per voxel
-static_assert(kWin == 128, "the mask layout and the 7-bit frame field assume windows of up to 128 frames");
-constexpr int kMaskWords = kWin / 32;
-constexpr int kClsFrames = 32;  // frames of one classification launch = one mask plane
 constexpr int kWinMinFrames = 16;  // shorter calls run the per-frame pipeline
 #ifndef SAF_WIN_HITCAP
 #define SAF_WIN_HITCAP 128
@@ -69,18 +60,6 @@ struct ClsArgs {
   const float* label_map[kClsFrames];
   const float* feat_map[kClsFrames];
 };
-struct WinTable {
-  const float* rgb[kWin];
-  const float* pose[kWin];
-  const float* K[kWin];
-  const float* label_map[kWin];
-  const float* feat_map[kWin];
-};
-struct WinArgs {  // what is common to a window's frames
-  int F, H, W, npy, npx, rgb_bilinear;
-};
-constexpr size_t kTableOff = 2048;  // WinTable in the workspace header
-static_assert(kTableOff + sizeof(WinTable) <= kHdrBytes, "workspace header layout");
 
 __device__ __forceinline__ void file_frames(const ClsArgs& ca, WinTable* __restrict__ tab, int tid) {
   if (tab && blockIdx.x == 0 && tid < ca.n) {
@@ -102,12 +81,6 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restri
   imgs[(size_t)blockIdx.y * img_floats + o] = p < P ? feat_map[(size_t)c * P + p] : 0.0f;
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
-  // LDS operations of one wave execute in order; this only stops the compiler from moving them
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 #ifdef SAF_WIN_TIMING  // development aid: per-phase wave cycles of the window kernel, printed by the host
 __device__ unsigned long long g_win_t[16];
@@ -287,8 +260,6 @@ __device__ __forceinline__ void classify_piece(const KVol& v, const ClsArgs& wa,
 // two addresses per launch -- they serialise in L2 and took 0.7 ms of a 1.8 ms kernel.  The four waves of a
 // workgroup are summed in LDS and added to one of 64 shards in the workspace header; the window's row kernel
 // folds the shards into stats[].
-constexpr int kClsShards = 64;
-constexpr size_t kClsAccOff = 1024;  // 64 x {tsdf updates, tsdf voxels} u64 in the workspace header
 __device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsigned long long tsdf_rows_done, int lane, int wave,
                                                unsigned long long (&s_acc)[4][2], unsigned long long* __restrict__ cls_acc) {
   for (int o = 32; o > 0; o >>= 1) {
@@ -485,7 +456,6 @@ struct WinCtx {
   float4* rows;
 };
 typedef unsigned int win_v4u __attribute__((vector_size(16)));
-constexpr uint32_t kTapOutside = 0x80000000u;  // byte offset of a tap outside the map: beyond any buffer
 __device__ __forceinline__ float4 win_tap_load(__amdgpu_buffer_rsrc_t maps, uint32_t byte_off) {
   const win_v4u v = __builtin_amdgcn_raw_buffer_load_b128(maps, (int)byte_off, 0, 0);
   return __builtin_bit_cast(float4, v);
@@ -1069,7 +1039,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
 // window's frame bitmasks (kMaskWords words per voxel).
 // ---------------------------------------------------------------------------------------------
 struct WinLayout {
-  size_t img_bytes, maps_bytes, mask_bytes, total;
+  size_t img_bytes, maps_bytes, mask_bytes, cmax_off, total;
   uint32_t mask_plane;
 };
 WinLayout win_layout(int64_t n_vox, int D, int P) {
@@ -1078,7 +1048,8 @@ WinLayout win_layout(int64_t n_vox, int D, int P) {
   w.maps_bytes = (size_t)kWin * w.img_bytes;
   w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
-  w.total = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;
+  w.cmax_off = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;  // the brick form's channel maxima and camera table
+  w.total = w.cmax_off + brick_aux_bytes(D);
   return w;
 }
 
@@ -1107,12 +1078,14 @@ int window_frames() {
 
 bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
   const bool enabled = !(getenv("SAF_WINDOW") && getenv("SAF_WINDOW")[0] == '0');
-  if (!enabled || n_frames < kWinMinFrames || kv.D % 256 != 0 || kv.D > 1024) return false;
-  // bf16 volumes: the rows are half the bytes, the map taps are not, so the gain is smaller than for f32
-  // (4253 vs 3916 frames/s, 3935 vs 3586 with labels, 4544 vs 3976 on the coherent scene);
-  // SAF_WINDOW_BF16=0 keeps them on the per-frame pipeline
+  if (!enabled || n_frames < kWinMinFrames) return false;
+  // SAF_WINDOW_BF16=0 keeps bf16 volumes on the per-frame pipeline
   const bool bf16_on = !(getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '0');
-  if (kv.bf16 && (!bf16_on || kv.D % 512 != 0)) return false;  // a lane moves 8 bf16 channels: 512 per wave
+  if (kv.bf16 && !bf16_on) return false;
+  if (!brick_form_ok(kv)) {  // the frame-ordered row kernel: whole 1 KiB pieces of a row per wave instruction
+    if (kv.D % 256 != 0 || kv.D > 1024) return false;
+    if (kv.bf16 && kv.D % 512 != 0) return false;  // a lane moves 8 bf16 channels: 512 per wave
+  }
   const saf_frame& f0 = frames[0];
   for (int32_t i = 0; i < n_frames; ++i) {
     const saf_frame& f = frames[i];
@@ -1141,15 +1114,16 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const bool sum = kv.accum == SAF_SUM;
   const int img_vecs = (int)(wl.img_bytes / sizeof(float4));
   const int prep_blocks = (kv.D * (P + 1) + 255) / 256;
-  WinFn fn;
-  size_t win_lds;
-  switch (kv.D / 256) {
+  const bool brick_form = brick_form_ok(kv);
+  WinFn fn = nullptr;
+  size_t win_lds = 0;
+  if (!brick_form) switch (kv.D / 256) {
     case 1: fn = pick_win<1>(sum, kv.bf16 != 0); win_lds = WinCfg<1>::total; break;
     case 2: fn = pick_win<2>(sum, kv.bf16 != 0); win_lds = WinCfg<2>::total; break;
     case 3: fn = pick_win<3>(sum, kv.bf16 != 0); win_lds = WinCfg<3>::total; break;
     default: fn = pick_win<4>(sum, kv.bf16 != 0); win_lds = WinCfg<4>::total; break;
   }
-  {
+  if (!brick_form) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)win_lds);
     if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", win_lds, hipGetErrorString(e));
@@ -1266,13 +1240,20 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
                          (int)(wl.img_bytes / sizeof(float)), kv.D, P);
     }
     if ((rc = check_launch("prep_rows_kernel"))) break;
-    {
+    if (brick_form) {
+      ScopedPair t(prof, 2, f0, s);
+      rc = launch_fuse_bricks(kv, wa, tab, maps, wl.img_bytes, reinterpret_cast<unsigned long long*>(stats),
+                              reinterpret_cast<unsigned int*>(hdr), masks, wl.mask_plane,
+                              reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff),
+                              ws + wl.cmax_off, s);
+    } else {
       ScopedPair t(prof, 2, f0, s);
       hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, tab, maps, img_vecs,
                          reinterpret_cast<unsigned long long*>(stats), reinterpret_cast<unsigned int*>(hdr), masks, wl.mask_plane,
                          reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff), xcd_order);
+      rc = check_launch("fuse_window_kernel");
     }
-    if ((rc = check_launch("fuse_window_kernel"))) break;
+    if (rc) break;
     mark("rows: queued", w);
     if (ov && hipEventRecord(ov->fuse_done[par], s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord"); break; }
     if (!ov && w + 1 < n_win) rc = classify(w + 1);

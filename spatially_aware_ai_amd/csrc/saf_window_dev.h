@@ -1,0 +1,54 @@
+// saf_window_dev.h -- what the two row kernels of the windowed path (saf_window.hip: frame-ordered rows; saf_brick.hip:
+// brick-resident rows with shared map taps) and the host side of saf_window.hip share: the workspace header layout,
+// the window's frame table, and the launcher of the brick form.
+#pragma once
+#include "saf_fuse_dev.h"
+
+namespace saf {
+
+constexpr size_t kHdrBytes = 8192;   // one workspace header (unit counters, dmax, counter shards, the window's frame table)
+constexpr size_t kHdrTotal = 2 * kHdrBytes;  // two of them, and two mask buffers: window w + 1 is classified while window w's rows are fused
+
+constexpr int kWin = SAF_WINDOW_FRAMES;  // frames of the longest window: four 32-bit mask words per voxel
+static_assert(kWin == 128, "the mask layout and the 7-bit frame field assume windows of up to 128 frames");
+constexpr int kMaskWords = kWin / 32;
+constexpr int kClsFrames = 32;  // frames of one classification launch = one mask plane
+
+struct WinTable {
+  const float* rgb[kWin];
+  const float* pose[kWin];
+  const float* K[kWin];
+  const float* label_map[kWin];
+  const float* feat_map[kWin];
+};
+struct WinArgs {  // what is common to a window's frames
+  int F, H, W, npy, npx, rgb_bilinear;
+};
+constexpr size_t kTableOff = 2048;  // WinTable in the workspace header
+static_assert(kTableOff + sizeof(WinTable) <= kHdrBytes, "workspace header layout");
+
+// Counters of a classification launch, sharded in the workspace header (see cls_accumulate in saf_window.hip); the
+// window's row kernel folds the shards into stats[].
+constexpr int kClsShards = 64;
+constexpr size_t kClsAccOff = 1024;  // 64 x {tsdf updates, tsdf voxels} u64 in the workspace header
+
+constexpr uint32_t kTapOutside = 0x80000000u;  // byte offset of a tap outside the map: beyond any buffer
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving them
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The brick form of the window's row kernel (saf_brick.hip).  `ctr`: the header's unit counters (8 words, zeroed),
+// `map_imgs`: the window's pixel-major map images (img_bytes each), `hitmask`: the window's mask planes.
+// `aux`: brick_aux_bytes(D) of workspace (the channels' largest magnitudes and the window's camera table, filled by the
+// launcher on `s`).
+bool brick_form_ok(const KVol& kv);
+size_t brick_aux_bytes(int D);
+int launch_fuse_bricks(const KVol& kv, const WinArgs& wa, const WinTable* tab, const float* map_imgs, size_t img_bytes,
+                       unsigned long long* stats, unsigned int* ctr, const uint32_t* hitmask, uint32_t mask_plane,
+                       const unsigned long long* cls_acc, void* aux, hipStream_t s);
+
+}  // namespace saf
