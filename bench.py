@@ -244,16 +244,19 @@ def main():
                                         stats_ptr, profiler, stream)
         check(rc, "saf_fuse_frames_profiled")
 
-    def merge(fz):
-        try:
-            return sdist.merge_volumes(fz, mode=merge_state["mode"])
-        except Exception as e:  # e.g. a backend without (in-place) reduce-scatter: fall back, say so on the line
-            if merge_state["mode"] == "all_reduce":
-                raise
-            merge_state["fallback"] = f"{type(e).__name__}: {e}"[:200]
+    if world > 1 and merge_state["mode"] == "reduce_scatter":
+        # the collectives of the merge are tried on a small tensor FIRST: a collective that raised in the middle of a
+        # volume could not be followed by another one (rows already summed would be summed twice), so the real merge is
+        # never retried
+        why = sdist.probe_collectives(device)
+        flag = torch.tensor([0 if why is None else 1], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            merge_state["fallback"] = why or "another rank's probe failed"
             merge_state["mode"] = "all_reduce"
-            fz.accum_mode, fz._shard_range = _abi.SAF_SUM, None
-            return sdist.merge_volumes(fz, mode="all_reduce")
+
+    def merge(fz):
+        return sdist.merge_volumes(fz, mode=merge_state["mode"])
 
     def barrier():
         if world > 1:

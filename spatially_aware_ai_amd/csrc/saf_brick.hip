@@ -35,6 +35,8 @@
 // the walkers' adds arrive and is reproducible bit for bit.  A window whose maps hold a non-finite value (no number to
 // scale by) takes float atomics instead: slow, NaN / inf propagate as in the reference.  SAF_WIN_FORM=rows selects the
 // frame-ordered kernel (bit-identical to fusing frame after frame).
+#include <type_traits>
+
 #include "saf_window_dev.h"
 
 namespace saf {
@@ -86,6 +88,40 @@ struct alignas(16) BrickLds {
   uint32_t rown[kBV];            // flat voxel index of a row
   uint32_t misc[32];
 };
+// The build kernel's LDS: everything but the accumulator (the rgb staging gets an array of its own).
+struct alignas(16) BuildLds {
+  float stage[kHC * 3];
+  uint4 grp_off[kHC + 1];
+  float2 rec_g[kHC];
+  uint32_t rec_k[kHC];
+  uint16_t grp_start[kHC + 8];
+  uint32_t mf[kWin * 2];
+  uint16_t off[kWin + 8];
+  uint8_t vrow[kBV];
+  uint8_t rowfresh[kBV];
+  float rowA[kBV], rowB[kBV];
+  uint32_t rown[kBV];
+  uint32_t misc[32];
+};
+
+// A SEGMENT: what the walk needs of one round of one brick, written by the build kernel into a pool in the workspace.
+constexpr uint32_t kSegHdr = 0;        // u32: R, nh, G, kexp
+constexpr uint32_t kSegRown = 64, kSegRowA = kSegRown + kBV * 4, kSegRowB = kSegRowA + kBV * 4, kSegFresh = kSegRowB + kBV * 4;
+constexpr uint32_t kSegRecK = kSegFresh + kBV, kSegRecG = kSegRecK + kHC * 4, kSegGrpStart = kSegRecG + kHC * 8;
+constexpr uint32_t kSegGrpOff = kSegGrpStart + (kHC + 8) * 2;
+constexpr uint32_t kSegBytes = ((kSegGrpOff + (kHC + 1) * 16) + 255u) & ~255u;
+static_assert(kSegGrpOff % 16 == 0 && kSegRecG % 8 == 0, "segment layout");
+// Control words of a window's pool (zeroed by the host before the build kernel)
+struct BrickCtl {
+  uint32_t seg_next;    // segments handed out
+  uint32_t list_n;      // bricks in the list (each: first segment, rounds)
+  uint32_t over_n;      // bricks that found the pool exhausted: the walk kernel builds them itself
+  uint32_t walk_next;   // list entries taken by the walk kernel
+  uint32_t over_next;   // overflow bricks taken
+  uint32_t pad[3];
+  unsigned long long acc[64][2];  // the build workgroups' counters (hits, rows), sharded
+};
+
 static_assert(sizeof(BrickLds<4>) <= 76 * 1024, "two workgroups per CU and room for the classification beside them");
 static_assert(kHC * 3 * sizeof(float) <= sizeof(int) * kBV * 64, "the rgb staging lives in the accumulator");
 
@@ -249,13 +285,28 @@ __device__ __forceinline__ uint32_t slab_max_bits(const uint32_t* __restrict__ c
   return m;
 }
 
-template <int CPL, bool SUM, bool BF16>
-__global__ __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fuse_brick_kernel(
+// What the build and the walk kernel share of the pool
+struct BrickPool {
+  unsigned char* segs;   // cap segments of kSegBytes
+  uint2* list;           // per listed brick: first segment, rounds
+  uint32_t* over;        // brick codes
+  BrickCtl* ctl;
+  uint32_t cap;
+  int split;             // 0: no build kernel ran -- the walk kernel takes every brick from the XCD counters and builds it itself
+};
+
+// One source for both kernels.  BUILD: one workgroup of 4 waves per brick, small LDS, many per CU: the per-brick build
+// (hit records, scalar side, sorted groups), written to the pool as segments.  !BUILD: the persistent walk kernel (4 walker +
+// 4 mover waves): segments from the pool, then the bricks of the overflow list (or, without a build kernel, every brick),
+// which it builds itself.
+template <int CPL, bool SUM, bool BF16, bool BUILD>
+__global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fuse_brick_kernel(
     KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, uint32_t img_bytes,
     unsigned long long* __restrict__ stats, unsigned int* __restrict__ ctr, const uint32_t* __restrict__ hitmask,
     uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc, const uint32_t* __restrict__ cmax,
-    const float* __restrict__ cams) {
-  using Lds = BrickLds<CPL>;
+    const float* __restrict__ cams, BrickPool pool) {
+  using Lds = typename std::conditional<BUILD, BuildLds, BrickLds<CPL>>::type;
+  constexpr int kNT = BUILD ? kHitThreads : kBThreads;
   extern __shared__ __align__(16) unsigned char s_dyn[];
   Lds& L = *reinterpret_cast<Lds*>(s_dyn);
   // (values read from LDS or derived from the thread index are divergent to the compiler: what is wave-uniform is said
@@ -264,15 +315,21 @@ __global__ __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   const int F = wa.F;
   constexpr int kSlabCh = 64 * CPL;
 
-  if (stats && blockIdx.x == 0 && tid < kClsShards) {  // the classification launches' sharded counters (cls_accumulate)
+  if (!BUILD && stats && blockIdx.x == 0 && tid < kClsShards) {  // the classification launches' sharded counters (cls_accumulate)
     unsigned long long a = cls_acc[2 * tid], b = cls_acc[2 * tid + 1];
+    unsigned long long c = 0, d = 0;  // ... and the build kernel's (hits, rows)
+    if (pool.split) { c = pool.ctl->acc[tid][0]; d = pool.ctl->acc[tid][1]; }
     for (int o = 32; o > 0; o >>= 1) {
       a += __shfl_xor(a, o);
       b += __shfl_xor(b, o);
+      c += __shfl_xor(c, o);
+      d += __shfl_xor(d, o);
     }
     if (tid == 0) {
       if (a) atomicAdd(&stats[1], a);
       if (b) atomicAdd(&stats[6], b);
+      if (c) atomicAdd(&stats[0], c);
+      if (d) atomicAdd(&stats[5], d);
     }
   }
   const Cam ucam = load_cam(tab->pose[0], tab->K[0], wa.W, wa.H);  // its image-size terms are the same for every frame
@@ -288,7 +345,7 @@ __global__ __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   unsigned long long hits_done = 0, rows_done = 0;
   // fixed-point accumulation unless a map value of this window is not finite (chan_max_kernel leaves the largest |x| of all
   // channels behind the per-channel and per-64-channel maxima)
-  const bool fx = rfl((int)(cmax[v.D + v.D / 64] < 0x7f800000u)) != 0;
+  const bool fx = BUILD ? true : rfl((int)(cmax[v.D + v.D / 64] < 0x7f800000u)) != 0;
   BT_DECL;
 
   // Bricks are handed out XCD by XCD: workgroup i runs on XCD i % 8 (round-robin dispatch), every XCD draws from its own
@@ -300,275 +357,10 @@ __global__ __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   const uint32_t zsecs = (nbz + 3u) / 4u, upt = zsecs * 64u;
   uint32_t xcd = blockIdx.x & 7u, xcd_tries = 0;
 
-  // voxel of this thread within a brick (wave 0)
-  const int lx = (tid >> 4) & 3, ly = (tid >> 2) & 3, lz = tid & 3;
-  const bool vth = tid < kBV;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-  for (;;) {
-    if (tid == 0) {
-      uint32_t code = 0xffffffffu;
-      while (xcd_tries < 8u) {
-        const uint32_t my_tiles = (n_tiles + 7u - xcd) / 8u;
-        const uint32_t j = atomicAdd(ctr + xcd, 1u);
-        if (j >= my_tiles * upt) {
-          ++xcd_tries;
-          xcd = (xcd + 1u) & 7u;
-          continue;
-        }
-        const uint32_t tl = j / upt, within = j - tl * upt, zs = within >> 6, k = within & 63u;
-        const uint32_t t = tl * 8u + xcd, tx = t / tiles_y, ty = t - tx * tiles_y;
-        const uint32_t bx = tx * 4u + ((k >> 2) & 3u), by = ty * 4u + (k & 3u), bz = zs * 4u + (k >> 4);
-        if (bx >= nbx || by >= nby || bz >= nbz) continue;
-        code = bx | (by << 10) | (bz << 20);
-        break;
-      }
-      L.misc[0] = code;
-    }
-    lds_barrier();
-    const uint32_t code = (uint32_t)rfl((int)L.misc[0]);
-    if (code == 0xffffffffu) break;
-    const int bx = (int)(code & 1023u), by = (int)((code >> 10) & 1023u), bz = (int)(code >> 20);
-    const int ix = bx * kBX + lx, iy = by * kBY + ly, iz = bz * kBZ + lz;
-    const bool inb = vth && ix < v.nx && iy < v.ny && iz < v.nz;
-    const uint32_t n = ((uint32_t)ix * (uint32_t)v.ny + (uint32_t)iy) * (uint32_t)v.nz + (uint32_t)iz;
-    uint32_t mk[kMaskWords];
-#pragma unroll
-    for (int w = 0; w < kMaskWords; ++w) mk[w] = (inb && w * 32 < F) ? hitmask[(size_t)w * mask_plane + n] : 0u;
-    uint32_t any = 0u;
-#pragma unroll
-    for (int w = 0; w < kMaskWords; ++w) any |= mk[w];
-    // (the zeroing of the bit matrix rides on this barrier)
-    if (tid < kWin * 2) L.mf[tid] = 0u;
-    if (wave == 0) {
-      const unsigned long long wany = __ballot(any != 0u);
-      if (lane == 0) L.misc[4] = wany != 0ull ? 1u : 0u;
-    }
-    lds_barrier();
-    BT(0);
-    if (rfl((int)L.misc[4]) == 0) continue;
-    int w_cur = 0;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    if (any) {
-      w_cur = v.weight[n];
-      const float* src = v.rgb + (int64_t)n * 3;
-      o0 = src[0]; o1 = src[1]; o2 = src[2];
-      rows_done += 1ull;
-      // ---- bit matrix frame x voxel
-#pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) {
-        uint32_t mm = mk[w];
-        while (mm) {
-          const int f = __ffs((int)mm) - 1 + 32 * w;
-          mm &= mm - 1u;
-          atomicOr(&L.mf[f * 2 + (tid >> 5)], 1u << (tid & 31));
-        }
-      }
-    }
-    lds_barrier();
-    // ---- hits per frame and their exclusive prefix (frames beyond F have none)
-    {
-      int cf = 0;
-      if (tid < kWin) cf = __popc(L.mf[tid * 2]) + __popc(L.mf[tid * 2 + 1]);
-      int incl = cf;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-      }
-      if (tid == 63) L.misc[1] = (uint32_t)incl;
-      lds_barrier();
-      if (tid < kWin) {
-        const int add = wave == 1 ? rfl((int)L.misc[1]) : 0;
-        L.off[tid] = (uint16_t)(incl - cf + add);
-        if (tid == kWin - 1) L.off[kWin] = (uint16_t)(incl + add);
-      }
-      lds_barrier();
-    }
-    if (tid == 0) hits_done += (unsigned long long)L.off[kWin];
-    BT(1);
-
-    // ---- rounds: consecutive frames whose hits fit the record arrays
-    int f0 = 0;
-    while (f0 < F) {
-      const int base = rfl((int)L.off[f0]);
-      int f1 = F;
-      if (rfl((int)L.off[F]) - base > kHC) {
-        int lo = f0 + 1, hi = F;  // a single frame has at most kBV <= kHC hits
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (rfl((int)L.off[mid]) - base <= kHC) lo = mid; else hi = mid - 1;
-        }
-        f1 = lo;
-      }
-      const int nh = rfl((int)L.off[f1]) - base;
-      if (nh == 0) break;  // only when nothing is left
-      // ---- the voxels' hits of this round: rows, record slots
-      uint32_t rm[kMaskWords];
-      int k_v = 0;
-#pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) {
-        const int lo_b = f0 - 32 * w, hi_b = f1 - 32 * w;  // bits [lo_b, hi_b) of word w
-        const uint32_t m_lo = lo_b <= 0 ? 0xffffffffu : (lo_b >= 32 ? 0u : ~((1u << lo_b) - 1u));
-        const uint32_t m_hi = hi_b <= 0 ? 0u : (hi_b >= 32 ? 0xffffffffu : ((1u << hi_b) - 1u));
-        rm[w] = mk[w] & m_lo & m_hi;
-        k_v += __popc(rm[w]);
-      }
-      const bool touched = k_v > 0;
-      const unsigned long long bal = __ballot(touched);
-      if (wave == 0) {
-        int km = k_v;  // the most hits any row takes in this round (bounds the fixed-point sums)
-        for (int o = 32; o > 0; o >>= 1) km = max(km, __shfl_xor(km, o));
-        if (lane == 0) { L.misc[2] = (uint32_t)__popcll(bal); L.misc[8] = (uint32_t)km; }
-        const int row = __popcll(bal & lt_mask);
-        if (touched) {
-          L.vrow[tid] = (uint8_t)row;
-          L.rown[row] = n;
-          L.rowfresh[row] = w_cur == 0 ? 1 : 0;  // never written: all zeros by construction, not read
-#pragma unroll
-          for (int w = 0; w < kMaskWords; ++w) {
-            uint32_t mm = rm[w];
-            while (mm) {
-              const int f = __ffs((int)mm) - 1 + 32 * w;
-              mm &= mm - 1u;
-              const int slot = (int)L.off[f] - base + rank_in_frame(&L.mf[f * 2], tid);
-              L.rec_k[slot] = (uint32_t)tid | ((uint32_t)f << 8);
-            }
-          }
-        }
-      }
-      lds_barrier();
-      const int R = rfl((int)L.misc[2]);
-      const int k_max = rfl((int)L.misc[8]);
-      const int kexp = k_max <= 1 ? 0 : 32 - __builtin_clz((unsigned)(k_max - 1));  // ceil(log2 k_max)
-      BT(2);
-
-      if (wave < kWalkers) {
-        // ---- walkers: per hit: projection, map cell, bilinear fractions, the frame's rgb sample and label count
-        //      (clipfusion.py:647-659, :701-713; clip_seem_fusion.py:786-822)
-        float* stage = reinterpret_cast<float*>(L.acc);
-        for (int j = tid; j < nh; j += kHitThreads) {
-          const uint32_t vf = L.rec_k[j];
-          const int tv = (int)(vf & 127u), f = (int)(vf >> 8);
-          const int hx = bx * kBX + ((tv >> 4) & 3), hy = by * kBY + ((tv >> 2) & 3), hz = bz * kBZ + (tv & 3);
-          const uint32_t hn = ((uint32_t)hx * (uint32_t)v.ny + (uint32_t)hy) * (uint32_t)v.nz + (uint32_t)hz;
-          const Cam cam = cam_from(cams + f * kCamFloats, ucam);
-          const Proj p = project(cam, v.ax[hx], v.ay[hy], v.az[hz]);
-          const Bilin bw = bilinear_setup(p.gx, p.gy, half_px, half_py);
-          // the fractions bilinear_setup built its weights from (nw = (1 - wy)(1 - wx), ...), recomputed the same way
-          const float ux = unnormalize(p.gx, half_px), uy = unnormalize(p.gy, half_py);
-          const float wx = ux - __builtin_floorf(ux), wy = uy - __builtin_floorf(uy);
-          const int cx = min(max(bw.x0, -2), wa.npx) + 2, cy = min(max(bw.y0, -2), wa.npy) + 2;
-          L.rec_g[j] = make_float2(wx, wy);
-          L.rec_k[j] = (uint32_t)L.vrow[tv] | ((uint32_t)cx << 7) | ((uint32_t)cy << 15) | ((uint32_t)f << 23);
-          kf.rgb = tab->rgb[f];
-          kf.label_map = tab->label_map[f];
-          float s0, s1, s2;
-          const int pix = sample_rgb_lane(kf, cam, p.gx, p.gy, s0, s1, s2);
-          stage[j * 3] = s0;
-          stage[j * 3 + 1] = s1;
-          stage[j * 3 + 2] = s2;
-          count_label_lane<true>(v, kf, hn, pix, stats);
-        }
-      }
-      lds_barrier();
-      BT(3);
-      // ---- per voxel, in frame order: the rgb running mean and the weight, exactly as frame after frame
-      //      (clipfusion.py:715-721); the row's coefficients for the folded update of the feature row
-      if (wave == 0 && touched) {
-        const float* stage = reinterpret_cast<const float*>(L.acc);
-        const int row = (int)L.vrow[tid];
-        int r = 0;
-#pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) {
-          uint32_t mm = rm[w];
-          while (mm) {
-            const int f = __ffs((int)mm) - 1 + 32 * w;
-            mm &= mm - 1u;
-            const int slot = (int)L.off[f] - base + rank_in_frame(&L.mf[f * 2], tid);
-            const int wi = w_cur + r;
-            const float a = 1.0f / (float)(wi + 1), b = (float)wi * a;
-            o0 = blend(stage[slot * 3], o0, a, b, SUM);
-            o1 = blend(stage[slot * 3 + 1], o1, a, b, SUM);
-            o2 = blend(stage[slot * 3 + 2], o2, a, b, SUM);
-            ++r;
-          }
-        }
-        const float a = SUM ? 1.0f : 1.0f / (float)(w_cur + k_v);
-        L.rowA[row] = a;
-        L.rowB[row] = SUM ? 1.0f : (float)w_cur * a;
-        w_cur += k_v;
-      }
-      lds_barrier();
-      BT(4);
-      // ---- everybody clears the accumulator (the staging is done with); the walkers sort their window of 64 hits by
-      //      (frame, cell): a group = a run of hits that blend the same four map rows
-      {
-        int4* acc4 = reinterpret_cast<int4*>(L.acc);
-        for (int i = tid; i < R * (kSlabCh / 4); i += kBThreads) acc4[i] = make_int4(0, 0, 0, 0);
-      }
-      if (wave < kWalkers) {
-        for (int win = wave; win < kWindows; win += kWalkers) {
-          const int wb = win * 64, cnt = min(64, nh - wb);  // (cnt <= 0: no such window)
-          const bool hv = lane < cnt;
-          const uint32_t key = hv ? L.rec_k[wb + lane] : 0xffffffffu;
-          const float2 g = L.rec_g[wb + lane];
-          const uint32_t sk = key >> 7;
-          int rank = 0;
-          if (cnt > 0) {
-            for (int j = 0; j < 64; ++j) {
-              const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)sk, j);
-              rank += (kj < sk || (kj == sk && j < lane)) ? 1 : 0;
-            }
-          }
-          wave_lds_sync();
-          if (hv) {
-            L.rec_k[wb + rank] = key;
-            L.rec_g[wb + rank] = g;
-          }
-          wave_lds_sync();
-          const uint32_t skey = hv ? L.rec_k[wb + lane] : 0xffffffffu;
-          const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
-          const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
-          if (lane == 0) L.misc[16 + win] = (uint32_t)__popcll(heads);
-        }
-      }
-      lds_barrier();
-      // ---- the table of groups: first hit, and the four map rows as byte offsets into the window's images; a tap outside
-      //      the map (zeros padding) gets an offset beyond the buffer: the range check returns zero and moves nothing
-      const int g_w0 = rfl((int)L.misc[16]), g_w1 = rfl((int)L.misc[17]), g_w2 = rfl((int)L.misc[18]), g_w3 = rfl((int)L.misc[19]);
-      const int G = g_w0 + g_w1 + g_w2 + g_w3;
-      if (wave < kWalkers) {
-        for (int win = wave; win < kWindows; win += kWalkers) {
-          const int wb = win * 64, cnt = min(64, nh - wb);
-          const bool hv = lane < cnt;
-          const uint32_t skey = hv ? L.rec_k[wb + lane] : 0xffffffffu;
-          const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
-          const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
-          const int gbase = win == 0 ? 0 : (win == 1 ? g_w0 : (win == 2 ? g_w0 + g_w1 : g_w0 + g_w1 + g_w2));
-          if ((heads >> lane) & 1ull) {
-            const int gi = gbase + __popcll(heads & lt_mask);
-            const int fb = (int)(skey >> 23), x0 = (int)((skey >> 7) & 255u) - 2, y0 = (int)((skey >> 15) & 255u) - 2;
-            const bool x0ok = x0 >= 0 && x0 < wa.npx, x1ok = x0 + 1 >= 0 && x0 + 1 < wa.npx;
-            const bool y0ok = y0 >= 0 && y0 < wa.npy, y1ok = y0 + 1 >= 0 && y0 + 1 < wa.npy;
-            const uint32_t ib = (uint32_t)fb * img_bytes;
-            uint4 o;
-            o.x = (x0ok && y0ok) ? ib + (uint32_t)(y0 * wa.npx + x0) * row_bytes : kTapOutside;
-            o.y = (x1ok && y0ok) ? ib + (uint32_t)(y0 * wa.npx + x0 + 1) * row_bytes : kTapOutside;
-            o.z = (x0ok && y1ok) ? ib + (uint32_t)((y0 + 1) * wa.npx + x0) * row_bytes : kTapOutside;
-            o.w = (x1ok && y1ok) ? ib + (uint32_t)((y0 + 1) * wa.npx + x0 + 1) * row_bytes : kTapOutside;
-            L.grp_off[gi] = o;
-            L.grp_start[gi] = (uint16_t)(wb + lane);
-          }
-        }
-        if (tid == 0) {
-          L.grp_off[G] = make_uint4(kTapOutside, kTapOutside, kTapOutside, kTapOutside);
-          L.grp_start[G] = (uint16_t)nh;
-        }
-      }
-      lds_barrier();
-      BT(5);
-
+  // ---- the slabs of one round: R rows, G groups, kexp = ceil(log2 of the most hits a row takes); the records, the group
+  //      table and the rows' coefficients are in LDS
+  [[maybe_unused]] auto run_slabs = [&](const int R, const int G, const int kexp) {
+    if constexpr (!BUILD) {
       // ---- slabs of 64 CPL channels.  The two roles run different code between the same barriers (their registers --
       //      the movers' row pieces, the walkers' two tap batches -- are never live together).
       if (wave >= kWalkers) {
@@ -662,7 +454,427 @@ __global__ __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
           BT(8);
         }
       }
-      if (f1 < F) {
+    }
+  };
+
+  // ---- BUILD: one round's records, group table and row coefficients go to the pool
+  uint32_t seg_base = 0;  // first segment of this brick
+  int seg_round = 0;
+  [[maybe_unused]] auto write_segment = [&](const int R, const int nh, const int G, const int kexp) {
+    if constexpr (BUILD) {
+      if (seg_base == 0xffffffffu) {
+        lds_barrier();
+        return;
+      }
+      unsigned char* sg = pool.segs + (size_t)(seg_base + (uint32_t)seg_round) * kSegBytes;
+      if (tid == 0) {
+        uint32_t* h = reinterpret_cast<uint32_t*>(sg + kSegHdr);
+        h[0] = (uint32_t)R; h[1] = (uint32_t)nh; h[2] = (uint32_t)G; h[3] = (uint32_t)kexp;
+      }
+      if (tid < R) {
+        reinterpret_cast<uint32_t*>(sg + kSegRown)[tid] = L.rown[tid];
+        reinterpret_cast<float*>(sg + kSegRowA)[tid] = L.rowA[tid];
+        reinterpret_cast<float*>(sg + kSegRowB)[tid] = L.rowB[tid];
+        sg[kSegFresh + tid] = L.rowfresh[tid];
+      }
+      for (int i = tid; i < nh; i += kNT) {
+        reinterpret_cast<uint32_t*>(sg + kSegRecK)[i] = L.rec_k[i];
+        reinterpret_cast<float2*>(sg + kSegRecG)[i] = L.rec_g[i];
+      }
+      for (int i = tid; i <= G; i += kNT) {
+        reinterpret_cast<uint16_t*>(sg + kSegGrpStart)[i] = L.grp_start[i];
+        reinterpret_cast<uint4*>(sg + kSegGrpOff)[i] = L.grp_off[i];
+      }
+      ++seg_round;
+      lds_barrier();  // the arrays are rewritten by the next round
+    }
+  };
+
+  // voxel of this thread within a brick (wave 0)
+  const int lx = (tid >> 4) & 3, ly = (tid >> 2) & 3, lz = tid & 3;
+  const bool vth = tid < kBV;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  if constexpr (!BUILD) {
+    // the accumulator starts clear and every slab leaves it clear
+    {
+      int4* acc4 = reinterpret_cast<int4*>(L.acc);
+      for (int i = tid; i < kBV * kSlabCh / 4; i += kNT) acc4[i] = make_int4(0, 0, 0, 0);
+    }
+    // ---- the bricks the build kernel has prepared: per listed brick, its rounds' segments one after the other
+    if (pool.split) {
+      const uint32_t n_list = pool.ctl->list_n;
+      for (;;) {
+        if (tid == 0) L.misc[0] = atomicAdd(&pool.ctl->walk_next, 1u);
+        lds_barrier();
+        const uint32_t e = (uint32_t)rfl((int)L.misc[0]);
+        if (e >= n_list) break;
+        const uint2 ent = pool.list[e];
+        const uint32_t s0 = (uint32_t)rfl((int)ent.x), n_r = (uint32_t)rfl((int)ent.y);
+        for (uint32_t r = 0; r < n_r; ++r) {
+          const unsigned char* sg = pool.segs + (size_t)(s0 + r) * kSegBytes;
+          const uint32_t* h = reinterpret_cast<const uint32_t*>(sg + kSegHdr);
+          const int R = rfl((int)h[0]), nh = rfl((int)h[1]), G = rfl((int)h[2]), kexp = rfl((int)h[3]);
+          if (tid < R) {
+            L.rown[tid] = reinterpret_cast<const uint32_t*>(sg + kSegRown)[tid];
+            L.rowA[tid] = reinterpret_cast<const float*>(sg + kSegRowA)[tid];
+            L.rowB[tid] = reinterpret_cast<const float*>(sg + kSegRowB)[tid];
+            L.rowfresh[tid] = sg[kSegFresh + tid];
+          }
+          for (int i = tid; i < nh; i += kNT) {
+            L.rec_k[i] = reinterpret_cast<const uint32_t*>(sg + kSegRecK)[i];
+            L.rec_g[i] = reinterpret_cast<const float2*>(sg + kSegRecG)[i];
+          }
+          for (int i = tid; i <= G; i += kNT) {
+            L.grp_start[i] = reinterpret_cast<const uint16_t*>(sg + kSegGrpStart)[i];
+            L.grp_off[i] = reinterpret_cast<const uint4*>(sg + kSegGrpOff)[i];
+          }
+          lds_barrier();
+          BT(5);
+          run_slabs(R, G, kexp);
+          if (r + 1 < n_r) {  // (see the end of a round below)
+            if (wave >= kWalkers) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            lds_barrier();
+          }
+        }
+      }
+    }
+  }
+
+  // ---- bricks built here: BUILD: the workgroup's own brick; the walk kernel: the bricks of the overflow list, or (no build
+  //      kernel) every brick, drawn XCD by XCD
+  bool build_done = false;
+  // The walk kernel behind a build kernel only rebuilds what the pool had no room for: the build kernel has already done
+  // those bricks' scalar side (rgb, weights, labels, counters) -- the next window's build kernel may be running beside this
+  // kernel and reads them -- so it is not done again, and the weight before this window is the stored one minus the hits.
+  const bool redo = !BUILD && pool.split != 0;
+  for (;;) {
+    if (tid == 0) {
+      uint32_t code = 0xffffffffu;
+      if constexpr (BUILD) {
+        if (!build_done) {
+          const uint32_t bxcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+          const uint32_t my_tiles = (n_tiles + 7u - bxcd) / 8u;
+          if (j < my_tiles * upt) {
+            const uint32_t tl = j / upt, within = j - tl * upt, zs = within >> 6, k = within & 63u;
+            const uint32_t t = tl * 8u + bxcd, tx = t / tiles_y, ty = t - tx * tiles_y;
+            const uint32_t bx = tx * 4u + ((k >> 2) & 3u), by = ty * 4u + (k & 3u), bz = zs * 4u + (k >> 4);
+            if (bx < nbx && by < nby && bz < nbz) code = bx | (by << 10) | (bz << 20);
+          }
+        }
+      } else if (pool.split) {
+        const uint32_t o = atomicAdd(&pool.ctl->over_next, 1u);
+        if (o < pool.ctl->over_n) code = pool.over[o];
+      } else
+      while (xcd_tries < 8u) {
+        const uint32_t my_tiles = (n_tiles + 7u - xcd) / 8u;
+        const uint32_t j = atomicAdd(ctr + xcd, 1u);
+        if (j >= my_tiles * upt) {
+          ++xcd_tries;
+          xcd = (xcd + 1u) & 7u;
+          continue;
+        }
+        const uint32_t tl = j / upt, within = j - tl * upt, zs = within >> 6, k = within & 63u;
+        const uint32_t t = tl * 8u + xcd, tx = t / tiles_y, ty = t - tx * tiles_y;
+        const uint32_t bx = tx * 4u + ((k >> 2) & 3u), by = ty * 4u + (k & 3u), bz = zs * 4u + (k >> 4);
+        if (bx >= nbx || by >= nby || bz >= nbz) continue;
+        code = bx | (by << 10) | (bz << 20);
+        break;
+      }
+      L.misc[0] = code;
+    }
+    lds_barrier();
+    const uint32_t code = (uint32_t)rfl((int)L.misc[0]);
+    if (code == 0xffffffffu) break;
+    build_done = true;
+    const int bx = (int)(code & 1023u), by = (int)((code >> 10) & 1023u), bz = (int)(code >> 20);
+    const int ix = bx * kBX + lx, iy = by * kBY + ly, iz = bz * kBZ + lz;
+    const bool inb = vth && ix < v.nx && iy < v.ny && iz < v.nz;
+    const uint32_t n = ((uint32_t)ix * (uint32_t)v.ny + (uint32_t)iy) * (uint32_t)v.nz + (uint32_t)iz;
+    uint32_t mk[kMaskWords];
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) mk[w] = (inb && w * 32 < F) ? hitmask[(size_t)w * mask_plane + n] : 0u;
+    uint32_t any = 0u;
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) any |= mk[w];
+    // (the zeroing of the bit matrix rides on this barrier)
+    if (tid < kWin * 2) L.mf[tid] = 0u;
+    if (wave == 0) {
+      const unsigned long long wany = __ballot(any != 0u);
+      if (lane == 0) L.misc[4] = wany != 0ull ? 1u : 0u;
+    }
+    lds_barrier();
+    BT(0);
+    if (rfl((int)L.misc[4]) == 0) continue;
+    int w_cur = 0;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (any) {
+      w_cur = v.weight[n];
+      if (redo) {
+        int h = 0;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) h += __popc(mk[w]);
+        w_cur -= h;
+      } else {
+        const float* src = v.rgb + (int64_t)n * 3;
+        o0 = src[0]; o1 = src[1]; o2 = src[2];
+        rows_done += 1ull;
+      }
+      // ---- bit matrix frame x voxel
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) {
+        uint32_t mm = mk[w];
+        while (mm) {
+          const int f = __ffs((int)mm) - 1 + 32 * w;
+          mm &= mm - 1u;
+          atomicOr(&L.mf[f * 2 + (tid >> 5)], 1u << (tid & 31));
+        }
+      }
+    }
+    lds_barrier();
+    // ---- hits per frame and their exclusive prefix (frames beyond F have none)
+    {
+      int cf = 0;
+      if (tid < kWin) cf = __popc(L.mf[tid * 2]) + __popc(L.mf[tid * 2 + 1]);
+      int incl = cf;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      if (tid == 63) L.misc[1] = (uint32_t)incl;
+      lds_barrier();
+      if (tid < kWin) {
+        const int add = wave == 1 ? rfl((int)L.misc[1]) : 0;
+        L.off[tid] = (uint16_t)(incl - cf + add);
+        if (tid == kWin - 1) L.off[kWin] = (uint16_t)(incl + add);
+      }
+      lds_barrier();
+    }
+    if (tid == 0 && !redo) hits_done += (unsigned long long)L.off[kWin];
+    BT(1);
+
+    // ---- rounds: consecutive frames whose hits fit the record arrays
+    auto round_end = [&](const int f0) {
+      const int base = rfl((int)L.off[f0]);
+      int f1 = F;
+      if (rfl((int)L.off[F]) - base > kHC) {
+        int lo = f0 + 1, hi = F;  // a single frame has at most kBV <= kHC hits
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (rfl((int)L.off[mid]) - base <= kHC) lo = mid; else hi = mid - 1;
+        }
+        f1 = lo;
+      }
+      return f1;
+    };
+    if constexpr (BUILD) {
+      // the brick's rounds get consecutive segments of the pool; a brick that finds the pool exhausted goes to the overflow
+      // list untouched (the walk kernel builds it itself)
+      int n_r = 0;
+      for (int f = 0; f < F;) {
+        const int f1 = round_end(f);
+        if (rfl((int)L.off[f1]) - rfl((int)L.off[f]) == 0) break;
+        ++n_r;
+        f = f1;
+      }
+      if (tid == 0) {
+        const uint32_t b0 = atomicAdd(&pool.ctl->seg_next, (uint32_t)n_r);
+        if (b0 + (uint32_t)n_r <= pool.cap) {
+          pool.list[atomicAdd(&pool.ctl->list_n, 1u)] = make_uint2(b0, (uint32_t)n_r);
+          L.misc[5] = b0;
+        } else {
+          pool.over[atomicAdd(&pool.ctl->over_n, 1u)] = code;
+          L.misc[5] = 0xffffffffu;
+        }
+      }
+      lds_barrier();
+      seg_base = (uint32_t)rfl((int)L.misc[5]);
+      seg_round = 0;
+      // (a brick without segments still gets its scalar side here; the walk kernel rebuilds its records)
+    }
+    int f0 = 0;
+    while (f0 < F) {
+      const int base = rfl((int)L.off[f0]);
+      const int f1 = round_end(f0);
+      const int nh = rfl((int)L.off[f1]) - base;
+      if (nh == 0) break;  // only when nothing is left
+      // ---- the voxels' hits of this round: rows, record slots
+      uint32_t rm[kMaskWords];
+      int k_v = 0;
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) {
+        const int lo_b = f0 - 32 * w, hi_b = f1 - 32 * w;  // bits [lo_b, hi_b) of word w
+        const uint32_t m_lo = lo_b <= 0 ? 0xffffffffu : (lo_b >= 32 ? 0u : ~((1u << lo_b) - 1u));
+        const uint32_t m_hi = hi_b <= 0 ? 0u : (hi_b >= 32 ? 0xffffffffu : ((1u << hi_b) - 1u));
+        rm[w] = mk[w] & m_lo & m_hi;
+        k_v += __popc(rm[w]);
+      }
+      const bool touched = k_v > 0;
+      const unsigned long long bal = __ballot(touched);
+      if (wave == 0) {
+        int km = k_v;  // the most hits any row takes in this round (bounds the fixed-point sums)
+        for (int o = 32; o > 0; o >>= 1) km = max(km, __shfl_xor(km, o));
+        if (lane == 0) { L.misc[2] = (uint32_t)__popcll(bal); L.misc[8] = (uint32_t)km; }
+        const int row = __popcll(bal & lt_mask);
+        if (touched) {
+          L.vrow[tid] = (uint8_t)row;
+          L.rown[row] = n;
+          L.rowfresh[row] = w_cur == 0 ? 1 : 0;  // never written: all zeros by construction, not read
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) {
+            uint32_t mm = rm[w];
+            while (mm) {
+              const int f = __ffs((int)mm) - 1 + 32 * w;
+              mm &= mm - 1u;
+              const int slot = (int)L.off[f] - base + rank_in_frame(&L.mf[f * 2], tid);
+              L.rec_k[slot] = (uint32_t)tid | ((uint32_t)f << 8);
+            }
+          }
+        }
+      }
+      lds_barrier();
+      const int R = rfl((int)L.misc[2]);
+      const int k_max = rfl((int)L.misc[8]);
+      const int kexp = k_max <= 1 ? 0 : 32 - __builtin_clz((unsigned)(k_max - 1));  // ceil(log2 k_max)
+      BT(2);
+
+      if (wave < kWalkers) {
+        // ---- walkers: per hit: projection, map cell, bilinear fractions, the frame's rgb sample and label count
+        //      (clipfusion.py:647-659, :701-713; clip_seem_fusion.py:786-822)
+        float* stage;
+        if constexpr (BUILD) stage = L.stage; else stage = reinterpret_cast<float*>(L.acc);
+        for (int j = tid; j < nh; j += kHitThreads) {
+          const uint32_t vf = L.rec_k[j];
+          const int tv = (int)(vf & 127u), f = (int)(vf >> 8);
+          const int hx = bx * kBX + ((tv >> 4) & 3), hy = by * kBY + ((tv >> 2) & 3), hz = bz * kBZ + (tv & 3);
+          const uint32_t hn = ((uint32_t)hx * (uint32_t)v.ny + (uint32_t)hy) * (uint32_t)v.nz + (uint32_t)hz;
+          const Cam cam = cam_from(cams + f * kCamFloats, ucam);
+          const Proj p = project(cam, v.ax[hx], v.ay[hy], v.az[hz]);
+          const Bilin bw = bilinear_setup(p.gx, p.gy, half_px, half_py);
+          // the fractions bilinear_setup built its weights from (nw = (1 - wy)(1 - wx), ...), recomputed the same way
+          const float ux = unnormalize(p.gx, half_px), uy = unnormalize(p.gy, half_py);
+          const float wx = ux - __builtin_floorf(ux), wy = uy - __builtin_floorf(uy);
+          const int cx = min(max(bw.x0, -2), wa.npx) + 2, cy = min(max(bw.y0, -2), wa.npy) + 2;
+          L.rec_g[j] = make_float2(wx, wy);
+          L.rec_k[j] = (uint32_t)L.vrow[tv] | ((uint32_t)cx << 7) | ((uint32_t)cy << 15) | ((uint32_t)f << 23);
+          if (!redo) {
+            kf.rgb = tab->rgb[f];
+            kf.label_map = tab->label_map[f];
+            float s0, s1, s2;
+            const int pix = sample_rgb_lane(kf, cam, p.gx, p.gy, s0, s1, s2);
+            stage[j * 3] = s0;
+            stage[j * 3 + 1] = s1;
+            stage[j * 3 + 2] = s2;
+            count_label_lane<true>(v, kf, hn, pix, stats);
+          }
+        }
+      }
+      lds_barrier();
+      BT(3);
+      // ---- per voxel, in frame order: the rgb running mean and the weight, exactly as frame after frame
+      //      (clipfusion.py:715-721); the row's coefficients for the folded update of the feature row
+      if (wave == 0 && touched) {
+        const float* stage;
+        if constexpr (BUILD) stage = L.stage; else stage = reinterpret_cast<const float*>(L.acc);
+        const int row = (int)L.vrow[tid];
+        int r = 0;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) {
+          uint32_t mm = redo ? 0u : rm[w];
+          while (mm) {
+            const int f = __ffs((int)mm) - 1 + 32 * w;
+            mm &= mm - 1u;
+            const int slot = (int)L.off[f] - base + rank_in_frame(&L.mf[f * 2], tid);
+            const int wi = w_cur + r;
+            const float a = 1.0f / (float)(wi + 1), b = (float)wi * a;
+            o0 = blend(stage[slot * 3], o0, a, b, SUM);
+            o1 = blend(stage[slot * 3 + 1], o1, a, b, SUM);
+            o2 = blend(stage[slot * 3 + 2], o2, a, b, SUM);
+            ++r;
+          }
+        }
+        const float a = SUM ? 1.0f : 1.0f / (float)(w_cur + k_v);
+        L.rowA[row] = a;
+        L.rowB[row] = SUM ? 1.0f : (float)w_cur * a;
+        w_cur += k_v;
+      }
+      lds_barrier();
+      BT(4);
+      // ---- everybody clears the accumulator (the staging is done with); the walkers sort their window of 64 hits by
+      //      (frame, cell): a group = a run of hits that blend the same four map rows
+      if constexpr (!BUILD) {
+        int4* acc4 = reinterpret_cast<int4*>(L.acc);
+        for (int i = tid; i < R * (kSlabCh / 4); i += kNT) acc4[i] = make_int4(0, 0, 0, 0);
+      }
+      if (wave < kWalkers) {
+        for (int win = wave; win < kWindows; win += kWalkers) {
+          const int wb = win * 64, cnt = min(64, nh - wb);  // (cnt <= 0: no such window)
+          const bool hv = lane < cnt;
+          const uint32_t key = hv ? L.rec_k[wb + lane] : 0xffffffffu;
+          const float2 g = L.rec_g[wb + lane];
+          const uint32_t sk = key >> 7;
+          int rank = 0;
+          if (cnt > 0) {
+            for (int j = 0; j < 64; ++j) {
+              const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)sk, j);
+              rank += (kj < sk || (kj == sk && j < lane)) ? 1 : 0;
+            }
+          }
+          wave_lds_sync();
+          if (hv) {
+            L.rec_k[wb + rank] = key;
+            L.rec_g[wb + rank] = g;
+          }
+          wave_lds_sync();
+          const uint32_t skey = hv ? L.rec_k[wb + lane] : 0xffffffffu;
+          const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
+          const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
+          if (lane == 0) L.misc[16 + win] = (uint32_t)__popcll(heads);
+        }
+      }
+      lds_barrier();
+      // ---- the table of groups: first hit, and the four map rows as byte offsets into the window's images; a tap outside
+      //      the map (zeros padding) gets an offset beyond the buffer: the range check returns zero and moves nothing
+      const int g_w0 = rfl((int)L.misc[16]), g_w1 = rfl((int)L.misc[17]), g_w2 = rfl((int)L.misc[18]), g_w3 = rfl((int)L.misc[19]);
+      const int G = g_w0 + g_w1 + g_w2 + g_w3;
+      if (wave < kWalkers) {
+        for (int win = wave; win < kWindows; win += kWalkers) {
+          const int wb = win * 64, cnt = min(64, nh - wb);
+          const bool hv = lane < cnt;
+          const uint32_t skey = hv ? L.rec_k[wb + lane] : 0xffffffffu;
+          const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
+          const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
+          const int gbase = win == 0 ? 0 : (win == 1 ? g_w0 : (win == 2 ? g_w0 + g_w1 : g_w0 + g_w1 + g_w2));
+          if ((heads >> lane) & 1ull) {
+            const int gi = gbase + __popcll(heads & lt_mask);
+            const int fb = (int)(skey >> 23), x0 = (int)((skey >> 7) & 255u) - 2, y0 = (int)((skey >> 15) & 255u) - 2;
+            const bool x0ok = x0 >= 0 && x0 < wa.npx, x1ok = x0 + 1 >= 0 && x0 + 1 < wa.npx;
+            const bool y0ok = y0 >= 0 && y0 < wa.npy, y1ok = y0 + 1 >= 0 && y0 + 1 < wa.npy;
+            const uint32_t ib = (uint32_t)fb * img_bytes;
+            uint4 o;
+            o.x = (x0ok && y0ok) ? ib + (uint32_t)(y0 * wa.npx + x0) * row_bytes : kTapOutside;
+            o.y = (x1ok && y0ok) ? ib + (uint32_t)(y0 * wa.npx + x0 + 1) * row_bytes : kTapOutside;
+            o.z = (x0ok && y1ok) ? ib + (uint32_t)((y0 + 1) * wa.npx + x0) * row_bytes : kTapOutside;
+            o.w = (x1ok && y1ok) ? ib + (uint32_t)((y0 + 1) * wa.npx + x0 + 1) * row_bytes : kTapOutside;
+            L.grp_off[gi] = o;
+            L.grp_start[gi] = (uint16_t)(wb + lane);
+          }
+        }
+        if (tid == 0) {
+          L.grp_off[G] = make_uint4(kTapOutside, kTapOutside, kTapOutside, kTapOutside);
+          L.grp_start[G] = (uint16_t)nh;
+        }
+      }
+      lds_barrier();
+      BT(5);
+
+      if constexpr (BUILD) {
+        write_segment(R, nh, G, kexp);
+      } else {
+        run_slabs(R, G, kexp);
+      }
+      if (!BUILD && f1 < F) {
         // Another round follows: its rows may be read by a different mover than the one that has just written them, and
         // nothing orders two waves' accesses to one address -- every mover's stores are in L2 before anybody goes on
         // (the loads are nontemporal: served by L2, never by the CU's L1).
@@ -671,7 +883,7 @@ __global__ __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
       }
       f0 = f1;
     }
-    if (any) {
+    if (any && !redo) {
       float* dst = v.rgb + (int64_t)n * 3;
       dst[0] = o0; dst[1] = o1; dst[2] = o2;
       v.weight[n] = w_cur;
@@ -682,13 +894,21 @@ __global__ __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   BT_FLUSH;
   if (stats) {
     for (int o = 32; o > 0; o >>= 1) rows_done += __shfl_xor(rows_done, o);
-    if (lane == 0 && rows_done) atomicAdd(&stats[5], rows_done);  // rows read-modify-written by this window
-    if (tid == 0 && hits_done) atomicAdd(&stats[0], hits_done);
+    if constexpr (BUILD) {  // one workgroup per brick: sharded, folded into stats[] by the walk kernel
+      unsigned long long* sh = pool.ctl->acc[blockIdx.x & 63u];
+      if (tid == 0 && (hits_done | rows_done)) {
+        atomicAdd(&sh[0], hits_done);
+        atomicAdd(&sh[1], rows_done);
+      }
+    } else {
+      if (lane == 0 && rows_done) atomicAdd(&stats[5], rows_done);  // rows read-modify-written by this window
+      if (tid == 0 && hits_done) atomicAdd(&stats[0], hits_done);
+    }
   }
 }
 
 using BrickFn = void (*)(KVol, WinArgs, const WinTable*, const float*, uint32_t, unsigned long long*, unsigned int*,
-                         const uint32_t*, uint32_t, const unsigned long long*, const uint32_t*, const float*);
+                         const uint32_t*, uint32_t, const unsigned long long*, const uint32_t*, const float*, BrickPool);
 
 // cmax[c] = bits of the largest |x| of channel c over the window's pixel-major map images, cmax[D + c / 64] = of every
 // group of 64 channels, cmax[D + D / 64] = of all channels (non-negative floats order like their bit patterns; NaN > inf >
@@ -727,8 +947,53 @@ size_t cmax_bytes(int D) { return (cmax_words(D) * sizeof(uint32_t) + 255) & ~(s
 
 template <int CPL>
 BrickFn pick_brick(bool sum, bool bf16) {
-  if (bf16) return sum ? fuse_brick_kernel<CPL, true, true> : fuse_brick_kernel<CPL, false, true>;
-  return sum ? fuse_brick_kernel<CPL, true, false> : fuse_brick_kernel<CPL, false, false>;
+  if (bf16) return sum ? fuse_brick_kernel<CPL, true, true, false> : fuse_brick_kernel<CPL, false, true, false>;
+  return sum ? fuse_brick_kernel<CPL, true, false, false> : fuse_brick_kernel<CPL, false, false, false>;
+}
+
+uint32_t brick_count(const KVol& kv) {
+  return (((uint32_t)kv.nx + kBX - 1) / kBX) * (((uint32_t)kv.ny + kBY - 1) / kBY) * (((uint32_t)kv.nz + kBZ - 1) / kBZ);
+}
+size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
+// The aux region of the workspace: the channel maxima, then per window parity the camera table and the segment pool.  The
+// lists are sized by the grid's bricks; the segments get what is left of `avail` (at most a round and a quarter per brick:
+// a brick that finds the pool exhausted is built by the walk kernel, slower, never wrong).
+struct AuxLayout {
+  size_t cams, ctl, list, over, segs, parity_bytes;
+  uint32_t cap;
+  bool fits;
+};
+size_t aux_fixed(uint32_t nb) {
+  return pad256((size_t)kWin * kCamFloats * sizeof(float)) + pad256(sizeof(BrickCtl)) + pad256((size_t)nb * sizeof(uint2)) +
+         pad256((size_t)nb * sizeof(uint32_t));
+}
+AuxLayout aux_layout(const KVol& kv, size_t avail) {
+  AuxLayout a;
+  const uint32_t nb = brick_count(kv);
+  a.cams = 0;
+  a.ctl = a.cams + pad256((size_t)kWin * kCamFloats * sizeof(float));
+  a.list = a.ctl + pad256(sizeof(BrickCtl));
+  a.over = a.list + pad256((size_t)nb * sizeof(uint2));
+  a.segs = a.over + pad256((size_t)nb * sizeof(uint32_t));
+  a.fits = avail >= cmax_bytes(kv.D) + 2 * a.segs;
+  const size_t per_parity = a.fits ? (avail - cmax_bytes(kv.D)) / 2 : a.segs;
+  a.parity_bytes = per_parity & ~(size_t)255;
+  const size_t want = (size_t)nb + nb / 4 + 64, room = (a.parity_bytes - a.segs) / kSegBytes;
+  a.cap = (uint32_t)(room < want ? room : want);
+  return a;
+}
+BrickPool make_pool(const KVol& kv, void* aux, size_t aux_bytes, int parity, int split, const float** cams) {
+  const AuxLayout a = aux_layout(kv, aux_bytes);
+  unsigned char* p = static_cast<unsigned char*>(aux) + cmax_bytes(kv.D) + (size_t)parity * a.parity_bytes;
+  BrickPool pool;
+  pool.segs = p + a.segs;
+  pool.list = reinterpret_cast<uint2*>(p + a.list);
+  pool.over = reinterpret_cast<uint32_t*>(p + a.over);
+  pool.ctl = reinterpret_cast<BrickCtl*>(p + a.ctl);
+  pool.cap = a.cap;
+  pool.split = split;
+  *cams = reinterpret_cast<const float*>(p + a.cams);
+  return pool;
 }
 
 }  // namespace
@@ -742,19 +1007,50 @@ bool brick_form_ok(const KVol& kv) {
   const uint32_t nbx = ((uint32_t)kv.nx + kBX - 1) / kBX, nby = ((uint32_t)kv.ny + kBY - 1) / kBY, nbz = ((uint32_t)kv.nz + kBZ - 1) / kBZ;
   return nbx < 1024u && nby < 1024u && nbz < 1024u;  // the brick code of a workgroup is three 10-bit fields
 }
+// SAF_BRICK_SPLIT=0 (read per call): no build kernel, the walk kernel builds every brick itself
+bool brick_split() {
+  const char* e = getenv("SAF_BRICK_SPLIT");
+  return !(e && e[0] == '0');
+}
 
-size_t brick_aux_bytes(int D) { return cmax_bytes(D) + (((size_t)kWin * kCamFloats * sizeof(float) + 255) & ~(size_t)255); }
+// What saf_fuse_workspace_bytes reserves (it knows the number of voxels, not the grid's shape): room for the lists and a full
+// pool of a grid with a tenth more bricks than n_vox / 64 (ragged edges); brick_aux_fits() says whether a given grid fits.
+size_t brick_aux_bytes_est(int64_t n_vox, int D) {
+  const uint32_t nb = (uint32_t)(n_vox / 64 + n_vox / 640 + 4096);
+  return cmax_bytes(D) + 2 * (aux_fixed(nb) + ((size_t)nb + nb / 4 + 64) * kSegBytes);
+}
+bool brick_aux_fits(const KVol& kv, size_t avail) { return aux_layout(kv, avail).fits; }
+
+// The build kernel of a window (after its classification, on the classification's stream): camera table, pool control
+// words, one workgroup per brick.
+int launch_brick_build(const KVol& kv, const WinArgs& wa, const WinTable* tab, size_t img_bytes, unsigned long long* stats,
+                       const uint32_t* hitmask, uint32_t mask_plane, void* aux, size_t aux_bytes, int parity, hipStream_t s) {
+  const float* cams;
+  const BrickPool pool = make_pool(kv, aux, aux_bytes, parity, 1, &cams);
+  if (hipMemsetAsync(pool.ctl, 0, sizeof(BrickCtl), s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(brick pool control)");
+  hipLaunchKernelGGL(cam_table_kernel, dim3(1), dim3(128), 0, s, tab, wa.F, const_cast<float*>(cams));
+  const uint32_t nbx = ((uint32_t)kv.nx + kBX - 1) / kBX, nby = ((uint32_t)kv.ny + kBY - 1) / kBY, nbz = ((uint32_t)kv.nz + kBZ - 1) / kBZ;
+  const uint32_t n_tiles = ((nbx + 3u) / 4u) * ((nby + 3u) / 4u), upt = ((nbz + 3u) / 4u) * 64u;
+  const uint32_t grid = 8u * ((n_tiles + 7u) / 8u) * upt;
+  const bool sum = kv.accum == SAF_SUM;
+  // (the build does not depend on the feature dtype or width: one instantiation per accumulation mode)
+  BrickFn fn = sum ? fuse_brick_kernel<1, true, false, true> : fuse_brick_kernel<1, false, false, true>;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kHitThreads), sizeof(BuildLds), s, kv, wa, tab, nullptr, (uint32_t)img_bytes, stats, nullptr,
+                     hitmask, mask_plane, nullptr, nullptr, cams, pool);
+  return check_launch("fuse_brick_kernel (build)");
+}
 
 int launch_fuse_bricks(const KVol& kv, const WinArgs& wa, const WinTable* tab, const float* map_imgs, size_t img_bytes,
                        unsigned long long* stats, unsigned int* ctr, const uint32_t* hitmask, uint32_t mask_plane,
-                       const unsigned long long* cls_acc, void* aux, hipStream_t s) {
+                       const unsigned long long* cls_acc, void* aux, size_t aux_bytes, int parity, int split, hipStream_t s) {
   uint32_t* cmax = static_cast<uint32_t*>(aux);
-  float* cams = reinterpret_cast<float*>(static_cast<unsigned char*>(aux) + cmax_bytes(kv.D));
-  // the channels' largest magnitudes over this window's maps (the scales of the fixed-point sums) and the cameras
+  const float* cams;
+  const BrickPool pool = make_pool(kv, aux, aux_bytes, parity, split, &cams);
+  // the channels' largest magnitudes over this window's maps (the scales of the fixed-point sums)
   if (hipMemsetAsync(cmax, 0, cmax_bytes(kv.D), s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(channel maxima)");
   hipLaunchKernelGGL(chan_max_kernel, dim3((kv.D + 255) / 256, (wa.F + 7) / 8), dim3(256), 0, s, map_imgs,
                      (int)(img_bytes / sizeof(float)), kv.D, wa.npy * wa.npx, wa.F, cmax);
-  hipLaunchKernelGGL(cam_table_kernel, dim3(1), dim3(128), 0, s, tab, wa.F, cams);
+  if (!split) hipLaunchKernelGGL(cam_table_kernel, dim3(1), dim3(128), 0, s, tab, wa.F, const_cast<float*>(cams));
   const bool sum = kv.accum == SAF_SUM, bf16 = kv.bf16 != 0;
   BrickFn fn;
   size_t lds;
@@ -770,7 +1066,7 @@ int launch_fuse_bricks(const KVol& kv, const WinArgs& wa, const WinTable* tab, c
   const int wgs_env = getenv("SAF_BRICK_WGS") ? atoi(getenv("SAF_BRICK_WGS")) : 0;
   const uint32_t grid = (uint32_t)device_cus() * (uint32_t)(wgs_env > 0 ? wgs_env : 2);
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kBThreads), lds, s, kv, wa, tab, map_imgs, (uint32_t)img_bytes, stats, ctr, hitmask,
-                     mask_plane, cls_acc, cmax, cams);
+                     mask_plane, cls_acc, cmax, cams, pool);
 #ifdef SAF_BRICK_TIMING
   {
     int nb = -1;

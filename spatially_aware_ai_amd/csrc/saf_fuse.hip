@@ -942,11 +942,11 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
     // SAF_WIN_OVERLAP=0: every kernel of the windowed path on the caller's stream (read per call: same-process A/Bs)
     const char* ov_env = getenv("SAF_WIN_OVERLAP");
     PipeRes* pr = (ov_env && ov_env[0] == '0') || n_frames <= window_frames() ? nullptr : pipe_acquire();
-    if (!pr) return fuse_many_windowed(kv, frames, n_frames, workspace, stats, prof, s, nullptr);
+    if (!pr) return fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, nullptr);
     WinOverlap ov;
     ov.aux = pr->aux; ov.fork = pr->fork; ov.join = pr->join;
     ov.cls_done[0] = pr->fused[0]; ov.cls_done[1] = pr->fused[1]; ov.fuse_done[0] = pr->fused[2]; ov.fuse_done[1] = pr->fused[3];
-    rc = fuse_many_windowed(kv, frames, n_frames, workspace, stats, prof, s, &ov);
+    rc = fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, &ov);
     pipe_release(pr);
     return rc;
   }

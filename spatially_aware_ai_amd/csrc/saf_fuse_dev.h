@@ -295,7 +295,7 @@ struct WinOverlap {
   hipStream_t aux;
   hipEvent_t fork, join, cls_done[2], fuse_done[2];
 };
-int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, uint64_t* stats,
-                       saf_profiler* prof, hipStream_t s, const WinOverlap* ov);
+int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
+                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov);
 
 }  // namespace saf

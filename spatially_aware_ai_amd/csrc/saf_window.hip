@@ -1049,7 +1049,7 @@ WinLayout win_layout(int64_t n_vox, int D, int P) {
   w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
   w.cmax_off = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;  // the brick form's channel maxima and camera table
-  w.total = w.cmax_off + brick_aux_bytes(D);
+  w.total = w.cmax_off + brick_aux_bytes_est(n_vox, D);
   return w;
 }
 
@@ -1082,7 +1082,10 @@ bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
   // SAF_WINDOW_BF16=0 keeps bf16 volumes on the per-frame pipeline
   const bool bf16_on = !(getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '0');
   if (kv.bf16 && !bf16_on) return false;
-  if (!brick_form_ok(kv)) {  // the frame-ordered row kernel: whole 1 KiB pieces of a row per wave instruction
+  const saf_frame& fr0 = frames[0];
+  const WinLayout wl0 = win_layout(kv.N, kv.D, fr0.npy * fr0.npx);
+  const bool bricks = brick_form_ok(kv) && workspace_bytes > wl0.cmax_off && brick_aux_fits(kv, workspace_bytes - wl0.cmax_off);
+  if (!bricks) {  // the frame-ordered row kernel: whole 1 KiB pieces of a row per wave instruction
     if (kv.D % 256 != 0 || kv.D > 1024) return false;
     if (kv.bf16 && kv.D % 512 != 0) return false;  // a lane moves 8 bf16 channels: 512 per wave
   }
@@ -1099,8 +1102,8 @@ bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
   return workspace_bytes >= wl.total;
 }
 
-int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, uint64_t* stats,
-                       saf_profiler* prof, hipStream_t s, const WinOverlap* ov) {
+int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
+                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   KFrame kf0;
@@ -1114,7 +1117,9 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const bool sum = kv.accum == SAF_SUM;
   const int img_vecs = (int)(wl.img_bytes / sizeof(float4));
   const int prep_blocks = (kv.D * (P + 1) + 255) / 256;
-  const bool brick_form = brick_form_ok(kv);
+  const size_t aux_bytes = workspace_bytes > wl.cmax_off ? workspace_bytes - wl.cmax_off : 0;
+  const bool brick_form = brick_form_ok(kv) && aux_bytes > 0 && brick_aux_fits(kv, aux_bytes);
+  const int split = brick_form && brick_split() ? 1 : 0;
   WinFn fn = nullptr;
   size_t win_lds = 0;
   if (!brick_form) switch (kv.D / 256) {
@@ -1220,6 +1225,14 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     }
     int r = check_launch("classify_window_kernel");
     if (r) return r;
+    if (split) {  // the brick form's build kernel: the window's hit records, sorted groups and scalar side, into the segment pool
+      WinArgs wa;
+      wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
+      ScopedPair t(prof, 3, f0, cs);
+      if ((r = launch_brick_build(kv, wa, tab, wl.img_bytes, reinterpret_cast<unsigned long long*>(stats), masks, wl.mask_plane,
+                                  ws + wl.cmax_off, aux_bytes, par, cs)))
+        return r;
+    }
     mark("classify: launches queued", w);
     if (ov && hipEventRecord(ov->cls_done[par], cs) != hipSuccess) return fail(SAF_E_HIP, "hipEventRecord");
     return SAF_OK;
@@ -1245,7 +1258,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       rc = launch_fuse_bricks(kv, wa, tab, maps, wl.img_bytes, reinterpret_cast<unsigned long long*>(stats),
                               reinterpret_cast<unsigned int*>(hdr), masks, wl.mask_plane,
                               reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff),
-                              ws + wl.cmax_off, s);
+                              ws + wl.cmax_off, aux_bytes, par, split, s);
     } else {
       ScopedPair t(prof, 2, f0, s);
       hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, tab, maps, img_vecs,

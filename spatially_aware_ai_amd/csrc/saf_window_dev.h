@@ -43,12 +43,16 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // The brick form of the window's row kernel (saf_brick.hip).  `ctr`: the header's unit counters (8 words, zeroed),
 // `map_imgs`: the window's pixel-major map images (img_bytes each), `hitmask`: the window's mask planes.
-// `aux`: brick_aux_bytes(D) of workspace (the channels' largest magnitudes and the window's camera table, filled by the
-// launcher on `s`).
+// `aux`: the rest of the workspace (saf_fuse_workspace_bytes reserves brick_aux_bytes_est): the channels' largest magnitudes and, per window parity, the camera table and the
+// pool of segments the build kernel (after the window's classification, on its stream) leaves for the walk kernel.
 bool brick_form_ok(const KVol& kv);
-size_t brick_aux_bytes(int D);
+bool brick_split();
+size_t brick_aux_bytes_est(int64_t n_vox, int D);
+bool brick_aux_fits(const KVol& kv, size_t avail);
+int launch_brick_build(const KVol& kv, const WinArgs& wa, const WinTable* tab, size_t img_bytes, unsigned long long* stats,
+                       const uint32_t* hitmask, uint32_t mask_plane, void* aux, size_t aux_bytes, int parity, hipStream_t s);
 int launch_fuse_bricks(const KVol& kv, const WinArgs& wa, const WinTable* tab, const float* map_imgs, size_t img_bytes,
                        unsigned long long* stats, unsigned int* ctr, const uint32_t* hitmask, uint32_t mask_plane,
-                       const unsigned long long* cls_acc, void* aux, hipStream_t s);
+                       const unsigned long long* cls_acc, void* aux, size_t aux_bytes, int parity, int split, hipStream_t s);
 
 }  // namespace saf

@@ -58,18 +58,34 @@ def _all_reduce(t, group):
         dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
 
 
-def _reduce_scatter_rows(t, group, rank, world):
+def _rows_per_piece(t, world):
+    """Rows of one rank block that one collective moves: world * rows * row_bytes <= _CHUNK_ELEMS * 4 bytes."""
+    row_elems = max(1, t[0].numel()) if t.dim() > 1 else 1
+    return max(1, _CHUNK_ELEMS // (world * row_elems))
+
+
+def _reduce_scatter_rows(t, group, rank, world, _force_collective=False):
     """Sum dim-0 row blocks across ranks so that rank k holds the reduced rows of voxel_shard(k);
-    other rows keep this rank's partial sums."""
+    other rows keep this rank's partial sums.
+
+    nccl (RCCL): issued in pieces of at most 1 GiB.  A piece is rows [j, j + c) of EVERY rank's block; RCCL wants the send
+    buffer contiguous, so the world slices are copied into a staging buffer (one strided device copy of 1 GiB, reused),
+    ``reduce_scatter_tensor`` sums them straight into this rank's slice of the volume.  (The earlier form handed the whole
+    34 GB volume to one in-place collective.)"""
     n = t.shape[0]
     per = n // world
     backend = dist.get_backend(group)
     if per > 0:
         main = t[: per * world]
-        if backend == "nccl":
-            # RCCL in-place form: the receive buffer is this rank's block of the send buffer
-            # (recvbuff == sendbuff + rank * recvcount), so no staging copy of the volume is made.
-            dist.reduce_scatter_tensor(main[rank * per : (rank + 1) * per], main, op=dist.ReduceOp.SUM, group=group)
+        if backend == "nccl" or _force_collective:
+            blocks = main.view((world, per) + tuple(main.shape[1:]))
+            c = min(per, _rows_per_piece(t, world))
+            stage = torch.empty((world, c) + tuple(main.shape[1:]), dtype=t.dtype, device=t.device)
+            for j in range(0, per, c):
+                cj = min(c, per - j)
+                src = stage[:, :cj] if cj == c else stage.view(-1)[: world * cj * blocks[0, 0].numel()].view((world, cj) + tuple(main.shape[1:]))
+                src.copy_(blocks[:, j : j + cj])
+                dist.reduce_scatter_tensor(blocks[rank, j : j + cj], src, op=dist.ReduceOp.SUM, group=group)
         else:  # gloo has no reduce_scatter: one rooted reduce per destination
             for k in range(world):
                 dist.reduce(main[k * per : (k + 1) * per], dst=dist.get_global_rank(group, k) if group else k,
@@ -80,20 +96,49 @@ def _reduce_scatter_rows(t, group, rank, world):
         dist.reduce(tail, dst=dist.get_global_rank(group, dst) if group else dst, op=dist.ReduceOp.SUM, group=group)
 
 
-def _all_gather_rows(t, group, rank, world):
+def _all_gather_rows(t, group, rank, world, _force_collective=False):
+    """Every rank's reduced block to every rank, in pieces of at most 1 GiB (nccl: ``all_gather_into_tensor`` into a
+    staging buffer, one strided copy back into the world blocks)."""
     n = t.shape[0]
     per = n // world
     if per > 0:
         main = t[: per * world]
-        if dist.get_backend(group) == "nccl":
-            # RCCL in-place form (sendbuff == recvbuff + rank * sendcount): no full-volume temporary
-            dist.all_gather_into_tensor(main, main[rank * per : (rank + 1) * per], group=group)
+        if dist.get_backend(group) == "nccl" or _force_collective:
+            blocks = main.view((world, per) + tuple(main.shape[1:]))
+            c = min(per, _rows_per_piece(t, world))
+            stage = torch.empty((world, c) + tuple(main.shape[1:]), dtype=t.dtype, device=t.device)
+            for j in range(0, per, c):
+                cj = min(c, per - j)
+                dst = stage[:, :cj] if cj == c else stage.view(-1)[: world * cj * blocks[0, 0].numel()].view((world, cj) + tuple(main.shape[1:]))
+                dist.all_gather_into_tensor(dst, blocks[rank, j : j + cj].contiguous(), group=group)
+                blocks[:, j : j + cj].copy_(dst)
         else:
             outs = [main[k * per : (k + 1) * per] for k in range(world)]
             dist.all_gather(outs, main[rank * per : (rank + 1) * per].clone(), group=group)
     if n > per * world:
         src = world - 1
         dist.broadcast(t[per * world :], src=dist.get_global_rank(group, src) if group else src, group=group)
+
+
+def probe_collectives(device, group=None):
+    """Run the reduce-scatter / all-gather forms ``merge_sums`` would use on a small tensor and check the sums: decides the
+    merge mode BEFORE any volume is touched (a collective that raises half-way through a volume cannot be retried with
+    another one -- the rows that were already summed would be summed twice).  Returns None, or what went wrong."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    try:
+        n = 4 * world + 3
+        t = (torch.arange(n * 6, dtype=torch.float32, device=device).view(n, 6) + 1.0) * (rank + 1)
+        want = (torch.arange(n * 6, dtype=torch.float32, device=device).view(n, 6) + 1.0) * (world * (world + 1) / 2)
+        _reduce_scatter_rows(t, group, rank, world)
+        first, count = voxel_shard(n, rank, world)
+        if not torch.equal(t[first : first + count], want[first : first + count]):
+            return "reduce-scatter probe: wrong sums"
+        _all_gather_rows(t, group, rank, world)
+        if not torch.equal(t, want):
+            return "all-gather probe: wrong rows"
+    except Exception as e:  # noqa: BLE001 -- whatever the backend raises is the answer
+        return f"{type(e).__name__}: {e}"[:200]
+    return None
 
 
 def slab_of_rank(nx: int, rank: int, world: int):
@@ -132,7 +177,17 @@ def gather_frames(tensors, group=None):
         t = t.contiguous()
         full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         if dist.get_backend(group) == "nccl":
-            dist.all_gather_into_tensor(full, t, group=group)
+            out_blocks = full.view((world, t.shape[0]) + tuple(t.shape[1:]))
+            c = min(t.shape[0], _rows_per_piece(t, world))
+            if c == t.shape[0]:
+                dist.all_gather_into_tensor(full, t, group=group)
+            else:  # pieces of at most 1 GiB: a staging buffer per piece, one strided copy into the rank blocks
+                stage = torch.empty((world, c) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                for j in range(0, t.shape[0], c):
+                    cj = min(c, t.shape[0] - j)
+                    dst = stage.view(-1)[: world * cj * t[0].numel()].view((world, cj) + tuple(t.shape[1:]))
+                    dist.all_gather_into_tensor(dst, t[j : j + cj], group=group)
+                    out_blocks[:, j : j + cj].copy_(dst)
         else:
             dist.all_gather(list(full.split(t.shape[0])), t, group=group)
         out.append(full)

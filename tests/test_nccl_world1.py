@@ -1,0 +1,59 @@
+"""RCCL has to execute the collectives of the merge at least once on the hardware the tests see: one GPU.  A child process
+brings up backend ``nccl`` with world_size 1 and drives the nccl-only branches of distributed.py (staged, chunked
+reduce-scatter / all-gather into the volume, the frame exchange) with the ``world == 1`` early return of ``merge_sums``
+bypassed; with one rank every sum is the identity, so the tensors must come back unchanged -- what is tested is that torch's
+and RCCL's argument checks accept the calls (in-place views, staging shapes, several pieces, a remainder tail)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_CHILD = textwrap.dedent('''
+    import os, sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["SAF_REPO"])
+    from spatially_aware_ai_amd import distributed as sd
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ["SAF_PORT"], world_size=1, rank=0)
+    dev = torch.device("cuda", 0)
+    sd._CHUNK_ELEMS = 1 << 12          # many pieces, a ragged last one
+    g = torch.Generator(device=dev).manual_seed(3)
+    for shape in ((1000, 24), (257, 3), (4099,), (130, 143)):
+        t = torch.randn(shape, generator=g, device=dev) if len(shape) > 1 or True else None
+        if shape == (130, 143):
+            t = torch.randint(0, 9, shape, generator=g, device=dev, dtype=torch.int32)
+        ref = t.clone()
+        sd._reduce_scatter_rows(t, None, 0, 1)
+        assert torch.equal(t, ref), ("reduce-scatter changed a one-rank tensor", shape)
+        sd._all_gather_rows(t, None, 0, 1)
+        assert torch.equal(t, ref), ("all-gather changed a one-rank tensor", shape)
+    fr = [torch.randn((9, 16, 12), generator=g, device=dev), None, torch.randn((9, 4, 4), generator=g, device=dev)]
+    out = sd.gather_frames(fr)
+    assert out[1] is None and torch.equal(out[0], fr[0]) and torch.equal(out[2], fr[2])
+    assert sd.probe_collectives(dev) is None
+    x = torch.ones(5, device=dev)
+    dist.all_reduce(x)
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    print("NCCL_WORLD1_OK")
+''')
+
+
+def test_nccl_collectives_of_the_merge_run_at_world_size_one(tmp_path):
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD)
+    env = dict(os.environ, SAF_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), SAF_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
