@@ -58,7 +58,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", type=int, default=256, help="voxels per axis")
+    ap.add_argument("--grid", default="256", help="voxels per axis, or nx,ny,nz (a ragged grid like the reference's 127,104,116; "
+                    "the longest edge spans 2.56 m)")
     ap.add_argument("--dim", type=int, default=512, help="feature dim D")
     ap.add_argument("--frames", type=int, default=512, help="frames per rank per step")
     ap.add_argument("--width", type=int, default=640)
@@ -96,7 +97,14 @@ def parse():
                     help="benchmark the text-query scan instead (BASELINE config 5 and the reference's L = 5 / L = 63 scans)")
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="record HIP events around the kernels of every n-th frame of the timed region")
-    return ap.parse_args()
+    a = ap.parse_args()
+    g3 = tuple(int(x) for x in str(a.grid).split(","))
+    if len(g3) == 1:
+        g3 = g3 * 3
+    assert len(g3) == 3 and min(g3) > 0, "--grid takes N or nx,ny,nz"
+    a.grid3 = g3
+    a.grid = g3[0] if g3[0] == g3[1] == g3[2] else "x".join(str(x) for x in g3)  # (label; cubic grids keep the integer)
+    return a
 
 
 def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device):
@@ -186,7 +194,7 @@ def main():
     from spatially_aware_ai_amd import distributed as sdist
 
     npy, npx = syn.feature_map_shape(a.width, a.height)
-    grid = syn.make_grid(a.grid)
+    grid = syn.make_grid(a.grid3, side=2.56 * a.grid3[0] / max(a.grid3))
     n_vox = grid.n_voxels
 
     class ResidentFeatures:  # stands in for the CLIP backbone: feature maps are already in HBM
@@ -652,7 +660,7 @@ def bench_query(a, world, rank, local_rank):
     from spatially_aware_ai_amd import distributed as sdist
     from spatially_aware_ai_amd.clipfusion import _query_scan, query_scan_wide
 
-    n_all = a.grid ** 3
+    n_all = a.grid3[0] * a.grid3[1] * a.grid3[2]
     first, n = sdist.voxel_shard(n_all, rank, world)
     d, q, n_bg = a.dim, a.queries, 4
     g = torch.Generator(device=device).manual_seed(100 + rank)

@@ -150,9 +150,10 @@ int saf_fuse_path(const saf_volume* vol, const saf_frame* frames, int32_t n_fram
 int saf_clear_unwritten_rows(const saf_volume* vol, int64_t first_voxel, int64_t n_voxels, void* stream);
 
 /* The per-frame pipeline hands sweep(i) to fuse(i) on the device; a fuse workgroup that waited ~2 s without
- * seeing its sweep gives up (stats[4]) and sets a host-visible latch.  Once set, saf_fuse_frame(s) on that
- * device return SAF_E_HIP (the volume of the earlier call is incomplete); this polls the latch without
- * launching anything. */
+ * seeing its sweep gives up (stats[4]) and sets a host-visible latch.  The NEXT saf_fuse_frame(s) call on that
+ * device -- or this poll, which launches nothing -- returns SAF_E_HIP once (the volume of the earlier call is
+ * incomplete; its stats[4] says so for as long as the volume lives) and clears the latch: a stall that has passed
+ * does not disable fusion for the rest of the process. */
 int saf_poll_async_error(void);
 
 /*

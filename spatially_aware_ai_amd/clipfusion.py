@@ -45,6 +45,12 @@ def _axis_tables(origin, voxel_size, nvox, index_offset=(0, 0, 0), x_planes=None
         idx[0] = torch.as_tensor(x_planes, dtype=torch.int64).detach().cpu()
         if idx[0].dim() != 1 or idx[0].numel() != int(nvox[0]):
             raise ValueError("x_planes must list nvox[0] x indices")
+        # The windowed path classifies 4 x 4 x 16 bricks against a bounding sphere built from a brick's first and last
+        # x-plane: every group of 4 consecutive entries must be 4 consecutive planes (a rank's slab is made of whole blocks).
+        if int(nvox[0]) % 4 == 0:
+            q = idx[0].view(-1, 4)
+            if not bool((q[:, 1:] - q[:, :-1] == 1).all()):
+                raise ValueError("x_planes must consist of runs of 4 consecutive x indices (blocks of slab_planes_of_rank)")
     return [(idx[a] * voxel_size + origin[a]).to(torch.float32).contiguous() for a in range(3)]
 
 
@@ -327,15 +333,21 @@ class _FusionVolumeMixin:
             return
         self.__dict__["_pending_n"] = 0  # first: the buffer accesses below must not re-enter
         st = self.__dict__["_stage"]
-        labs = None if st["labels"] is None else st["labels"][:n]
-        feat = st["feat"][:n]
-        if st.get("lazy") is not None:  # the queued frames' feature maps, in one backbone batch
-            fn, ac_on, ac_dtype = st["lazy"]
-            with torch.no_grad(), torch.autocast("cuda", dtype=ac_dtype, enabled=ac_on):
-                feat = fn(st["rgb"][:n])
-            if tuple(feat.shape) != (n,) + tuple(st["key"][2]):
-                raise SafError(f"the backbone returned {tuple(feat.shape)} for {n} frames, expected {(n,) + tuple(st['key'][2])}")
-        self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], feat, labs, st["key"][4])
+        try:
+            labs = None if st["labels"] is None else st["labels"][:n]
+            feat = st["feat"][:n]
+            if st.get("lazy") is not None:  # the queued frames' feature maps, in one backbone batch
+                fn, ac_on, ac_dtype = st["lazy"]
+                with torch.no_grad(), torch.autocast("cuda", dtype=ac_dtype, enabled=ac_on):
+                    feat = fn(st["rgb"][:n])
+                if tuple(feat.shape) != (n,) + tuple(st["key"][2]):
+                    raise SafError(f"the backbone returned {tuple(feat.shape)} for {n} frames, expected {(n,) + tuple(st['key'][2])}")
+            self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], feat, labs, st["key"][4])
+        except BaseException:
+            # the backbone or the fuse call failed (out of memory, an unsupported tiling): the frames stay queued -- the next
+            # access raises again instead of reading a volume that silently lacks them
+            self.__dict__["_pending_n"] = n
+            raise
         dev = self._buffers["tsdf"].device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)
@@ -372,7 +384,12 @@ class _FusionVolumeMixin:
 
     def _load_from_state_dict(self, *args, **kwargs):
         self._sync_volume()
-        return super()._load_from_state_dict(*args, **kwargs)
+        out = super()._load_from_state_dict(*args, **kwargs)
+        # The windowed path never reads the feature row of a voxel whose weight is 0 (such a row is zero by construction).  A
+        # loaded state need not keep that promise: the rows of weight-0 voxels are zeroed at the next access (the deferred
+        # clear of reset(): saf_clear_unwritten_rows), so the invariant is enforced, not assumed.
+        self.__dict__["_feat_stale"] = True
+        return out
 
     def named_buffers(self, *args, **kwargs):
         self._sync_volume()
@@ -750,14 +767,22 @@ class Clip(torch.nn.Module):
 
     def img_inference_tiled(self, rgb_imgs, patch_size, patch_stride):
         """[B,3,H,W] in 0..1 -> [B,D,npy,npx] CLIP embedding per tile (clipfusion.py:808-839)."""
-        patches = self.tiles_224(rgb_imgs, patch_size, patch_stride)
         bsz = rgb_imgs.shape[0]
         npy = 1 + (rgb_imgs.shape[2] - patch_size) // patch_stride
         npx = 1 + (rgb_imgs.shape[3] - patch_size) // patch_stride
-        feats = torch.empty(len(patches), self.feature_dim, device=rgb_imgs.device)
+        per_frame = npy * npx
+        feats = torch.empty(bsz * per_frame, self.feature_dim, device=rgb_imgs.device)
         step = int(self.max_patch_batch_size)
-        for start in range(0, len(patches), step):
-            feats[start : start + step] = self.clip.encode_image(patches[start : start + step])
+        # The tile batch is produced in slices of whole frames -- at most max_patch_batch_size tiles (and never more than the
+        # tile kernel's 65535 per launch) exist at a time: the deferred-backbone queue hands over up to 512 frames at once,
+        # whose tiles would be tens of GB (a fine tiling has hundreds of tiles per frame).
+        fpb = max(1, min(step, 65535) // per_frame)
+        for f0 in range(0, bsz, fpb):
+            patches = self.tiles_224(rgb_imgs[f0 : f0 + fpb], patch_size, patch_stride)
+            base = f0 * per_frame
+            for start in range(0, len(patches), step):
+                cur = patches[start : start + step]
+                feats[base + start : base + start + len(cur)] = self.clip.encode_image(cur)
         return feats.view(bsz, npy, npx, self.feature_dim).permute(0, 3, 1, 2)
 
     def img_inference_tiled_depthscaled(self, rgb_imgs, depth_imgs, K, patch_stride):

@@ -286,10 +286,11 @@ __device__ __forceinline__ uint32_t slab_max_bits(const uint32_t* __restrict__ c
 }
 
 // What the build and the walk kernel share of the pool
+constexpr uint32_t kOverWords = 1 + kBV + 3;  // (68: entries stay 16-byte aligned)
 struct BrickPool {
   unsigned char* segs;   // cap segments of kSegBytes
   uint2* list;           // per listed brick: first segment, rounds
-  uint32_t* over;        // brick codes
+  uint32_t* over;        // per overflow brick kOverWords words: the brick's code, then its voxels' weights before this window
   BrickCtl* ctl;
   uint32_t cap;
   int split;             // 0: no build kernel ran -- the walk kernel takes every brick from the XCD counters and builds it itself
@@ -564,7 +565,10 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
         }
       } else if (pool.split) {
         const uint32_t o = atomicAdd(&pool.ctl->over_next, 1u);
-        if (o < pool.ctl->over_n) code = pool.over[o];
+        if (o < pool.ctl->over_n) {
+          code = pool.over[(size_t)o * kOverWords];
+          L.misc[6] = o;
+        }
       } else
       while (xcd_tries < 8u) {
         const uint32_t my_tiles = (n_tiles + 7u - xcd) / 8u;
@@ -609,12 +613,10 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
     int w_cur = 0;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
     if (any) {
-      w_cur = v.weight[n];
+      if (!redo) w_cur = v.weight[n];
       if (redo) {
-        int h = 0;
-#pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) h += __popc(mk[w]);
-        w_cur -= h;
+        // (NOT the stored weight minus this window's hits: the next window's build kernel may already have added its own)
+        w_cur = (int)pool.over[(size_t)L.misc[6] * kOverWords + 1 + tid];
       } else {
         const float* src = v.rgb + (int64_t)n * 3;
         o0 = src[0]; o1 = src[1]; o2 = src[2];
@@ -684,13 +686,17 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
           pool.list[atomicAdd(&pool.ctl->list_n, 1u)] = make_uint2(b0, (uint32_t)n_r);
           L.misc[5] = b0;
         } else {
-          pool.over[atomicAdd(&pool.ctl->over_n, 1u)] = code;
+          const uint32_t o = atomicAdd(&pool.ctl->over_n, 1u);
+          pool.over[(size_t)o * kOverWords] = code;
           L.misc[5] = 0xffffffffu;
+          L.misc[6] = o;
         }
       }
       lds_barrier();
       seg_base = (uint32_t)rfl((int)L.misc[5]);
       seg_round = 0;
+      if (seg_base == 0xffffffffu && vth)  // the walk kernel rebuilds this brick: it needs the weights as they are NOW
+        pool.over[(size_t)L.misc[6] * kOverWords + 1 + tid] = (uint32_t)w_cur;
       // (a brick without segments still gets its scalar side here; the walk kernel rebuilds its records)
     }
     int f0 = 0;
@@ -965,7 +971,7 @@ struct AuxLayout {
 };
 size_t aux_fixed(uint32_t nb) {
   return pad256((size_t)kWin * kCamFloats * sizeof(float)) + pad256(sizeof(BrickCtl)) + pad256((size_t)nb * sizeof(uint2)) +
-         pad256((size_t)nb * sizeof(uint32_t));
+         pad256((size_t)nb * kOverWords * sizeof(uint32_t));
 }
 AuxLayout aux_layout(const KVol& kv, size_t avail) {
   AuxLayout a;
@@ -974,12 +980,16 @@ AuxLayout aux_layout(const KVol& kv, size_t avail) {
   a.ctl = a.cams + pad256((size_t)kWin * kCamFloats * sizeof(float));
   a.list = a.ctl + pad256(sizeof(BrickCtl));
   a.over = a.list + pad256((size_t)nb * sizeof(uint2));
-  a.segs = a.over + pad256((size_t)nb * sizeof(uint32_t));
+  a.segs = a.over + pad256((size_t)nb * kOverWords * sizeof(uint32_t));
   a.fits = avail >= cmax_bytes(kv.D) + 2 * a.segs;
   const size_t per_parity = a.fits ? (avail - cmax_bytes(kv.D)) / 2 : a.segs;
   a.parity_bytes = per_parity & ~(size_t)255;
   const size_t want = (size_t)nb + nb / 4 + 64, room = (a.parity_bytes - a.segs) / kSegBytes;
   a.cap = (uint32_t)(room < want ? room : want);
+  if (const char* e = getenv("SAF_BRICK_POOL_CAP")) {  // development / tests: a small pool drives bricks into the overflow list
+    const long c = atol(e);
+    if (c >= 0 && (uint32_t)c < a.cap) a.cap = (uint32_t)c;
+  }
   return a;
 }
 BrickPool make_pool(const KVol& kv, void* aux, size_t aux_bytes, int parity, int split, const float** cams) {
@@ -998,14 +1008,19 @@ BrickPool make_pool(const KVol& kv, void* aux, size_t aux_bytes, int parity, int
 
 }  // namespace
 
-// The brick form takes every grid shape (partial bricks are masked) and every feat_dim that is a multiple of 64;
-// SAF_WIN_FORM=rows (read per call) keeps the frame-ordered row kernel.
+// The brick form takes every grid shape (partial bricks are masked) and every feat_dim that is a multiple of 64.  It is
+// the default for the feature widths the frame-ordered row kernel does not take (it wants whole 1 KiB pieces of a row:
+// feat_dim a multiple of 256 up to 1024, of 512 for bf16) -- those used to fall back to the per-frame pipeline -- and what
+// SAF_WIN_FORM=bricks (read per call) asks for; SAF_WIN_FORM=rows never uses it.
 bool brick_form_ok(const KVol& kv) {
   const char* e = getenv("SAF_WIN_FORM");
   if (e && e[0] == 'r') return false;
   if (kv.D % 64 != 0 || kv.D > 8192) return false;
   const uint32_t nbx = ((uint32_t)kv.nx + kBX - 1) / kBX, nby = ((uint32_t)kv.ny + kBY - 1) / kBY, nbz = ((uint32_t)kv.nz + kBZ - 1) / kBZ;
-  return nbx < 1024u && nby < 1024u && nbz < 1024u;  // the brick code of a workgroup is three 10-bit fields
+  if (nbx >= 1024u || nby >= 1024u || nbz >= 1024u) return false;  // the brick code of a workgroup is three 10-bit fields
+  if (e && e[0] == 'b') return true;
+  const bool rows_take_it = kv.D % 256 == 0 && kv.D <= 1024 && (!kv.bf16 || kv.D % 512 == 0);
+  return !rows_take_it;
 }
 // SAF_BRICK_SPLIT=0 (read per call): no build kernel, the walk kernel builds every brick itself
 bool brick_split() {

@@ -911,10 +911,14 @@ int ensure_latch() {
 int poll_latch() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return SAF_OK;
-  const int* h = g_latch_host[dev];
-  if (h && *reinterpret_cast<const volatile int*>(h) != 0)
+  int* h = g_latch_host[dev];
+  if (h && *reinterpret_cast<volatile int*>(h) != 0) {
+    // reported ONCE, then cleared: the call that dropped frames is what is wrong, not the device -- a stall that has passed
+    // (a debugger stop, another tenant) must not disable fusion for the life of the process
+    *reinterpret_cast<volatile int*>(h) = 0;
     return fail(SAF_E_HIP, "an earlier saf_fuse_frames call on this device dropped frames: fuse workgroups timed out "
-                           "waiting for their frame's sweep (stats[4]); the volume is incomplete");
+                           "waiting for their frame's sweep (stats[4] of that volume); that volume is incomplete");
+  }
   return SAF_OK;
 }
 

@@ -156,6 +156,8 @@ def slab_planes_of_rank(nx: int, rank: int, world: int, block: int = 16):
     and block b goes to rank (b mod B/2) mod world: a rank's block in the left half is as far out as its block in the right
     half is far in.  Falls back to the contiguous slab of ``slab_of_rank`` when the blocks do not divide evenly.  Returns
     the x indices, ascending."""
+    if block % 4 != 0:
+        raise ValueError("block must be a multiple of 4 (the classification's bricks are 4 x-planes wide)")
     nb = nx // block
     if nx % block != 0 or nb % (2 * world) != 0:
         first, cnt = slab_of_rank(nx, rank, world)
