@@ -82,11 +82,13 @@ def parse():
                     help="ClipSeemFusion path: panoptic label histogram + bilinear rgb (BASELINE config 3)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile-events", action="store_true")
-    ap.add_argument("--end-to-end", type=int, default=0, metavar="FRAMES",
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side workloads of the default single-GPU run (configs 2, 3, 5, the coherent scene, the HBM copy rate)")
+    ap.add_argument("--end-to-end", type=int, default=-1, metavar="FRAMES",
                     help="after the timed region, also time FRAMES frames through the reference-shaped API with a "
                          "ViT-B/32-shaped random-weight CLIP image tower in front of the fuse (reported separately)")
-    ap.add_argument("--e2e-batch", type=int, default=8, help="frames per integrate() call in the end-to-end pass")
-    ap.add_argument("--e2e-dtype", default="f32", choices=["f32", "bf16"], help="backbone compute dtype")
+    ap.add_argument("--e2e-batch", type=int, default=1, help="frames per integrate() call in the end-to-end pass")
+    ap.add_argument("--e2e-dtype", default="bf16", choices=["f32", "bf16"], help="backbone compute dtype")
     ap.add_argument("--e2e-tile-batch", type=int, default=0, help="tiles per encode_image call (0 = the Clip class's default)")
     ap.add_argument("--api-b1", type=int, default=0, metavar="FRAMES",
                     help="also time FRAMES frames through integrate_features() ONE FRAME PER CALL (the reference's loop, "
@@ -103,6 +105,8 @@ def parse():
         g3 = g3 * 3
     assert len(g3) == 3 and min(g3) > 0, "--grid takes N or nx,ny,nz"
     a.grid3 = g3
+    if a.end_to_end < 0:  # default: on for the plain single-GPU run (128 frames, one frame per integrate() call, bf16 tower)
+        a.end_to_end = 128 if (a.gpus == 1 and not a.query and not a.labels and a.dim == 512 and not a.no_side) else 0
     a.grid = g3[0] if g3[0] == g3[1] == g3[2] else "x".join(str(x) for x in g3)  # (label; cubic grids keep the integer)
     return a
 
@@ -588,6 +592,16 @@ def main():
     if a.api_b1 > 0 and rank == 0 and world == 1:
         api_b1 = bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, value)
 
+    # ---- the other configurations and the copy rate of this box, measured in this run (rank 0, N = 1) ----
+    side, copy_rate = None, None
+    if rank == 0 and world == 1 and not a.no_side and isinstance(a.grid, int) and a.grid == 256 and a.depth_kind == "A" and not a.labels \
+            and a.feat_dtype == "f32" and a.width == 640 and a.height == 480:
+        copy_rate = hbm_copy_rate(device)
+        side = side_workloads(a, device, L, (depth, rgb, poses, ks, feat), npy, npx)
+    if roofline is not None and copy_rate is not None:
+        roofline["hbm_copy_GBps"] = copy_rate
+        roofline["frac_of_copy_rate"] = round(roofline["achieved"] / copy_rate, 4)
+
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1 only) ----
     cpu = None
     if rank == 0 and world == 1 and a.cpu_frames != 0:
@@ -624,6 +638,8 @@ def main():
             "kernel_breakdown": breakdown,
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "hbm_copy_GBps": copy_rate,
+            "side_workloads": side,
         }
         if api_b1 is not None:
             out["api_b1"] = api_b1
@@ -631,6 +647,145 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+
+def hbm_copy_rate(device, nbytes=4 << 30, reps=3):
+    """Device-to-device copy rate measured in this run (read + write bytes per second), beside the 8 TB/s spec peak."""
+    x = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    y = torch.empty_like(x)
+    y.copy_(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    s = e0.elapsed_time(e1) * 1e-3 / reps
+    return round(2 * nbytes / s / 1e9, 1)
+
+
+def side_workloads(a, device, L, frames_A, npy, npx):
+    """The other BASELINE configurations on the same box, each a short timed job with its own roofline (rank 0, N = 1):
+    config 2 (128^3 x 512 f32), config 3 (256^3 bf16 + panoptic label histogram), the coherent scene (depth B), config 5
+    (1000 fp16 queries over 256^3 x 512: per-voxel best query, heat maps, per-query best voxel).  About ten seconds."""
+    from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
+    from spatially_aware_ai_amd.clipfusion import query_scan_wide
+
+    t_begin = time.perf_counter()
+    depth, rgb, poses, ks, feat = frames_A
+    uniq = depth.shape[0]
+    n_frames = 512
+    out = {}
+
+    class Resident:
+        feature_dim = a.dim
+
+    def fuse_case(name, nvox, fdt, labels, fr, note):
+        grid = syn.make_grid(nvox)
+        d_, r_, p_, k_, f_ = fr
+        if labels:
+            fz = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, a.height // 3, a.height // 6,
+                                Resident(), None, keep_xyz_world=False, feat_dtype=fdt).to(device)
+            gl = torch.Generator(device=device).manual_seed(77)
+            lm = torch.randint(0, 134, (d_.shape[0], a.height, a.width), generator=gl, device=device).float()
+        else:
+            fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, Resident(), None, a.height // 3,
+                            a.height // 6, keep_xyz_world=False, feat_dtype=fdt).to(device)
+            lm = None
+        arr_u, keep, _, _ = fz._make_frames(d_, r_, p_, k_, f_, lm, labels)
+        arr = (_abi.SafFrame * n_frames)()
+        for i in range(n_frames):
+            arr[i] = arr_u[i % d_.shape[0]]
+        ws = fz._get_workspace(npy, npx)
+        stream = torch.cuda.current_stream().cuda_stream
+        prof = L.saf_profiler_create(3 * n_frames)
+        L.saf_profiler_set_stride(prof, 4)
+        esz = 2 if fdt == torch.bfloat16 else 4
+
+        def job(p):
+            fz.reset()
+            vol = fz._c_volume(for_fuse=True)
+            check(L.saf_fuse_frames_profiled(C.byref(vol), arr, n_frames, ws.data_ptr(), ws.numel(),
+                                             fz._buffers["fuse_stats"].data_ptr(), p, stream), "side workload")
+            fz.flush()
+
+        job(None)
+        torch.cuda.synchronize()
+        fz.fuse_stats.zero_()
+        t0 = time.perf_counter()
+        job(prof)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = fz.stats()
+        tot, n = C.c_double(0), C.c_int64(0)
+        check(L.saf_profiler_read(prof, 2, C.byref(tot), C.byref(n)), "saf_profiler_read")
+        L.saf_profiler_destroy(prof)
+        lab = 8 if labels else 0
+        n_win = (n_frames + WIN - 1) // WIN
+        uv = st["window_rows"] / n_win
+        fuse_bytes = (uv * (2 * a.dim * esz + 2 * 12 + 2 * 4 + lab)
+                      + n_frames / n_win * (a.height * a.width * (12 + (4 if labels else 0)) + a.dim * npy * npx * 4))
+        kern = tot.value / max(1, n.value) * 1e-3
+        out[name] = {
+            "value": round(n_frames / dt, 1), "unit": "frames/s", "ms_per_job": round(dt * 1e3, 2), "frames": n_frames,
+            "workload": note, "valid_voxels_per_frame": round(st["valid"] / n_frames, 1),
+            "hits_per_row": round(st["valid"] / max(1, st["window_rows"]), 2),
+            "roofline": {"kernel": "fuse_window_kernel" if os.environ.get("SAF_WIN_FORM", "r")[0] != "b" else "fuse_brick_kernel",
+                         "bound": "hbm", "achieved": round(fuse_bytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(fuse_bytes / kern / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_us": round(kern * 1e6, 1), "launches": int(n.value),
+                         "algorithmic_bytes_per_launch": int(fuse_bytes)}}
+        del fz, ws, keep
+        torch.cuda.empty_cache()
+
+    fuse_case("config2_128cube_f32", 128, torch.float32, False, frames_A,
+              "BASELINE config 2's shape: 512 frames 640x480 (depth A) into a 128^3 x 512 fp32 grid (resident ViT-B/32-shaped features)")
+    if a.dim % 512 == 0:
+        fuse_case("config3_256cube_bf16_labels", 256, torch.bfloat16, True, frames_A,
+                  "BASELINE config 3's fused part: 512 frames into a 256^3 x 512 bf16 grid + the 143-class label histogram")
+    nb = min(128, uniq)
+    frames_B = gen_frames_gpu(nb, a.width, a.height, a.dim, npy, npx, "B", 2000, device)
+    fuse_case("coherent_scene_depth_B", 256, torch.float32, False, frames_B,
+              "the headline job on the coherent analytic scene (sphere in a box, SURVEY 8d depth B): 512 frames (128 unique), 256^3 x 512 fp32")
+    del frames_B
+
+    # ---- config 5: 1000 fp16 queries over the 256^3 x 512 volume
+    n, d, q, n_bg = 256 ** 3, a.dim, 1000, 4
+    g = torch.Generator(device=device).manual_seed(100)
+    feats16 = torch.empty((n, d), dtype=torch.float16, device=device)
+    for s0 in range(0, n, 1 << 20):
+        feats16[s0:s0 + (1 << 20)] = torch.randn((min(1 << 20, n - s0), d), generator=g, device=device).half()
+    text = torch.randn((n_bg + q, d), generator=torch.Generator().manual_seed(9))
+    text = (text / text.norm(dim=-1, keepdim=True)).to(device)
+    big = torch.empty((n, (q + 7) // 8 * 8), dtype=torch.float16, device=device)[:, :q]
+
+    def scan_case(name, fn, n_q, out_bytes):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        kern = e0.elapsed_time(e1) * 1e-3 / 2
+        flop = 2.0 * n * d * n_q
+        out[name] = {"value": round(q / kern, 1), "unit": "queries/s", "ms": round(kern * 1e3, 3),
+                     "workload": f"{q} fp16 queries over {n} voxel rows x {d} (BASELINE config 5)",
+                     "roofline": {"kernel": "query_wide2_kernel", "bound": "mfma", "achieved": round(flop / kern / 1e12, 1),
+                                  "peak": MFMA16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / kern / 1e12 / MFMA16_PEAK_TFLOPS, 4),
+                                  "traffic": None, "algorithmic_bytes_per_launch": int(n * d * 2 + n_q * d * 2 + out_bytes)}}
+
+    scan_case("config5_row_argmax", lambda: query_scan_wide(feats16, text[n_bg:], "row_argmax"), q, n * 8)
+    scan_case("config5_heat_maps", lambda: query_scan_wide(feats16, text, "vs_background", scale=100.0, n_background=n_bg,
+                                                             rescale=True, out=big), q + n_bg, n * q * 2)
+    scan_case("config5_query_max", lambda: query_scan_wide(feats16, text[n_bg:], "query_max"), q, q * 12)
+    del feats16, big
+    torch.cuda.empty_cache()
+    out["seconds"] = round(time.perf_counter() - t_begin, 1)
+    return out
 
 
 MFMA16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak of MI355X (guides/MI355X_MICROARCH.md)
