@@ -354,6 +354,45 @@ def main():
         voxel_sharded = bench_voxel_sharded(a, dist, sdist, grid, fusions, (depth, rgb, poses, ks, feat, label_maps), new_volume,
                                             world, rank, device, L, stream, npy, npx)
 
+    # ---- timed region 4 (N > 1): ONE job with its merge pipelined slab by slab (BASELINE config 4's own layout) ----
+    slab_pipe = None
+    if world > 1 and merge_state["mode"] in ("reduce_scatter", "all_reduce"):
+        n_slabs = 8
+
+        def pipe_job():
+            fusion.reset(accum_mode=_abi.SAF_SUM)
+            return sdist.fuse_merge_pipelined(fusion, frames, a.frames, ws, n_slabs=n_slabs, comm_stream=comm_stream,
+                                              mode=merge_state["mode"], stats_ptr=stats_ptr)
+
+        pipe_job()
+        barrier()
+        fusion.fuse_stats.zero_()
+        t0 = time.perf_counter()
+        stripes = None
+        for _ in range(a.steps):
+            stripes = pipe_job()
+        barrier()
+        dt4 = time.perf_counter() - t0
+        tmax = torch.tensor([dt4], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt4 = float(tmax.item())
+        st4 = fusion.stats()
+        # integrity: over all ranks, the weights of the owned stripes add up to the valid hits of all ranks' frames
+        own_w = sum(int(fusion.weight[f:f + c].sum(dtype=torch.int64)) for f, c in stripes)
+        sums = torch.tensor([own_w, st4["valid"]], dtype=torch.int64, device=device)
+        dist.all_reduce(sums)
+        w_all, v_all = (int(x) for x in sums.tolist())
+        if merge_state["mode"] == "all_reduce":
+            w_all //= world
+        assert w_all * a.steps == v_all, f"slab-pipelined merge: owned weights {w_all} x {a.steps} steps != valid hits {v_all}"
+        fusion.accum_mode = _abi.SAF_RUNNING_MEAN
+        slab_pipe = {"value": round(total_frames / dt4, 2), "unit": "frames/s", "ms_per_step": round(dt4 / a.steps * 1e3, 3),
+                     "slabs": n_slabs, "merge_check": {"owned_weight_sum_all_ranks": w_all, "valid_hits_all_ranks_per_step": v_all // a.steps},
+                     "note": "the same single job as `value` (config 4's layout: frames sharded, one per-rank volume, one merge) with "
+                             "the merge issued slab by slab on a communication stream while the next slab is fused; rank k ends "
+                             "with the k-th part of every slab"}
+        fusion.fuse_stats.zero_()
+
     # ---- N > 1: the merged shard of a small sharded job against a single-rank fusion of ALL its frames ----
     if world > 1 and a.check_frames > 0:
         merge_check.update(check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, (depth, rgb, poses, ks, feat, label_maps),
@@ -592,6 +631,41 @@ def main():
     if a.api_b1 > 0 and rank == 0 and world == 1:
         api_b1 = bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, value)
 
+    # ---- N = 1: the job fused slab by slab (what the slab-pipelined merge of N > 1 does between its collectives) ----
+    slabwise = None
+    if rank == 0 and world == 1 and windowed_headline(st) and not a.no_side:
+        n_slabs = 8
+        bounds = sdist.slab_bounds(int(grid.nvox[0]), n_slabs)
+
+        def whole():
+            fusion.reset()
+            fusion.flush()
+            fuse_into(fusion, frames, a.frames, None)
+
+        def by_slab():
+            fusion.reset()
+            fusion.flush()
+            for x0, cnt in bounds:
+                vol = sdist.slab_descriptor(fusion, x0, cnt)
+                check(L.saf_fuse_frames_profiled(C.byref(vol), frames, a.frames, ws.data_ptr(), ws.numel(), stats_ptr, None, stream),
+                      "slab-wise fuse")
+
+        def timed2(fn):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / 2
+
+        t_whole, t_slab = timed2(whole), timed2(by_slab)
+        fusion.fuse_stats.zero_()
+        slabwise = {"slabs": len(bounds), "ms_whole_volume": round(t_whole * 1e3, 2), "ms_slab_by_slab": round(t_slab * 1e3, 2),
+                    "ratio": round(t_slab / t_whole, 3),
+                    "note": "the rank's 512 frames fused into x-slabs of the ONE per-rank volume, one saf_fuse_frames call per slab "
+                            "(up-front clear in both): between two such calls the N > 1 job starts the finished slab's reduce-scatter"}
+
     # ---- the other configurations and the copy rate of this box, measured in this run (rank 0, N = 1) ----
     side, copy_rate = None, None
     if rank == 0 and world == 1 and not a.no_side and isinstance(a.grid, int) and a.grid == 256 and a.depth_kind == "A" and not a.labels \
@@ -639,6 +713,8 @@ def main():
             "cpu_baseline": cpu,
             "end_to_end": e2e,
             "hbm_copy_GBps": copy_rate,
+            "slab_by_slab_fuse": slabwise,
+            "slab_pipelined_merge": slab_pipe,
             "side_workloads": side,
         }
         if api_b1 is not None:
@@ -648,6 +724,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
 
+
+
+def windowed_headline(st):
+    return st.get("window_rows", 0) > 0
 
 
 def hbm_copy_rate(device, nbytes=4 << 30, reps=3):

@@ -199,6 +199,111 @@ def gather_frames(tensors, group=None):
 VOLUME_TENSORS = ("clip_feat", "rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot")
 
 
+# ---- the frame-sharded job with the merge PIPELINED slab by slab inside one job (BASELINE config 4's own layout) ----
+#
+# A serial job is fuse (84 ms) + one collective over the 34 GB volume (about 100 ms): 3.7 x at 8 GPUs.  The fused kernels are
+# voxel-major and a slab of x-planes is a contiguous range of the flat voxel index, so the rank's frames can be fused SLAB
+# BY SLAB into the one per-rank volume: when slab s is complete nothing will touch it again and its reduce-scatter can run on
+# a communication stream while slab s + 1 is being fused.  Only the last slab's collective is exposed.  Rank k ends with
+# the k-th part of EVERY slab (stripes), which is as good a voxel sharding for the query scan as one range.
+
+
+def slab_bounds(nx: int, n_slabs: int, align: int = 16):
+    """x-plane ranges [(x0, count)] of n_slabs slabs; boundaries on multiples of ``align`` planes (the row kernel's tile)
+    when nx allows it."""
+    unit = align if nx % align == 0 and nx // align >= n_slabs else 1
+    blocks = nx // unit
+    out, x = [], 0
+    for s in range(n_slabs):
+        cnt = (blocks // n_slabs + (1 if s < blocks % n_slabs else 0)) * unit
+        if cnt:
+            out.append((x, cnt))
+        x += cnt
+    return out
+
+
+def slab_descriptor(fusion, x0: int, count: int):
+    """The saf_volume descriptor of x-planes [x0, x0 + count) of ``fusion``'s volume: the same buffers, offset; fusing
+    into it touches only that slab (the axis table starts at x0, so voxel centres -- and every decision -- are those of the
+    full volume's voxels, bit for bit)."""
+    vol = fusion._c_volume(for_fuse=True)
+    nx, ny, nz = (int(v) for v in fusion.nvox)
+    if not (0 <= x0 and count > 0 and x0 + count <= nx):
+        raise ValueError("slab outside the volume")
+    rows = x0 * ny * nz
+    esz = 2 if fusion._buffers["clip_feat"].dtype == torch.bfloat16 else 4
+    out = _abi.SafVolume.from_buffer_copy(vol)
+    out.nx = count
+    out.axis_x = vol.axis_x + 4 * x0
+    out.tsdf = vol.tsdf + 4 * rows
+    out.tsdf_weight = vol.tsdf_weight + 4 * rows
+    out.weight = vol.weight + 4 * rows
+    out.rgb = vol.rgb + 12 * rows
+    out.clip_feat = vol.clip_feat + esz * int(fusion.n_clip_feats) * rows
+    if vol.labels_one_hot:
+        out.labels_one_hot = vol.labels_one_hot + 4 * int(vol.n_classes) * rows
+    return out
+
+
+def slab_rows(fusion, x0: int, count: int):
+    nx, ny, nz = (int(v) for v in fusion.nvox)
+    return x0 * ny * nz, count * ny * nz
+
+
+def merge_slab_sums(tensors: dict, first_row: int, n_rows: int, group=None, mode: str = "reduce_scatter"):
+    """SUM rows [first_row, first_row + n_rows) of every tensor across the ranks; with ``reduce_scatter`` rank k ends with
+    the k-th part of the slab (returned as (first, count) in volume rows), the other rows keep partial sums."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return first_row, n_rows
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    for t in tensors.values():
+        part = t[first_row : first_row + n_rows]
+        if mode == "all_reduce":
+            _all_reduce(part, group)
+        else:
+            _reduce_scatter_rows(part, group, rank, world)
+    if mode == "all_reduce":
+        return first_row, n_rows
+    f, c = voxel_shard(n_rows, rank, world)
+    return first_row + f, c
+
+
+def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, group=None, comm_stream=None, mode="reduce_scatter",
+                         stats_ptr=None, profiler=None):
+    """One frame-sharded job with the merge hidden behind the fusion: the rank's frames are fused slab by slab (SUM mode)
+    and each finished slab is reduce-scattered + finalised on ``comm_stream`` while the next one is fused.  Returns the list
+    of (first_row, count) stripes that hold final means on this rank.  The caller's stream ends ordered after the last
+    collective."""
+    if fusion.accum_mode != _abi.SAF_SUM:
+        raise SafError("fuse_merge_pipelined fuses sums: set accum_mode = SAF_SUM (reset(accum_mode=SAF_SUM))")
+    L = lib()
+    dev = fusion._buffers["tsdf"].device
+    main = torch.cuda.current_stream(dev)
+    comm = comm_stream if comm_stream is not None else main
+    tensors = {k: fusion._buffers[k] for k in VOLUME_TENSORS if fusion._buffers.get(k) is not None}
+    stats_ptr = fusion._buffers["fuse_stats"].data_ptr() if stats_ptr is None else stats_ptr
+    if fusion.__dict__.get("_feat_stale"):
+        fusion.flush()  # (slabs are fused one by one: the deferred clear of reset() is finished first)
+    stripes = []
+    nx = int(fusion.nvox[0])
+    for x0, cnt in slab_bounds(nx, n_slabs):
+        vol = slab_descriptor(fusion, x0, cnt)
+        check(L.saf_fuse_frames_profiled(C.byref(vol), frame_arr, n_frames, workspace.data_ptr(), workspace.numel(), stats_ptr,
+                                         profiler, main.cuda_stream), "saf_fuse_frames (slab)")
+        fused = main.record_event()
+        with torch.cuda.stream(comm):
+            comm.wait_event(fused)
+            r0, nr = slab_rows(fusion, x0, cnt)
+            first, count = merge_slab_sums(tensors, r0, nr, group, mode)
+            vdesc = fusion._c_volume(for_fuse=True)
+            check(L.saf_merge_finalize(C.byref(vdesc), first, count, comm.cuda_stream), "saf_merge_finalize")
+            stripes.append((first, count))
+    if comm is not main:
+        main.wait_event(comm.record_event())
+    return stripes
+
+
 def merge_sums(tensors: dict, group=None, mode: str = "reduce_scatter", gather: bool = False):
     """Element-wise SUM of per-rank volume tensors (dict name -> tensor with voxels on dim 0).
     Device-agnostic (RCCL on GPUs, gloo in the CPU tests).  Returns (first, count): the voxel range

@@ -208,3 +208,55 @@ def test_balanced_planes_partition_the_grid():
             centre = (nx - 1) / 2
             assert abs(float((p.double() - centre).mean())) < 16 * world, "blocks of a rank do not mirror each other"
     assert sdist.slab_planes_of_rank(33, 1, 3).tolist() == list(range(11, 22))  # no blocks of 16: the contiguous slab
+
+
+def _slab_merge_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_rows = 7 * 5 * 3  # 7 x-planes of 15 voxels: slabs of unequal size, parts with a remainder
+        g = torch.Generator().manual_seed(100 + rank)
+        mine = {"clip_feat": torch.randn(n_rows, 6, generator=g), "weight": torch.randint(0, 9, (n_rows,), generator=g, dtype=torch.int32)}
+        total = {}
+        for k, v in mine.items():
+            parts = [torch.empty_like(v) for _ in range(world)]
+            dist.all_gather(parts, v)
+            total[k] = torch.stack(parts).sum(0)
+        why = sdist.probe_collectives(torch.device("cpu"))
+        assert why is None, why
+        stripes = []
+        for x0, cnt in sdist.slab_bounds(7, 3):
+            stripes.append(sdist.merge_slab_sums(mine, x0 * 15, cnt * 15))
+        covered = torch.zeros(n_rows, dtype=torch.int32)
+        for f, c in stripes:
+            assert torch.equal(mine["weight"][f:f + c], total["weight"][f:f + c])
+            torch.testing.assert_close(mine["clip_feat"][f:f + c], total["clip_feat"][f:f + c], rtol=1e-6, atol=1e-6)
+            covered[f:f + c] += 1
+        allc = [torch.empty_like(covered) for _ in range(world)]
+        dist.all_gather(allc, covered)
+        assert torch.equal(torch.stack(allc).sum(0), torch.ones(n_rows, dtype=torch.int32)), "the ranks' stripes must tile the volume"
+        out[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_wise_merge_leaves_every_rank_its_part_of_every_slab():
+    """The slab-pipelined merge (distributed.fuse_merge_pipelined): each slab's rows are reduce-scattered on their own; rank k
+    must end with the exact sums of the k-th part of every slab, and the ranks' stripes must tile the volume."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_slab_merge_worker, args=(world, port, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world))
+
+
+def test_slab_bounds_tile_the_x_axis():
+    for nx, s in ((256, 8), (127, 8), (48, 8), (5, 8), (64, 3)):
+        b = sdist.slab_bounds(nx, s)
+        assert b[0][0] == 0 and sum(c for _, c in b) == nx
+        assert all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+        if nx % 16 == 0 and nx // 16 >= s:
+            assert all(x % 16 == 0 and c % 16 == 0 for x, c in b)

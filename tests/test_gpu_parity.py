@@ -1175,3 +1175,58 @@ def test_balanced_plane_slabs_equal_the_full_volume(dim, n_frames):
             assert torch.equal(getattr(slab, nm).view(planes.numel() * nvox[1] * nvox[2], -1), pick(getattr(full, nm))), (rank, nm)
         seen += planes.tolist()
     assert sorted(seen) == list(range(nvox[0])) and int(full.weight.sum()) > 0
+
+
+@pytest.mark.parametrize("seem", [False, True])
+def test_slab_by_slab_fusion_equals_the_whole_volume(seem):
+    """distributed.slab_descriptor: the frames fused into x-slabs of ONE volume, one saf_fuse_frames call per slab (what the
+    slab-pipelined merge does between its collectives), leave every buffer bit for bit as one call over the whole volume;
+    fuse_merge_pipelined on a single rank (no collective) ends with the running means of a plain fusion."""
+    import ctypes as C
+
+    from spatially_aware_ai_amd import ClipFusion, ClipSeemFusion
+    from spatially_aware_ai_amd import distributed as sdist
+    from spatially_aware_ai_amd._lib import check, lib
+
+    dim, n_frames, nvox, w, h = 256, 70, (64, 32, 64), 64, 48
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid(nvox, side=2.56)
+    frames = syn.make_frames(321, n_frames, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="B", missing_depth_frac=0.05)
+    cat = lambda k: torch.cat([f[k] for f in frames]).cuda()
+    labs = [f["labels"].float().cuda() for f in frames] if seem else None
+
+    def build():
+        if seem:
+            return ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, 10, 10, FakeClip(dim), FakeSeg(),
+                                  keep_xyz_world=False).cuda()
+        return ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, FakeClip(dim), None, 10, 10,
+                          keep_xyz_world=False).cuda()
+
+    whole = build()
+    whole.integrate_features(cat("depth"), cat("rgb"), cat("pose"), cat("K"), cat("feat"), labs)
+    L = lib()
+    names = ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat") + (("labels_one_hot",) if seem else ())
+    for mode in ("slabs", "pipelined"):
+        fz = build()
+        arr, keep, _, _ = fz._make_frames(cat("depth"), cat("rgb"), cat("pose"), cat("K"), cat("feat"), labs, seem)
+        ws = fz._get_workspace(npy, npx)
+        stream = torch.cuda.current_stream().cuda_stream
+        if mode == "slabs":
+            for x0, cnt in sdist.slab_bounds(nvox[0], 4):
+                vol = sdist.slab_descriptor(fz, x0, cnt)
+                check(L.saf_fuse_frames(C.byref(vol), arr, n_frames, ws.data_ptr(), ws.numel(), fz._buffers["fuse_stats"].data_ptr(),
+                                        stream), "slab fuse")
+        else:
+            fz.reset(accum_mode=_abi.SAF_SUM)
+            stripes = sdist.fuse_merge_pipelined(fz, arr, n_frames, ws, n_slabs=4, comm_stream=torch.cuda.Stream())
+            assert sum(c for _, c in stripes) == fz.tsdf.numel()
+            fz.accum_mode = _abi.SAF_RUNNING_MEAN
+        torch.cuda.synchronize()
+        for name in names:
+            if mode == "slabs" or name in ("weight", "tsdf_weight", "labels_one_hot"):
+                assert torch.equal(getattr(whole, name), getattr(fz, name)), (mode, name)
+            else:  # sums divided once instead of running means: the same means within fp32 rounding
+                np.testing.assert_allclose(getattr(fz, name).cpu().numpy(), getattr(whole, name).cpu().numpy(), rtol=1e-4, atol=2e-5)
+        s1, s2 = whole.stats(), fz.stats()
+        for k in ("valid", "tsdf_valid", "labels_dropped"):
+            assert s1[k] == s2[k], (mode, k, s1, s2)
