@@ -9,6 +9,13 @@ timing the *shape* of the work is what matters (SURVEY.md §7 "Backbones are una
                          ``open_clip.create_model`` returns (reference clipfusion.py:769-781, :833).
   * ``RandomPanoptic`` -- a constant-time stand-in for ``KmaxSegmentationModel.run_on_image``
                          (handy_utils.py:60-161): class-id map [H, W] from a tiny strided conv.
+  * ``RandomKmaxConvNeXtL`` -- the SHAPE of the reference's kMaX-DeepLab panoptic model (handy_utils.py:29-58: detectron2
+                         ``build_model`` of the kMaX ConvNeXt-L config) behind detectron2's calling convention, with seeded
+                         random weights: a ConvNeXt-L encoder (depths 3-3-27-3, widths 192-384-768-1536, 7x7 depthwise
+                         convolutions, at the 1281 x 960 input ``KmaxSegmentationModel.preprocess`` produces) and a light
+                         stand-in for the kMaX decoder (lateral 1x1 convolutions, top-down sum, 128 mask queries, per-pixel
+                         argmax).  Injected into ``segmentation.KmaxSegmentationModel`` it makes BASELINE config 3 -- kMaX +
+                         CLIP jointly fused -- measurable end to end; the encoder carries the work (about 0.84 TFLOP per frame).
 """
 from __future__ import annotations
 
@@ -94,3 +101,89 @@ class RandomPanoptic:
         # a fixed hash of the quantised colours: stands in for the detectron2 / kMaX forward
         q = (rgb_chw * 255.0).to(torch.int64)
         return (q[0] * 7 + q[1] * 13 + q[2] * 29) % self.n_classes
+
+
+class _LayerNorm2d(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.ln = nn.LayerNorm(c, eps=1e-6)
+
+    def forward(self, x):  # [B, C, H, W]
+        return self.ln(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+
+
+class _ConvNeXtBlock(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dw = nn.Conv2d(c, c, 7, padding=3, groups=c)
+        self.ln = nn.LayerNorm(c, eps=1e-6)
+        self.fc1 = nn.Linear(c, 4 * c)
+        self.fc2 = nn.Linear(4 * c, c)
+        self.gamma = nn.Parameter(torch.full((c,), 1e-6))
+
+    def forward(self, x):
+        y = self.dw(x).permute(0, 2, 3, 1)
+        y = self.fc2(F.gelu(self.fc1(self.ln(y)))) * self.gamma
+        return x + y.permute(0, 3, 1, 2)
+
+
+class RandomKmaxConvNeXtL(nn.Module):
+    """``model([{"image": int32 BGR [3,h,w], "height": H, "width": W}]) -> [{"panoptic_seg": (ids [H,W], segments_info)}]``:
+    detectron2's interface for the kMaX-DeepLab ConvNeXt-L panoptic model, random weights (see the module docstring)."""
+
+    DEPTHS, DIMS, QUERIES, EMBED = (3, 3, 27, 3), (192, 384, 768, 1536), 128, 128
+
+    def __init__(self, seed: int = 0, n_classes: int = 133):
+        super().__init__()
+        d = self.DIMS
+        self.stem = nn.Sequential(nn.Conv2d(3, d[0], 4, 4), _LayerNorm2d(d[0]))
+        self.stages = nn.ModuleList()
+        self.down = nn.ModuleList()
+        for i, (n, c) in enumerate(zip(self.DEPTHS, d)):
+            if i:
+                self.down.append(nn.Sequential(_LayerNorm2d(d[i - 1]), nn.Conv2d(d[i - 1], c, 2, 2)))
+            self.stages.append(nn.Sequential(*[_ConvNeXtBlock(c) for _ in range(n)]))
+        self.lateral = nn.ModuleList(nn.Conv2d(c, 256, 1) for c in d)
+        self.pixel = nn.Conv2d(256, self.EMBED, 3, padding=1)
+        self.centers = nn.Parameter(torch.zeros(self.QUERIES, self.EMBED))
+        self.register_buffer("pixel_mean", torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1))
+        self.register_buffer("pixel_std", torch.tensor([57.375, 57.12, 58.395]).view(3, 1, 1))
+        self.n_classes = n_classes
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for p in self.parameters():
+                if p.dim() > 1:
+                    fan_in = p[0].numel()
+                    p.copy_(torch.randn(p.shape, generator=g) * fan_in ** -0.5)
+            for m in self.modules():
+                if isinstance(m, nn.LayerNorm):
+                    m.weight.fill_(1.0)
+                    m.bias.zero_()
+                elif isinstance(m, _ConvNeXtBlock):
+                    m.gamma.fill_(0.1)
+        self.query_class = [(7 * q + 3) % n_classes for q in range(self.QUERIES)]
+
+    def forward(self, batched_inputs):
+        out = []
+        for inp in batched_inputs:
+            img = inp["image"].to(self.pixel_mean.device).float()
+            x = ((img - self.pixel_mean) / self.pixel_std)[None].contiguous(memory_format=torch.channels_last)
+            feats = []
+            x = self.stem(x)
+            for i, stage in enumerate(self.stages):
+                if i:
+                    x = self.down[i - 1](x)
+                x = stage(x)
+                feats.append(x)
+            y = self.lateral[3](feats[3])
+            for i in (2, 1, 0):  # top-down: the pixel decoder's place
+                y = self.lateral[i](feats[i]) + F.interpolate(y, size=feats[i].shape[-2:], mode="nearest")
+            emb = self.pixel(y)  # [1, E, h/4, w/4]
+            logits = torch.einsum("qe,behw->bqhw", self.centers.to(emb.dtype), emb)
+            ids = logits.argmax(dim=1, keepdim=True).float()
+            ids = F.interpolate(ids, size=(int(inp["height"]), int(inp["width"])), mode="nearest")[0, 0].long() + 1
+            present = torch.unique(ids).tolist()
+            info = [{"id": int(i), "category_id": self.query_class[int(i) - 1], "isthing": self.query_class[int(i) - 1] < 80}
+                    for i in present]
+            out.append({"panoptic_seg": (ids, info)})
+        return out

@@ -52,3 +52,23 @@ def test_wrapper_on_device(golden, c):
     # the resize runs in PyTorch-ROCm here: same pixels up to the float -> int truncation at exact integers
     diff = (seen["image"][:, ::9, ::11].cpu().numpy().astype(np.int32) - golden[f"c{c}_model_input_sample"]).astype(np.int32)
     assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 1e-3
+
+
+def test_convnext_l_shaped_stand_in_behind_the_wrapper(monkeypatch):
+    """BASELINE config 3 needs a panoptic backbone to run end to end: RandomKmaxConvNeXtL has the encoder of the reference's
+    kMaX-DeepLab config (ConvNeXt-L: 198 M parameters) behind detectron2's calling convention; through the wrapper it yields a
+    class-id map of the frame's size with ids in [0, 134).  (Small input here: the CPU suite stays short.)"""
+    import torch
+
+    from spatially_aware_ai_amd import segmentation as S
+    from spatially_aware_ai_amd.backbones import RandomKmaxConvNeXtL
+
+    model = RandomKmaxConvNeXtL().eval()
+    assert 190e6 < sum(p.numel() for p in model.parameters()) < 205e6
+    assert model.DEPTHS == (3, 3, 27, 3) and model.DIMS == (192, 384, 768, 1536)
+    monkeypatch.setattr(S, "LONG_EDGE", 128)
+    seg = S.KmaxSegmentationModel(model)
+    img = torch.rand(3, 48, 64, generator=torch.Generator().manual_seed(1))
+    out = seg.run_on_image(img)
+    assert out.shape == (48, 64) and int(out.min()) >= 0 and int(out.max()) < 134
+    assert torch.equal(out, seg.run_on_image(img)), "deterministic"
