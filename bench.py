@@ -442,7 +442,7 @@ def main():
         # from the committed rocprofv3 --pmc passes of this same command (tools/profile.sh, newest round first)
         traffic, traffic_source = None, None
         kname = "fuse_window_kernel" if windowed else "fuse_kernel"
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             rel = os.path.join("profiles", rnd, "window_traffic.json" if windowed else "fuse_traffic.json")
             try:
                 tj = json.load(open(os.path.join(ROOT, rel)))

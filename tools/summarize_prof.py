@@ -13,7 +13,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
-dst = f"profiles/{tag}"
+dst = sys.argv[2] if len(sys.argv) > 2 else f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
 def newest(pattern):
     fs = sorted(glob.glob(pattern), key=os.path.getmtime)
