@@ -436,6 +436,50 @@ struct W2Fast {
   unsigned long long qk[16];       // QUERY_MAX: per register, the wave's best (ordered score, ~row) for lane r = 0
 };
 
+// QUERY_MAX: per query, the largest key over the 32 lanes of a half.  A lane holds 16 keys (its row's scores of the half's 16
+// queries): a reduce-scatter BUTTERFLY -- at each of four levels a lane keeps half of its keys and trades the other half
+// with the lane whose index differs in one bit (bit 4: v_permlane16_swap; bit 3: DPP row_ror:8; bits 2, 1: ds_swizzle /
+// quad_perm), then one exchange over bit 0 -- 16 exchanges of a key in all, instead of five shuffles and a ballot per key
+// (16 x 5): the per-query maximum was 45 ms of a 19 ms scan.  Afterwards lane r of half h holds the half's best key of query
+// register i(r) = 8 b4 + 4 b3 + 2 b2 + b1 (b_k = bit k of r; lanes r and r ^ 1 hold the same).
+__device__ __forceinline__ unsigned long long w2_key_max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long w2_key_dpp_ror8(unsigned long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x128, 0xf, 0xf, false);          // row_ror:8 = lane ^ 8 of a 16-lane row
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x128, 0xf, 0xf, false);
+  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+template <int PATTERN>
+__device__ __forceinline__ unsigned long long w2_key_swizzle(unsigned long long v) {
+  const int lo = __builtin_amdgcn_ds_swizzle((int)(uint32_t)v, PATTERN);
+  const int hi = __builtin_amdgcn_ds_swizzle((int)(uint32_t)(v >> 32), PATTERN);
+  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ unsigned long long w2_query_max_reduce(const unsigned long long (&qk)[16], int r) {
+  unsigned long long k8[8], k4[4], k2[2];
+  // bit 4: lanes 0-15 of a half keep keys 0-7, lanes 16-31 keys 8-15.  v_permlane16_swap(x, y) exchanges x[16:31] with
+  // y[0:15] (in both halves of the wave): afterwards x and y hold, in every lane, the two candidates of the key it keeps
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)qk[j], (uint32_t)qk[j + 8], false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(qk[j] >> 32), (uint32_t)(qk[j + 8] >> 32), false, false);
+    k8[j] = w2_key_max(((unsigned long long)hi[0] << 32) | lo[0], ((unsigned long long)hi[1] << 32) | lo[1]);
+  }
+  const bool b3 = (r & 8) != 0, b2 = (r & 4) != 0, b1 = (r & 2) != 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // bit 3: keep j (bit clear) or j + 4 (bit set), trade the other one
+    const unsigned long long keep = b3 ? k8[j + 4] : k8[j], give = b3 ? k8[j] : k8[j + 4];
+    k4[j] = w2_key_max(keep, w2_key_dpp_ror8(give));
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {  // bit 2 (ds_swizzle, bit mode: and 0x1f, xor 4)
+    const unsigned long long keep = b2 ? k4[j + 2] : k4[j], give = b2 ? k4[j] : k4[j + 2];
+    k2[j] = w2_key_max(keep, w2_key_swizzle<(4 << 10) | 0x1f>(give));
+  }
+  const unsigned long long keep = b1 ? k2[1] : k2[0], give = b1 ? k2[0] : k2[1];
+  const unsigned long long k1 = w2_key_max(keep, w2_key_swizzle<(2 << 10) | 0x1f>(give));
+  return w2_key_max(k1, w2_key_swizzle<(1 << 10) | 0x1f>(k1));  // bit 0: both lanes end with the half's best
+}
+
 template <int OT, int EPI, int NF>
 __device__ __forceinline__ void w2_fast_piece(int i, const Wide2Args& wa, const f32x16_t (&c)[NF], const W2Tile<NF>& t,
                                               W2State<NF>& st, W2Fast<NF>& fs, int r, int h, int n_qt) {
@@ -481,22 +525,17 @@ __device__ __forceinline__ void w2_fast_piece(int i, const Wide2Args& wa, const 
       st.best_q[f] = better ? q : st.best_q[f];
     }
   } else {  // SAF_QW_QUERY_MAX
-    float x[NF];
-    float m = -INFINITY;
+    // this lane's best over its NF rows for query register i, as a key (ordered score << 32 | ~row: the larger key is the
+    // larger score, then the smaller row); the 32 lanes of a half are combined after the tile (w2_query_max_reduce)
+    float m = c[0][i] * t.inv[0];
+    uint32_t row = (uint32_t)(t.row[0] + wa.row_offset);
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      x[f] = c[f][i] * t.inv[f];
-      m = fmaxf(m, x[f]);
+    for (int f = 1; f < NF; ++f) {
+      const float x = c[f][i] * t.inv[f];
+      const bool better = x > m;  // rows ascend with f: the first maximum stays
+      m = better ? x : m;
+      row = better ? (uint32_t)(t.row[f] + wa.row_offset) : row;
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    uint32_t slot = 0xffffffffu;
-#pragma unroll
-    for (int f = NF - 1; f >= 0; --f) {
-      const uint32_t hb = (uint32_t)(__ballot(x[f] == m) >> (32 * h));
-      slot = hb ? 32u * f + (uint32_t)__ffs((int)hb) - 1u : slot;
-    }
-    const uint32_t row = (uint32_t)(t.row[0] - r + wa.row_offset) + slot;  // row[0] - r: the wave's first row
     fs.qk[i] = ((unsigned long long)ordered_bits(m) << 32) | (uint32_t)~row;
   }
 }
@@ -656,9 +695,10 @@ query_wide2_kernel(Wide2Args wa) {
         __builtin_amdgcn_sched_barrier(0);  // keep the pieces where they are: between the MFMAs
       }
       if (EPI == SAF_QW_QUERY_MAX) {
-        if (r == 0) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) atomicMax(&wa.qkeys[prev.qt * kWTile + 4 * h + 8 * (i >> 2) + (i & 3)], fs.qk[i]);
+        const unsigned long long best = w2_query_max_reduce(fs.qk, r);
+        if ((r & 1) == 0) {  // one atomic per query and half-wave, all in one instruction
+          const int i = ((r >> 4) & 1) * 8 + ((r >> 3) & 1) * 4 + ((r >> 2) & 1) * 2 + ((r >> 1) & 1);
+          atomicMax(&wa.qkeys[prev.qt * kWTile + 4 * h + 8 * (i >> 2) + (i & 3)], best);
         }
       }
     }
