@@ -577,7 +577,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
   constexpr int SR = Cfg::SR;
   // (s_setprio 1 / 3 here, ahead of the classification waves that share the SIMDs, changes nothing: 105.4 / 105.7 / 105.8 ms)
   // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
-  constexpr int P = BF16 && Cfg::P > 2 ? Cfg::P - 1 : Cfg::P;
+  constexpr int P = BF16 && Cfg::P > 2 ? Cfg::P - 1 : (BF16 && CPL == 4 ? 1 : Cfg::P);  // (bf16, D = 1024: two groups of 64 tap registers in flight spilled)
   extern __shared__ __align__(16) unsigned char s_dyn[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4* rows = reinterpret_cast<float4*>(s_dyn + Cfg::rows_off) + (size_t)wave * SR * CPL * 64;

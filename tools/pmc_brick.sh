@@ -17,6 +17,12 @@ run g TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum &&
 run h TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum
 python3 - <<PY
 import csv, glob, json, collections, os
+def kind(name):
+    if "fuse_window" in name:
+        return "rows"
+    if "fuse_brick" in name:  # fuse_brick_kernel<CPL, SUM, BF16, BUILD>: the last template argument tells the two kernels apart
+        return "build" if name.split(">(")[0].rstrip().endswith("true") else "walk"
+    return None
 out = {}
 for d in "abcdefgh":
     fs = sorted(glob.glob("$OUT/%s/*/*_counter_collection.csv" % d), key=os.path.getmtime)
@@ -24,21 +30,27 @@ for d in "abcdefgh":
         continue
     acc = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(fs[-1])):
-        if "fuse_brick" in r["Kernel_Name"] or "fuse_window" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-    for c, v in acc.items():
-        out[c] = v / n[c]
+        k = kind(r["Kernel_Name"])
+        if k:
+            acc[(k, r["Counter_Name"])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+    for (k, c), v in acc.items():
+        out.setdefault(k, {})[c] = v / n[(k, c)]
     ks = sorted(glob.glob("$OUT/%s/*/*_kernel_trace.csv" % d), key=os.path.getmtime)
     if ks:
-        du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(ks[-1])) if "fuse_brick" in r["Kernel_Name"] or "fuse_window" in r["Kernel_Name"]]
-        if du:
-            out["us_pass_" + d] = sum(du) / len(du)
-if "FETCH_SIZE" in out:
-    out["hbm_read_GB"] = out["FETCH_SIZE"] * 1024 * 2 / 1e9   # KiB, and the gfx950 halving
-if "WRITE_SIZE" in out:
-    out["hbm_write_GB"] = out["WRITE_SIZE"] * 1024 / 1e9
-if "TCP_TCC_READ_REQ_sum" in out:
-    out["l1_to_l2_read_GB_at_128B"] = out["TCP_TCC_READ_REQ_sum"] * 128 / 1e9
+        du = collections.defaultdict(list)
+        for r in csv.DictReader(open(ks[-1])):
+            k = kind(r["Kernel_Name"])
+            if k:
+                du[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        for k, v in du.items():
+            out.setdefault(k, {})["us_pass_" + d] = sum(v) / len(v)
+for k, o in out.items():
+    if "FETCH_SIZE" in o:
+        o["hbm_read_GB"] = o["FETCH_SIZE"] * 1024 * 2 / 1e9   # KiB, and the gfx950 halving
+    if "WRITE_SIZE" in o:
+        o["hbm_write_GB"] = o["WRITE_SIZE"] * 1024 / 1e9
+    if "TCP_TCC_READ_REQ_sum" in o:
+        o["l1_to_l2_read_GB_at_128B"] = o["TCP_TCC_READ_REQ_sum"] * 128 / 1e9
 json.dump(out, open("$OUT/brick_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
