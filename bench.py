@@ -17,13 +17,18 @@ N > 1: when WORLD_SIZE is not set, `python bench.py --gpus N` starts the N ranks
 `python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches the GPU), forwards
 rank 0's JSON line and exits non-zero if any rank fails.  The headline `value` of an N > 1 run is the SERIAL-merge
 job (fuse, then the RCCL merge, nothing overlapped: BASELINE config 4 is one job); the same K steps are then timed
-again with each job's merge overlapped with the next job's fusion (`overlapped_merge`), and a third time with the VOXELS
+again with each job's merge overlapped with the next job's fusion (`overlapped_merge`), a third time with the VOXELS
 sharded instead of the frames (`voxel_sharded`: balanced slabs, the frames all-gathered in segments beside the fusion, no
-merge).  After the timed regions an untimed integrity pass proves the merge: weight sums against the kernels' valid counts,
+merge), and a fourth time as ONE job whose merge is pipelined slab by slab behind its own fusion (`slab_pipelined_merge`:
+config 4's layout; distributed.fuse_merge_pipelined).  The merge's collectives are probed on a small tensor first (a
+collective that raised inside a volume is never retried).  After the timed regions an untimed integrity pass proves the merge: weight sums against the kernels' valid counts,
 and the merged voxel shard of a small sharded job against a single-rank fusion of all its frames (`merge_check`).
 
 Other passes: --query (BASELINE config 5: the text-query scans), --api-b1 N (one frame per integrate() call through the
-deferred window queue), --end-to-end N (a ViT-B/32-shaped backbone in front), --depth-kind B, --labels, --feat-dtype bf16.
+deferred window queue), --end-to-end N (a ViT-B/32-shaped backbone in front; 128 frames by default), --depth-kind B, --labels,
+--feat-dtype bf16, --grid nx,ny,nz.  The default single-GPU run also reports `side_workloads` (BASELINE configs 2, 3 and 5, the
+coherent scene, config 3 end to end: about 40 s; --no-side skips them), `hbm_copy_GBps` (this box's copy rate, measured in the
+run) and `slab_by_slab_fuse` (the job fused into 8 x-slabs one after the other against one call).
 
 Extra objects on the JSON line:
   roofline     : the dominant kernel (fuse_window_kernel): algorithmic bytes per launch (from the row / voxel counters
