@@ -69,7 +69,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=512, help="frames per rank per step")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--depth-kind", default="A", choices=["A", "B"])
+    ap.add_argument("--depth-kind", default="A", choices=["A", "B", "Z"],
+                    help="A: iid depth per pixel (the worst case); B: a coherent analytic scene; Z: no valid depth (nothing hits: the fixed cost)")
     ap.add_argument("--unique-frames", type=int, default=512,
                     help="distinct synthetic frames resident per rank (cycled to --frames)")
     ap.add_argument("--merge", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
@@ -130,6 +131,8 @@ def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device):
     g = torch.Generator(device=device).manual_seed(seed)
     if depth_kind == "A":
         depth = torch.rand((n, height, width), generator=g, device=device) * 2.0 + 1.5
+    elif depth_kind == "Z":
+        depth = torch.zeros((n, height, width), device=device)
     else:
         depth = torch.stack([syn._analytic_depth(p, k, width, height) for p, k in zip(poses, ks)])
     rgb = torch.rand((n, height, width, 3), generator=g, device=device)

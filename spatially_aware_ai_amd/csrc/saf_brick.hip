@@ -35,6 +35,7 @@
 // the walkers' adds arrive and is reproducible bit for bit.  A window whose maps hold a non-finite value (no number to
 // scale by) takes float atomics instead: slow, NaN / inf propagate as in the reference.  SAF_WIN_FORM=rows selects the
 // frame-ordered kernel (bit-identical to fusing frame after frame).
+#include <cstddef>
 #include <type_traits>
 
 #include "saf_window_dev.h"
@@ -52,6 +53,7 @@ constexpr int kWalkers = 4, kMovers = 4;   // waves 0 .. 3 walk, waves 4 .. 7 mo
 constexpr int kBWaves = kWalkers + kMovers;
 constexpr int kBThreads = kBWaves * 64;
 constexpr int kHitThreads = kWalkers * 64;
+constexpr int kBuildThreads = 128;        // the build kernel: two waves per brick, eight bricks per CU
 constexpr int kWindows = 4;                // 64-hit windows of a round, sorted one by one
 constexpr int kHC = kWindows * 64;         // hit records of one round (a brick with more hits takes its frames in rounds)
 static_assert(kHC >= kBV, "a frame's hits fit a round");
@@ -62,68 +64,87 @@ constexpr int kP = SAF_BRICK_P;            // groups of one batch: 4 tap loads e
 
 #ifdef SAF_BRICK_TIMING  // development aid: per-phase wave cycles, by role, printed by the host after every launch
 __device__ unsigned long long g_brick_t[32];
-#define BT_DECL unsigned long long bt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, bt_last_ = __builtin_readcyclecounter()
+__device__ unsigned long long g_walk_t[8];
+#define BT_DECL unsigned long long bt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, bt_last_ = __builtin_readcyclecounter(), wt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define BT(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); bt_[k] += n_ - bt_last_; bt_last_ = n_; } while (0)
-#define BT_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_brick_t[(wave >= kWalkers ? 16 : 0) + k_], bt_[k_]); } while (0)
+#define BT_FLUSH do { if (lane == 0) { for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_brick_t[(wave >= kWalkers ? 16 : 0) + k_], bt_[k_]); for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_walk_t[k_], wt_[k_]); } } while (0)
+// ... and the walkers' time inside a slab's walk: [0] issue, [1] records + weights, [2] waiting for the taps, [3] the hits
+#define WT_PARAM , unsigned long long* wt_
+#define WT_ARG , wt_
+#define WT(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); wt_[k] += n_ - wt_[7]; wt_[7] = n_; } while (0)
 #else
 #define BT_DECL
 #define BT(k)
 #define BT_FLUSH
+#define WT_PARAM
+#define WT_ARG
+#define WT(k)
 #endif
 
 constexpr int kCamFloats = 21;  // the per-frame part of Cam: pose[:3,:4], K (the image-size terms are launch-uniform)
 
+// What the walk needs of one round of one brick -- the IMAGE the build kernel leaves in the pool (a SEGMENT) and the walk
+// kernel copies into LDS as it stands.  The group table comes last: a segment is read up to its last used group.
+// The movers' part first (they still read it while the walkers, done with a round, already replace theirs) ...
+struct alignas(16) SegRows {
+  uint32_t hdr[16];              // R, nh, G, kexp, G of the brick's next round
+  uint32_t rown[kBV];            // flat voxel index of a row
+  float rowA[kBV], rowB[kBV];    // new = old * b + acc * a
+  uint8_t rowfresh[kBV];         // row was never written (weight 0): nothing to read
+};
+// ... then the walkers'
+struct alignas(16) SegWalk {
+  uint32_t rec_k[kHC];           // row (7) | cell x (8) << 7 | cell y (8) << 15 | frame (7) << 23
+  float2 rec_g[kHC];             // a hit's bilinear fractions (wx, wy)
+  uint16_t grp_start[kHC + 8];   // first hit of a group; [G] = number of hits
+  uint4 grp_off[kHC + 1];        // a group's four map rows: byte offsets into the window's images (slab 0, lane 0)
+};
+struct alignas(16) SegImage {
+  SegRows rows;
+  SegWalk walk;
+};
+constexpr uint32_t kSegBytes = (sizeof(SegImage) + 255u) & ~255u;
+constexpr uint32_t kSegFixed = sizeof(SegRows) + offsetof(SegWalk, grp_off);  // a segment's used bytes: kSegFixed + (G + 1) * 16
+constexpr int kRows16 = (int)(sizeof(SegRows) / 16);
+static_assert(kSegFixed % 16 == 0 && sizeof(SegImage) % 16 == 0 && sizeof(SegRows) % 16 == 0 &&
+                  sizeof(SegImage) == sizeof(SegRows) + sizeof(SegWalk), "segment layout");
+
 template <int CPL>
 struct alignas(16) BrickLds {
   int acc[kBV * 64 * CPL];       // [row][channel of the lane][lane]; during the build it stages the hits' rgb samples
-  uint4 grp_off[kHC + 1];        // a group's four map rows: byte offsets into the window's images (slab 0, lane 0)
-  float2 rec_g[kHC];             // a hit's bilinear fractions (wx, wy)
-  uint32_t rec_k[kHC];           // row (7) | cell x (8) << 7 | cell y (8) << 15 | frame (7) << 23
-  uint16_t grp_start[kHC + 8];   // first hit of a group; [G] = number of hits
+  SegRows rows[2];               // the round at work and the one after it
+  SegWalk walk;
   uint32_t mf[kWin * 2];         // bit matrix: frame x voxel
   uint16_t off[kWin + 8];        // exclusive prefix of the frames' hit counts
   uint8_t vrow[kBV];             // voxel -> row of this round
-  uint8_t rowfresh[kBV];         // row was never written (weight 0): nothing to read
-  float rowA[kBV], rowB[kBV];    // new = old * b + acc * a
-  uint32_t rown[kBV];            // flat voxel index of a row
+  uint32_t slabm[128];           // the slabs' largest map magnitudes (bits), read once per launch
   uint32_t misc[32];
 };
 // The build kernel's LDS: everything but the accumulator (the rgb staging gets an array of its own).
 struct alignas(16) BuildLds {
   float stage[kHC * 3];
-  uint4 grp_off[kHC + 1];
-  float2 rec_g[kHC];
-  uint32_t rec_k[kHC];
-  uint16_t grp_start[kHC + 8];
+  SegRows rows[1];               // (rows[0] and walk: one SegImage, written to the pool as it stands)
+  SegWalk walk;
   uint32_t mf[kWin * 2];
   uint16_t off[kWin + 8];
   uint8_t vrow[kBV];
-  uint8_t rowfresh[kBV];
-  float rowA[kBV], rowB[kBV];
-  uint32_t rown[kBV];
   uint32_t misc[32];
 };
 
-// A SEGMENT: what the walk needs of one round of one brick, written by the build kernel into a pool in the workspace.
-constexpr uint32_t kSegHdr = 0;        // u32: R, nh, G, kexp
-constexpr uint32_t kSegRown = 64, kSegRowA = kSegRown + kBV * 4, kSegRowB = kSegRowA + kBV * 4, kSegFresh = kSegRowB + kBV * 4;
-constexpr uint32_t kSegRecK = kSegFresh + kBV, kSegRecG = kSegRecK + kHC * 4, kSegGrpStart = kSegRecG + kHC * 8;
-constexpr uint32_t kSegGrpOff = kSegGrpStart + (kHC + 8) * 2;
-constexpr uint32_t kSegBytes = ((kSegGrpOff + (kHC + 1) * 16) + 255u) & ~255u;
-static_assert(kSegGrpOff % 16 == 0 && kSegRecG % 8 == 0, "segment layout");
 // Control words of a window's pool (zeroed by the host before the build kernel)
 struct BrickCtl {
   uint32_t seg_next;    // segments handed out
-  uint32_t list_n;      // bricks in the list (each: first segment, rounds)
   uint32_t over_n;      // bricks that found the pool exhausted: the walk kernel builds them itself
-  uint32_t walk_next;   // list entries taken by the walk kernel
   uint32_t over_next;   // overflow bricks taken
-  uint32_t pad[3];
+  uint32_t pad;
+  uint32_t list_n[8];   // listed bricks per XCD (each entry: first segment, rounds, groups of the first round)
+  uint32_t walk_next[8];  // ... and how many of them the walk kernel has taken
   unsigned long long acc[64][2];  // the build workgroups' counters (hits, rows), sharded
 };
 
-static_assert(sizeof(BrickLds<4>) <= 76 * 1024, "two workgroups per CU and room for the classification beside them");
+static_assert(sizeof(BrickLds<4>) <= 78 * 1024, "two workgroups per CU and room for the classification beside them");
 static_assert(kHC * 3 * sizeof(float) <= sizeof(int) * kBV * 64, "the rgb staging lives in the accumulator");
+static_assert(offsetof(BuildLds, walk) == offsetof(BuildLds, rows) + sizeof(SegRows), "rows[0] and walk form one SegImage");
 
 // LDS-only barrier: the walkers' tap loads and the movers' row traffic stay in flight across it
 __device__ __forceinline__ void lds_barrier() {
@@ -193,29 +214,34 @@ struct WalkCtx {
 
 template <int CPL>
 __device__ __forceinline__ void walk_issue(const BrickLds<CPL>& L, const WalkCtx& cx, int batch, WalkBatch& b,
-                                           TapVec<CPL> (&tp)[kP][4]) {
+                                           TapVec<CPL> (&tp)[kP][4] WT_PARAM) {
   const int g0 = batch * kP;
-  const int hs = (int)L.grp_start[min(g0 + min(cx.lane, kP), cx.G)];  // lanes 0 .. kP: the groups' first hits ([G] = the end)
+  const int hs = (int)L.walk.grp_start[min(g0 + min(cx.lane, kP), cx.G)];  // lanes 0 .. kP: the groups' first hits ([G] = the end)
 #pragma unroll
   for (int u = 0; u <= kP; ++u) b.hl[u] = __builtin_amdgcn_readlane(hs, u);
 #pragma unroll
   for (int u = 0; u < kP; ++u) {
-    const uint4 o = L.grp_off[min(g0 + u, cx.G)];  // entry G: four offsets beyond the buffer (no such group: nothing moves)
+#ifdef SAF_BRICK_NOTAPS  // ablation: every tap outside the buffer (no L2 -> L1 traffic, same instruction stream)
+    const uint4 o = L.walk.grp_off[cx.G];
+#else
+    const uint4 o = L.walk.grp_off[min(g0 + u, cx.G)];  // entry G: four offsets beyond the buffer (no such group: nothing moves)
+#endif
     tp[u][0] = tap_load<CPL>(cx.maps, o.x + cx.lane_off);
     tp[u][1] = tap_load<CPL>(cx.maps, o.y + cx.lane_off);
     tp[u][2] = tap_load<CPL>(cx.maps, o.z + cx.lane_off);
     tp[u][3] = tap_load<CPL>(cx.maps, o.w + cx.lane_off);
   }
+  WT(0);
 }
 
 // FX: fixed-point accumulation (`scale` is folded into the weights); otherwise float atomics
 template <int CPL, bool FX>
 __device__ __forceinline__ void walk_process(BrickLds<CPL>& L, const WalkCtx& cx, const WalkBatch& b,
-                                             const TapVec<CPL> (&tp)[kP][4], float scale) {
+                                             const TapVec<CPL> (&tp)[kP][4], float scale, bool pending WT_PARAM) {
   for (int c0 = b.hl[0]; c0 < b.hl[kP]; c0 += 64) {  // (one round trip unless the batch has more than 64 hits)
     const int slot = min(c0 + cx.lane, b.hl[kP] - 1);
-    const uint32_t key = L.rec_k[slot];
-    const float2 g = L.rec_g[slot];
+    const uint32_t key = L.walk.rec_k[slot];
+    const float2 g = L.walk.rec_g[slot];
     // the bilinear weights (bilinear_setup's products), times the slab's fixed-point scale (a power of two: exact)
     const float ex = 1.0f - g.x, sy = 1.0f - g.y;
     const float w_nw = (sy * ex) * scale, w_ne = (sy * g.x) * scale, w_sw = (g.y * ex) * scale, w_se = (g.y * g.x) * scale;
@@ -224,10 +250,20 @@ __device__ __forceinline__ void walk_process(BrickLds<CPL>& L, const WalkCtx& cx
     // an lgkmcnt(0) at the head of the per-hit loop, where it waits for the previous hit's ds_add every time round
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt, expcnt untouched
     const int c1 = c0 + 64;
+#ifdef SAF_BRICK_TIMING  // (the taps of this batch; the next batch's 4 kP loads may stay in flight)
+    WT(1);
+    static_assert(kP == 2, "the wait below counts the next batch's loads");
+    if (pending) __builtin_amdgcn_s_waitcnt(0x0F78); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    WT(2);
+#endif
 #pragma unroll
     for (int u = 0; u < kP; ++u) {
       const int l0 = max(b.hl[u], c0), l1 = min(b.hl[u + 1], c1);
+#ifdef SAF_BRICK_NOHITS  // ablation: no per-hit work at all
+      for (int l = l0; l < l0; ++l) {
+#else
       for (int l = l0; l < l1; ++l) {
+#endif
         const int li = l - c0;
         const float wnw = rl_f(w_nw, li), wne = rl_f(w_ne, li), wsw = rl_f(w_sw, li), wse = rl_f(w_se, li);
         const int idx = __builtin_amdgcn_readlane(rowbase, li) - li + cx.lane;  // the hit's row, this lane
@@ -237,7 +273,13 @@ __device__ __forceinline__ void walk_process(BrickLds<CPL>& L, const WalkCtx& cx
           s = __builtin_fmaf(tp[u][1].v[c], wne, s);
           s = __builtin_fmaf(tp[u][2].v[c], wsw, s);
           s = __builtin_fmaf(tp[u][3].v[c], wse, s);
+#ifdef SAF_BRICK_NOATOM  // ablation: a plain LDS store instead of the atomic add (wrong sums, same instruction count)
+          if (true) {
+            L.acc[idx + c * 64] = cvt_rpi(s);
+          } else if (FX) {
+#else
           if (FX) {
+#endif
             __hip_atomic_fetch_add(&L.acc[idx + c * 64], cvt_rpi(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           } else {
             __hip_atomic_fetch_add(reinterpret_cast<float*>(&L.acc[idx + c * 64]), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -245,26 +287,32 @@ __device__ __forceinline__ void walk_process(BrickLds<CPL>& L, const WalkCtx& cx
         }
       }
     }
+    WT(3);
   }
 }
 
 template <int CPL, bool FX>
-__device__ __forceinline__ void walk_slab(BrickLds<CPL>& L, const WalkCtx& wc, int wave, float scale) {
+__device__ __forceinline__ void walk_slab(BrickLds<CPL>& L, const WalkCtx& wc, int wave, float scale WT_PARAM) {
   const int n_batch = (wc.G + kP - 1) / kP;
   WalkBatch bA, bB;
   TapVec<CPL> tpA[kP][4], tpB[kP][4];
   int batch = wave;
   if (batch >= n_batch) return;
-  walk_issue<CPL>(L, wc, batch, bA, tpA);
+#ifdef SAF_BRICK_TIMING
+  wt_[7] = __builtin_readcyclecounter();
+  wt_[4] += (unsigned long long)n_batch;
+  wt_[5] += (unsigned long long)L.walk.grp_start[wc.G];
+#endif
+  walk_issue<CPL>(L, wc, batch, bA, tpA WT_ARG);
   for (;;) {
     const bool hasB = batch + kWalkers < n_batch;
-    if (hasB) walk_issue<CPL>(L, wc, batch + kWalkers, bB, tpB);
-    walk_process<CPL, FX>(L, wc, bA, tpA, scale);
+    if (hasB) walk_issue<CPL>(L, wc, batch + kWalkers, bB, tpB WT_ARG);
+    walk_process<CPL, FX>(L, wc, bA, tpA, scale, hasB WT_ARG);
     if (!hasB) break;
     batch += 2 * kWalkers;
     const bool hasA = batch < n_batch;
-    if (hasA) walk_issue<CPL>(L, wc, batch, bA, tpA);
-    walk_process<CPL, FX>(L, wc, bB, tpB, scale);
+    if (hasA) walk_issue<CPL>(L, wc, batch, bA, tpA WT_ARG);
+    walk_process<CPL, FX>(L, wc, bB, tpB, scale, hasA WT_ARG);
     if (!hasA) break;
   }
 }
@@ -289,7 +337,8 @@ __device__ __forceinline__ uint32_t slab_max_bits(const uint32_t* __restrict__ c
 constexpr uint32_t kOverWords = 1 + kBV + 3;  // (68: entries stay 16-byte aligned)
 struct BrickPool {
   unsigned char* segs;   // cap segments of kSegBytes
-  uint2* list;           // per listed brick: first segment, rounds
+  uint4* list;           // 8 lists (one per XCD) of list_stride entries; per listed brick: first segment, rounds, groups of round 0
+  uint32_t list_stride;
   uint32_t* over;        // per overflow brick kOverWords words: the brick's code, then its voxels' weights before this window
   BrickCtl* ctl;
   uint32_t cap;
@@ -301,13 +350,15 @@ struct BrickPool {
 // 4 mover waves): segments from the pool, then the bricks of the overflow list (or, without a build kernel, every brick),
 // which it builds itself.
 template <int CPL, bool SUM, bool BF16, bool BUILD>
-__global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fuse_brick_kernel(
+__global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fuse_brick_kernel(
     KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, uint32_t img_bytes,
     unsigned long long* __restrict__ stats, unsigned int* __restrict__ ctr, const uint32_t* __restrict__ hitmask,
     uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc, const uint32_t* __restrict__ cmax,
     const float* __restrict__ cams, BrickPool pool) {
   using Lds = typename std::conditional<BUILD, BuildLds, BrickLds<CPL>>::type;
-  constexpr int kNT = BUILD ? kHitThreads : kBThreads;
+  constexpr int kNT = BUILD ? kBuildThreads : kBThreads;
+  constexpr int kNHit = BUILD ? kBuildThreads : kHitThreads;  // threads that build hit records
+  constexpr int kNW = kNHit / 64;                             // ... and waves that sort windows
   extern __shared__ __align__(16) unsigned char s_dyn[];
   Lds& L = *reinterpret_cast<Lds*>(s_dyn);
   // (values read from LDS or derived from the thread index are divergent to the compiler: what is wave-uniform is said
@@ -358,6 +409,37 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
   const uint32_t zsecs = (nbz + 3u) / 4u, upt = zsecs * 64u;
   uint32_t xcd = blockIdx.x & 7u, xcd_tries = 0;
 
+  // The next segment's image is fetched by the walkers when they have walked a round's last slab, while the movers write
+  // that slab out (3 x 16 bytes per walker thread): the walkers' part of the image replaces the current one, which only
+  // they read; the movers' part goes to the other of two buffers.
+  constexpr int kImgRegs = (int)((sizeof(SegImage) / 16 + kHitThreads - 1) / kHitThreads);
+  [[maybe_unused]] bool ahead = false;       // (the segment loop is running)
+  [[maybe_unused]] bool ahead_same = false;  // the next segment is this brick's next round ...
+  [[maybe_unused]] uint32_t ahead_seg = 0;   // ... this one; otherwise the next brick's first (L.misc[24..])
+  [[maybe_unused]] bool take_entry = false;  // a brick's first round: one mover thread draws the workgroup's next brick
+  int cur = 0;  // the rows buffer of the round at work
+  // The workgroup's next listed brick: from its XCD's list, then (that one exhausted) the next XCD's ...  One thread; the
+  // entry (first segment, rounds, groups of round 0, found) goes to L.misc[20 + 4 slot ..]: two slots, the brick at work and
+  // the one after it; the list position is kept in L.misc[28..29].
+  int eb = 0;  // the slot of the brick at work
+  [[maybe_unused]] auto draw_entry = [&](const int slot) {
+    if constexpr (!BUILD) {
+      uint32_t lxx = L.misc[28], tries = L.misc[29];
+      uint4 en = make_uint4(0u, 0u, 0u, 0u);
+      while (tries < 8u) {
+        const uint32_t n = atomicAdd(&pool.ctl->walk_next[lxx], 1u);
+        if (n < pool.ctl->list_n[lxx]) {
+          en = pool.list[(size_t)lxx * pool.list_stride + n];
+          en.w = 1u;
+          break;
+        }
+        lxx = (lxx + 1u) & 7u;
+        ++tries;
+      }
+      L.misc[20 + 4 * slot] = en.x; L.misc[21 + 4 * slot] = en.y; L.misc[22 + 4 * slot] = en.z; L.misc[23 + 4 * slot] = en.w;
+      L.misc[28] = lxx; L.misc[29] = tries;
+    }
+  };
   // ---- the slabs of one round: R rows, G groups, kexp = ceil(log2 of the most hits a row takes); the records, the group
   //      table and the rows' coefficients are in LDS
   [[maybe_unused]] auto run_slabs = [&](const int R, const int G, const int kexp) {
@@ -382,14 +464,15 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
         for (int i = 0; i < kMI; ++i) {
           const int mr = (i * kRPI + m_sub) * kMovers + (wave - kWalkers);
           old[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (i * kRPI * kMovers < R && mr < R && !L.rowfresh[mr]) old[i] = ld_stream(feat + (int64_t)L.rown[mr] * row_vecs + m_pc);
+          if (i * kRPI * kMovers < R && mr < R && !L.rows[cur].rowfresh[mr]) old[i] = ld_stream(feat + (int64_t)L.rows[cur].rown[mr] * row_vecs + m_pc);
         }
+        if (take_entry && tid == kHitThreads) draw_entry(eb ^ 1);  // (published by the slab's barriers)
         int* acc = L.acc;
         for (int p = 0; p < n_pass; ++p) {
           lds_barrier();  // the walkers have added this slab's samples
           BT(6);
           asm volatile("" : "+v"(m_sub), "+v"(m_pc));
-          const float inv = fx ? pow2f(-scale_exp(slab_max_bits<CPL>(cmax, v.D, p), kexp)) : 1.0f;
+          const float inv = fx ? pow2f(-scale_exp((uint32_t)rfl((int)L.slabm[p & 127]), kexp)) : 1.0f;
           // new = old * b + acc * a.  The old pieces were requested a whole walk ago: one explicit wait (the BUILTIN, which
           // the wait-count pass sees) -- left to itself the pass puts a vmcnt(0) into every conditional iteration, where it
           // waits for the store of the iteration before: a memory round trip per iteration
@@ -398,7 +481,7 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
           for (int i = 0; i < kMI; ++i) {
             const int mr = (i * kRPI + m_sub) * kMovers + (wave - kWalkers);
             if (i * kRPI * kMovers < R && mr < R) {
-              const float a = L.rowA[mr], b = L.rowB[mr];
+              const float a = L.rows[cur].rowA[mr], b = L.rows[cur].rowB[mr];
               // channel ch of the slab lives in lane ch / CPL, slot ch % CPL of the walkers' layout
               float sm[kCPP];
 #pragma unroll
@@ -409,7 +492,7 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
                 *ap = 0;
                 sm[j] = (fx ? (float)raw * inv : __builtin_bit_cast(float, raw)) * a;
               }
-              float4* gp = feat + (int64_t)L.rown[mr] * row_vecs + (int64_t)p * kPPR + m_pc;
+              float4* gp = feat + (int64_t)L.rows[cur].rown[mr] * row_vecs + (int64_t)p * kPPR + m_pc;
               float4 o;
               if constexpr (BF16) {
                 const uint32_t ox = __builtin_bit_cast(uint32_t, old[i].x), oy = __builtin_bit_cast(uint32_t, old[i].y);
@@ -422,7 +505,11 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
                 o.x = old[i].x * b + sm[0]; o.y = old[i].y * b + sm[1];
                 o.z = old[i].z * b + sm[2]; o.w = old[i].w * b + sm[3];
               }
+#ifndef SAF_BRICK_NOROWS  // ablation: no row stores (and no row loads below)
               st_stream(gp, o);
+#else
+              asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+#endif
             }
           }
           // (a loop of its own: behind each store, a load would make the wait-count pass drain the queue in every
@@ -431,8 +518,10 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
 #pragma unroll
             for (int i = 0; i < kMI; ++i) {
               const int mr = (i * kRPI + m_sub) * kMovers + (wave - kWalkers);
-              if (i * kRPI * kMovers < R && mr < R && !L.rowfresh[mr])
-                old[i] = ld_stream(feat + (int64_t)L.rown[mr] * row_vecs + (int64_t)(p + 1) * kPPR + m_pc);
+#ifndef SAF_BRICK_NOROWS
+              if (i * kRPI * kMovers < R && mr < R && !L.rows[cur].rowfresh[mr])
+                old[i] = ld_stream(feat + (int64_t)L.rows[cur].rown[mr] * row_vecs + (int64_t)(p + 1) * kPPR + m_pc);
+#endif
             }
           }
           BT(7);
@@ -445,11 +534,31 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
         for (int p = 0; p < n_pass; ++p) {
           wc.lane_off = (uint32_t)p * (kSlabCh * 4u) + (uint32_t)lane * (4u * CPL);
           if (fx)
-            walk_slab<CPL, true>(L, wc, wave, pow2f(scale_exp(slab_max_bits<CPL>(cmax, v.D, p), kexp)));
+            walk_slab<CPL, true>(L, wc, wave, pow2f(scale_exp((uint32_t)rfl((int)L.slabm[p & 127]), kexp)) WT_ARG);
           else
-            walk_slab<CPL, false>(L, wc, wave, 1.0f);
+            walk_slab<CPL, false>(L, wc, wave, 1.0f WT_ARG);
           BT(6);
           lds_barrier();  // this slab's samples are in the accumulator
+          // the last slab is walked: the next segment's image
+          const uint32_t* nx_ent = &L.misc[20 + 4 * (eb ^ 1)];
+          const uint32_t nx_seg = ahead_same ? ahead_seg : (uint32_t)rfl((int)nx_ent[0]);
+          const int next_n16 = (int)(kSegFixed / 16) + 1 + min(rfl((int)(ahead_same ? L.rows[cur].hdr[4] : nx_ent[2])), kHC);
+          if (p + 1 == n_pass && ahead && (ahead_same || rfl((int)nx_ent[3]) != 0)) {
+            const uint4* next_sg = reinterpret_cast<const uint4*>(pool.segs + (size_t)nx_seg * kSegBytes);
+            uint4 img[kImgRegs];
+#pragma unroll
+            for (int k = 0; k < kImgRegs; ++k) {
+              const int i16 = tid + k * kHitThreads;
+              if (i16 < next_n16) img[k] = next_sg[i16];
+            }
+            uint4* d_rows = reinterpret_cast<uint4*>(&L.rows[cur ^ 1]);
+            uint4* d_walk = reinterpret_cast<uint4*>(&L.walk) - kRows16;
+#pragma unroll
+            for (int k = 0; k < kImgRegs; ++k) {
+              const int i16 = tid + k * kHitThreads;
+              if (i16 < next_n16) (i16 < kRows16 ? d_rows : d_walk)[i16] = img[k];
+            }
+          }
           BT(7);
           lds_barrier();  // the movers have written the slab and cleared the accumulator
           BT(8);
@@ -461,31 +570,28 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
   // ---- BUILD: one round's records, group table and row coefficients go to the pool
   uint32_t seg_base = 0;  // first segment of this brick
   int seg_round = 0;
+  uint32_t list_slot = 0;  // this brick's entry in its XCD's list
   [[maybe_unused]] auto write_segment = [&](const int R, const int nh, const int G, const int kexp) {
     if constexpr (BUILD) {
       if (seg_base == 0xffffffffu) {
         lds_barrier();
         return;
       }
-      unsigned char* sg = pool.segs + (size_t)(seg_base + (uint32_t)seg_round) * kSegBytes;
       if (tid == 0) {
-        uint32_t* h = reinterpret_cast<uint32_t*>(sg + kSegHdr);
-        h[0] = (uint32_t)R; h[1] = (uint32_t)nh; h[2] = (uint32_t)G; h[3] = (uint32_t)kexp;
+        L.rows[cur].hdr[0] = (uint32_t)R; L.rows[cur].hdr[1] = (uint32_t)nh; L.rows[cur].hdr[2] = (uint32_t)G; L.rows[cur].hdr[3] = (uint32_t)kexp;
+        L.rows[cur].hdr[4] = (uint32_t)kHC;
+        // the walk kernel reads a segment up to its last group: a first round's count is in the list, a later one's in
+        // the header of the round before
+        if (seg_round == 0)
+          pool.list[list_slot].z = (uint32_t)G;
+        else
+          reinterpret_cast<uint32_t*>(pool.segs + (size_t)(seg_base + (uint32_t)seg_round - 1u) * kSegBytes)[4] = (uint32_t)G;
       }
-      if (tid < R) {
-        reinterpret_cast<uint32_t*>(sg + kSegRown)[tid] = L.rown[tid];
-        reinterpret_cast<float*>(sg + kSegRowA)[tid] = L.rowA[tid];
-        reinterpret_cast<float*>(sg + kSegRowB)[tid] = L.rowB[tid];
-        sg[kSegFresh + tid] = L.rowfresh[tid];
-      }
-      for (int i = tid; i < nh; i += kNT) {
-        reinterpret_cast<uint32_t*>(sg + kSegRecK)[i] = L.rec_k[i];
-        reinterpret_cast<float2*>(sg + kSegRecG)[i] = L.rec_g[i];
-      }
-      for (int i = tid; i <= G; i += kNT) {
-        reinterpret_cast<uint16_t*>(sg + kSegGrpStart)[i] = L.grp_start[i];
-        reinterpret_cast<uint4*>(sg + kSegGrpOff)[i] = L.grp_off[i];
-      }
+      lds_barrier();
+      uint4* dst = reinterpret_cast<uint4*>(pool.segs + (size_t)(seg_base + (uint32_t)seg_round) * kSegBytes);
+      const uint4* src = reinterpret_cast<const uint4*>(&L.rows[0]);  // (rows[0] and walk: one image)
+      const int n16 = (int)(kSegFixed / 16) + G + 1;
+      for (int i = tid; i < n16; i += kNT) dst[i] = src[i];
       ++seg_round;
       lds_barrier();  // the arrays are rewritten by the next round
     }
@@ -502,43 +608,54 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
       int4* acc4 = reinterpret_cast<int4*>(L.acc);
       for (int i = tid; i < kBV * kSlabCh / 4; i += kNT) acc4[i] = make_int4(0, 0, 0, 0);
     }
-    // ---- the bricks the build kernel has prepared: per listed brick, its rounds' segments one after the other
+    for (int p = tid; p < n_pass && p < 128; p += kNT) L.slabm[p] = slab_max_bits<CPL>(cmax, v.D, p);
+    lds_barrier();
+    // ---- the bricks the build kernel has prepared.  Every XCD has its own list (the build workgroups of its tiles filled
+    //      it) and its workgroups draw from it -- the map taps and rows of neighbouring bricks stay in one L2.  A brick is
+    //      drawn while the one before it is walked, and the walkers fetch a segment's image as soon as they have walked
+    //      the last slab of the segment before: it lands while the movers write that slab out.
     if (pool.split) {
-      const uint32_t n_list = pool.ctl->list_n;
-      for (;;) {
-        if (tid == 0) L.misc[0] = atomicAdd(&pool.ctl->walk_next, 1u);
-        lds_barrier();
-        const uint32_t e = (uint32_t)rfl((int)L.misc[0]);
-        if (e >= n_list) break;
-        const uint2 ent = pool.list[e];
-        const uint32_t s0 = (uint32_t)rfl((int)ent.x), n_r = (uint32_t)rfl((int)ent.y);
+      if (tid == kHitThreads) {
+        L.misc[28] = blockIdx.x & 7u;
+        L.misc[29] = 0u;
+        draw_entry(0);
+      }
+      lds_barrier();
+      ahead = true;
+      bool have_image = false;  // the segment's image is already in LDS
+      while (rfl((int)L.misc[23 + 4 * eb]) != 0) {
+        const uint32_t s0 = (uint32_t)rfl((int)L.misc[20 + 4 * eb]), n_r = (uint32_t)rfl((int)L.misc[21 + 4 * eb]);
+        const uint32_t g0 = (uint32_t)rfl((int)L.misc[22 + 4 * eb]);
         for (uint32_t r = 0; r < n_r; ++r) {
-          const unsigned char* sg = pool.segs + (size_t)(s0 + r) * kSegBytes;
-          const uint32_t* h = reinterpret_cast<const uint32_t*>(sg + kSegHdr);
-          const int R = rfl((int)h[0]), nh = rfl((int)h[1]), G = rfl((int)h[2]), kexp = rfl((int)h[3]);
-          if (tid < R) {
-            L.rown[tid] = reinterpret_cast<const uint32_t*>(sg + kSegRown)[tid];
-            L.rowA[tid] = reinterpret_cast<const float*>(sg + kSegRowA)[tid];
-            L.rowB[tid] = reinterpret_cast<const float*>(sg + kSegRowB)[tid];
-            L.rowfresh[tid] = sg[kSegFresh + tid];
+          if (have_image) {
+            cur ^= 1;
+          } else {  // (the workgroup's first segment)
+            const uint4* sg = reinterpret_cast<const uint4*>(pool.segs + (size_t)(s0 + r) * kSegBytes);
+            uint4* d_rows = reinterpret_cast<uint4*>(&L.rows[cur]);
+            uint4* d_walk = reinterpret_cast<uint4*>(&L.walk) - kRows16;
+            const int n16 = (int)(kSegFixed / 16) + (int)(r == 0 ? g0 : (uint32_t)kHC) + 1;
+            for (int i16 = tid; i16 < n16; i16 += kNT) (i16 < kRows16 ? d_rows : d_walk)[i16] = sg[i16];
+            lds_barrier();
           }
-          for (int i = tid; i < nh; i += kNT) {
-            L.rec_k[i] = reinterpret_cast<const uint32_t*>(sg + kSegRecK)[i];
-            L.rec_g[i] = reinterpret_cast<const float2*>(sg + kSegRecG)[i];
-          }
-          for (int i = tid; i <= G; i += kNT) {
-            L.grp_start[i] = reinterpret_cast<const uint16_t*>(sg + kSegGrpStart)[i];
-            L.grp_off[i] = reinterpret_cast<const uint4*>(sg + kSegGrpOff)[i];
-          }
-          lds_barrier();
+          const int R = rfl((int)L.rows[cur].hdr[0]), G = rfl((int)L.rows[cur].hdr[2]), kexp = rfl((int)L.rows[cur].hdr[3]);
+          ahead_same = r + 1 < n_r;
+          ahead_seg = s0 + r + 1;
+          take_entry = r == 0;
           BT(5);
           run_slabs(R, G, kexp);
-          if (r + 1 < n_r) {  // (see the end of a round below)
+          have_image = true;
+          // (a brick's next round reads the rows this one has written: see the end of a round below.  The round's last
+          //  barrier has also published the next image.)
+          if (ahead_same) {
             if (wave >= kWalkers) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             lds_barrier();
           }
         }
+        eb ^= 1;
       }
+      ahead = false;  // (the bricks built here have nothing to fetch ahead)
+      take_entry = false;
+      cur = 0;
     }
   }
 
@@ -602,7 +719,7 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
 #pragma unroll
     for (int w = 0; w < kMaskWords; ++w) any |= mk[w];
     // (the zeroing of the bit matrix rides on this barrier)
-    if (tid < kWin * 2) L.mf[tid] = 0u;
+    for (int i = tid; i < kWin * 2; i += kNT) L.mf[i] = 0u;
     if (wave == 0) {
       const unsigned long long wany = __ballot(any != 0u);
       if (lane == 0) L.misc[4] = wany != 0ull ? 1u : 0u;
@@ -683,8 +800,11 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
       if (tid == 0) {
         const uint32_t b0 = atomicAdd(&pool.ctl->seg_next, (uint32_t)n_r);
         if (b0 + (uint32_t)n_r <= pool.cap) {
-          pool.list[atomicAdd(&pool.ctl->list_n, 1u)] = make_uint2(b0, (uint32_t)n_r);
+          const uint32_t lx = blockIdx.x & 7u;  // the XCD this brick's tile belongs to
+          const uint32_t slot = lx * pool.list_stride + atomicAdd(&pool.ctl->list_n[lx], 1u);
+          pool.list[slot] = make_uint4(b0, (uint32_t)n_r, 0u, 0u);
           L.misc[5] = b0;
+          L.misc[7] = slot;
         } else {
           const uint32_t o = atomicAdd(&pool.ctl->over_n, 1u);
           pool.over[(size_t)o * kOverWords] = code;
@@ -694,6 +814,7 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
       }
       lds_barrier();
       seg_base = (uint32_t)rfl((int)L.misc[5]);
+      list_slot = (uint32_t)rfl((int)L.misc[7]);
       seg_round = 0;
       if (seg_base == 0xffffffffu && vth)  // the walk kernel rebuilds this brick: it needs the weights as they are NOW
         pool.over[(size_t)L.misc[6] * kOverWords + 1 + tid] = (uint32_t)w_cur;
@@ -725,8 +846,8 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
         const int row = __popcll(bal & lt_mask);
         if (touched) {
           L.vrow[tid] = (uint8_t)row;
-          L.rown[row] = n;
-          L.rowfresh[row] = w_cur == 0 ? 1 : 0;  // never written: all zeros by construction, not read
+          L.rows[cur].rown[row] = n;
+          L.rows[cur].rowfresh[row] = w_cur == 0 ? 1 : 0;  // never written: all zeros by construction, not read
 #pragma unroll
           for (int w = 0; w < kMaskWords; ++w) {
             uint32_t mm = rm[w];
@@ -734,7 +855,7 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
               const int f = __ffs((int)mm) - 1 + 32 * w;
               mm &= mm - 1u;
               const int slot = (int)L.off[f] - base + rank_in_frame(&L.mf[f * 2], tid);
-              L.rec_k[slot] = (uint32_t)tid | ((uint32_t)f << 8);
+              L.walk.rec_k[slot] = (uint32_t)tid | ((uint32_t)f << 8);
             }
           }
         }
@@ -750,8 +871,8 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
         //      (clipfusion.py:647-659, :701-713; clip_seem_fusion.py:786-822)
         float* stage;
         if constexpr (BUILD) stage = L.stage; else stage = reinterpret_cast<float*>(L.acc);
-        for (int j = tid; j < nh; j += kHitThreads) {
-          const uint32_t vf = L.rec_k[j];
+        for (int j = tid; j < nh; j += kNHit) {
+          const uint32_t vf = L.walk.rec_k[j];
           const int tv = (int)(vf & 127u), f = (int)(vf >> 8);
           const int hx = bx * kBX + ((tv >> 4) & 3), hy = by * kBY + ((tv >> 2) & 3), hz = bz * kBZ + (tv & 3);
           const uint32_t hn = ((uint32_t)hx * (uint32_t)v.ny + (uint32_t)hy) * (uint32_t)v.nz + (uint32_t)hz;
@@ -762,8 +883,8 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
           const float ux = unnormalize(p.gx, half_px), uy = unnormalize(p.gy, half_py);
           const float wx = ux - __builtin_floorf(ux), wy = uy - __builtin_floorf(uy);
           const int cx = min(max(bw.x0, -2), wa.npx) + 2, cy = min(max(bw.y0, -2), wa.npy) + 2;
-          L.rec_g[j] = make_float2(wx, wy);
-          L.rec_k[j] = (uint32_t)L.vrow[tv] | ((uint32_t)cx << 7) | ((uint32_t)cy << 15) | ((uint32_t)f << 23);
+          L.walk.rec_g[j] = make_float2(wx, wy);
+          L.walk.rec_k[j] = (uint32_t)L.vrow[tv] | ((uint32_t)cx << 7) | ((uint32_t)cy << 15) | ((uint32_t)f << 23);
           if (!redo) {
             kf.rgb = tab->rgb[f];
             kf.label_map = tab->label_map[f];
@@ -801,8 +922,8 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
           }
         }
         const float a = SUM ? 1.0f : 1.0f / (float)(w_cur + k_v);
-        L.rowA[row] = a;
-        L.rowB[row] = SUM ? 1.0f : (float)w_cur * a;
+        L.rows[cur].rowA[row] = a;
+        L.rows[cur].rowB[row] = SUM ? 1.0f : (float)w_cur * a;
         w_cur += k_v;
       }
       lds_barrier();
@@ -814,11 +935,11 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
         for (int i = tid; i < R * (kSlabCh / 4); i += kNT) acc4[i] = make_int4(0, 0, 0, 0);
       }
       if (wave < kWalkers) {
-        for (int win = wave; win < kWindows; win += kWalkers) {
+        for (int win = wave; win < kWindows; win += kNW) {
           const int wb = win * 64, cnt = min(64, nh - wb);  // (cnt <= 0: no such window)
           const bool hv = lane < cnt;
-          const uint32_t key = hv ? L.rec_k[wb + lane] : 0xffffffffu;
-          const float2 g = L.rec_g[wb + lane];
+          const uint32_t key = hv ? L.walk.rec_k[wb + lane] : 0xffffffffu;
+          const float2 g = L.walk.rec_g[wb + lane];
           const uint32_t sk = key >> 7;
           int rank = 0;
           if (cnt > 0) {
@@ -829,11 +950,11 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
           }
           wave_lds_sync();
           if (hv) {
-            L.rec_k[wb + rank] = key;
-            L.rec_g[wb + rank] = g;
+            L.walk.rec_k[wb + rank] = key;
+            L.walk.rec_g[wb + rank] = g;
           }
           wave_lds_sync();
-          const uint32_t skey = hv ? L.rec_k[wb + lane] : 0xffffffffu;
+          const uint32_t skey = hv ? L.walk.rec_k[wb + lane] : 0xffffffffu;
           const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
           const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
           if (lane == 0) L.misc[16 + win] = (uint32_t)__popcll(heads);
@@ -845,10 +966,10 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
       const int g_w0 = rfl((int)L.misc[16]), g_w1 = rfl((int)L.misc[17]), g_w2 = rfl((int)L.misc[18]), g_w3 = rfl((int)L.misc[19]);
       const int G = g_w0 + g_w1 + g_w2 + g_w3;
       if (wave < kWalkers) {
-        for (int win = wave; win < kWindows; win += kWalkers) {
+        for (int win = wave; win < kWindows; win += kNW) {
           const int wb = win * 64, cnt = min(64, nh - wb);
           const bool hv = lane < cnt;
-          const uint32_t skey = hv ? L.rec_k[wb + lane] : 0xffffffffu;
+          const uint32_t skey = hv ? L.walk.rec_k[wb + lane] : 0xffffffffu;
           const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
           const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
           const int gbase = win == 0 ? 0 : (win == 1 ? g_w0 : (win == 2 ? g_w0 + g_w1 : g_w0 + g_w1 + g_w2));
@@ -863,13 +984,13 @@ __global__ __launch_bounds__(BUILD ? kHitThreads : kBThreads) __attribute__((amd
             o.y = (x1ok && y0ok) ? ib + (uint32_t)(y0 * wa.npx + x0 + 1) * row_bytes : kTapOutside;
             o.z = (x0ok && y1ok) ? ib + (uint32_t)((y0 + 1) * wa.npx + x0) * row_bytes : kTapOutside;
             o.w = (x1ok && y1ok) ? ib + (uint32_t)((y0 + 1) * wa.npx + x0 + 1) * row_bytes : kTapOutside;
-            L.grp_off[gi] = o;
-            L.grp_start[gi] = (uint16_t)(wb + lane);
+            L.walk.grp_off[gi] = o;
+            L.walk.grp_start[gi] = (uint16_t)(wb + lane);
           }
         }
         if (tid == 0) {
-          L.grp_off[G] = make_uint4(kTapOutside, kTapOutside, kTapOutside, kTapOutside);
-          L.grp_start[G] = (uint16_t)nh;
+          L.walk.grp_off[G] = make_uint4(kTapOutside, kTapOutside, kTapOutside, kTapOutside);
+          L.walk.grp_start[G] = (uint16_t)nh;
         }
       }
       lds_barrier();
@@ -966,11 +1087,18 @@ size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
 // a brick that finds the pool exhausted is built by the walk kernel, slower, never wrong).
 struct AuxLayout {
   size_t cams, ctl, list, over, segs, parity_bytes;
-  uint32_t cap;
+  uint32_t cap, list_stride;
   bool fits;
 };
-size_t aux_fixed(uint32_t nb) {
-  return pad256((size_t)kWin * kCamFloats * sizeof(float)) + pad256(sizeof(BrickCtl)) + pad256((size_t)nb * sizeof(uint2)) +
+// workgroups of the build kernel (one per brick position of the XCD-compact order, ragged edges included) per XCD = the
+// length of an XCD's list
+uint32_t build_wgs_per_xcd(const KVol& kv) {
+  const uint32_t nbx = ((uint32_t)kv.nx + kBX - 1) / kBX, nby = ((uint32_t)kv.ny + kBY - 1) / kBY, nbz = ((uint32_t)kv.nz + kBZ - 1) / kBZ;
+  const uint32_t n_tiles = ((nbx + 3u) / 4u) * ((nby + 3u) / 4u), upt = ((nbz + 3u) / 4u) * 64u;
+  return ((n_tiles + 7u) / 8u) * upt;
+}
+size_t aux_fixed(uint32_t nb, uint32_t list_entries) {
+  return pad256((size_t)kWin * kCamFloats * sizeof(float)) + pad256(sizeof(BrickCtl)) + pad256((size_t)list_entries * sizeof(uint4)) +
          pad256((size_t)nb * kOverWords * sizeof(uint32_t));
 }
 AuxLayout aux_layout(const KVol& kv, size_t avail) {
@@ -979,7 +1107,8 @@ AuxLayout aux_layout(const KVol& kv, size_t avail) {
   a.cams = 0;
   a.ctl = a.cams + pad256((size_t)kWin * kCamFloats * sizeof(float));
   a.list = a.ctl + pad256(sizeof(BrickCtl));
-  a.over = a.list + pad256((size_t)nb * sizeof(uint2));
+  a.list_stride = build_wgs_per_xcd(kv);
+  a.over = a.list + pad256((size_t)8 * a.list_stride * sizeof(uint4));
   a.segs = a.over + pad256((size_t)nb * kOverWords * sizeof(uint32_t));
   a.fits = avail >= cmax_bytes(kv.D) + 2 * a.segs;
   const size_t per_parity = a.fits ? (avail - cmax_bytes(kv.D)) / 2 : a.segs;
@@ -997,7 +1126,8 @@ BrickPool make_pool(const KVol& kv, void* aux, size_t aux_bytes, int parity, int
   unsigned char* p = static_cast<unsigned char*>(aux) + cmax_bytes(kv.D) + (size_t)parity * a.parity_bytes;
   BrickPool pool;
   pool.segs = p + a.segs;
-  pool.list = reinterpret_cast<uint2*>(p + a.list);
+  pool.list = reinterpret_cast<uint4*>(p + a.list);
+  pool.list_stride = a.list_stride;
   pool.over = reinterpret_cast<uint32_t*>(p + a.over);
   pool.ctl = reinterpret_cast<BrickCtl*>(p + a.ctl);
   pool.cap = a.cap;
@@ -1032,7 +1162,7 @@ bool brick_split() {
 // pool of a grid with a tenth more bricks than n_vox / 64 (ragged edges); brick_aux_fits() says whether a given grid fits.
 size_t brick_aux_bytes_est(int64_t n_vox, int D) {
   const uint32_t nb = (uint32_t)(n_vox / 64 + n_vox / 640 + 4096);
-  return cmax_bytes(D) + 2 * (aux_fixed(nb) + ((size_t)nb + nb / 4 + 64) * kSegBytes);
+  return cmax_bytes(D) + 2 * (aux_fixed(nb, 2 * nb) + ((size_t)nb + nb / 4 + 64) * kSegBytes);
 }
 bool brick_aux_fits(const KVol& kv, size_t avail) { return aux_layout(kv, avail).fits; }
 
@@ -1044,13 +1174,11 @@ int launch_brick_build(const KVol& kv, const WinArgs& wa, const WinTable* tab, s
   const BrickPool pool = make_pool(kv, aux, aux_bytes, parity, 1, &cams);
   if (hipMemsetAsync(pool.ctl, 0, sizeof(BrickCtl), s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(brick pool control)");
   hipLaunchKernelGGL(cam_table_kernel, dim3(1), dim3(128), 0, s, tab, wa.F, const_cast<float*>(cams));
-  const uint32_t nbx = ((uint32_t)kv.nx + kBX - 1) / kBX, nby = ((uint32_t)kv.ny + kBY - 1) / kBY, nbz = ((uint32_t)kv.nz + kBZ - 1) / kBZ;
-  const uint32_t n_tiles = ((nbx + 3u) / 4u) * ((nby + 3u) / 4u), upt = ((nbz + 3u) / 4u) * 64u;
-  const uint32_t grid = 8u * ((n_tiles + 7u) / 8u) * upt;
+  const uint32_t grid = 8u * build_wgs_per_xcd(kv);
   const bool sum = kv.accum == SAF_SUM;
   // (the build does not depend on the feature dtype or width: one instantiation per accumulation mode)
   BrickFn fn = sum ? fuse_brick_kernel<1, true, false, true> : fuse_brick_kernel<1, false, false, true>;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kHitThreads), sizeof(BuildLds), s, kv, wa, tab, nullptr, (uint32_t)img_bytes, stats, nullptr,
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), s, kv, wa, tab, nullptr, (uint32_t)img_bytes, stats, nullptr,
                      hitmask, mask_plane, nullptr, nullptr, cams, pool);
   return check_launch("fuse_brick_kernel (build)");
 }
@@ -1101,6 +1229,14 @@ int launch_fuse_bricks(const KVol& kv, const WinArgs& wa, const WinTable* tab, c
       }
       memset(t, 0, sizeof(t));
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_brick_t), t, sizeof(t));
+      unsigned long long w[8];
+      if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_walk_t), sizeof(w)) == hipSuccess) {
+        const double tot = (double)(w[0] + w[1] + w[2] + w[3]);
+        fprintf(stderr, "[brick timing] walk: issue %.1f%% records %.1f%% tap wait %.1f%% hits %.1f%% (%.3g wave-cycles; %llu batch-waves, %llu hit-waves)\n",
+                100.0 * w[0] / tot, 100.0 * w[1] / tot, 100.0 * w[2] / tot, 100.0 * w[3] / tot, tot, w[4], w[5]);
+        memset(w, 0, sizeof(w));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_t), w, sizeof(w));
+      }
     }
   }
 #endif

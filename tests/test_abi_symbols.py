@@ -104,7 +104,7 @@ def test_committed_bench_line_keeps_the_contract():
     driver's contract, the roofline and cpu_baseline objects included."""
     import json
 
-    path = os.path.join(ROOT, "profiles", "r02", "bench_n1.json")
+    path = os.path.join(ROOT, "profiles", "r03", "bench_n1.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -120,3 +120,14 @@ def test_committed_bench_line_keeps_the_contract():
         assert k in c, k
     assert c["kind"] in ("port", "reference")
     assert abs(d["value"] - d["config"]["frames_per_rank"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
+    # round 3: the side evidence rides on the driver's line
+    assert d["end_to_end"] is not None and d["end_to_end"]["value"] > 0
+    assert d["hbm_copy_GBps"] > 1000 and r["traffic"] is not None
+    side = d["side_workloads"]
+    for k in ("config2_128cube_f32", "config3_256cube_bf16_labels", "coherent_scene_depth_B", "config5_row_argmax",
+              "config5_heat_maps", "config5_query_max", "config3_end_to_end"):
+        assert k in side and side[k]["value"] is not None, k
+    for k in ("config2_128cube_f32", "config5_row_argmax"):
+        rr = side[k]["roofline"]
+        assert rr["bound"] in ("hbm", "mfma") and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3
+    assert d["slab_by_slab_fuse"]["ratio"] < 1.25
