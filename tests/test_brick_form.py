@@ -181,3 +181,53 @@ def test_default_form_by_feature_width(monkeypatch):
         else:
             assert not torch.equal(one.clip_feat, win.clip_feat), "expected the brick form (folded updates)"
             _feat_close(win.clip_feat, one.clip_feat, 5e-6, f"D = {dim}")
+
+
+def test_full_size_brick_form_against_the_oracle(oracle, monkeypatch):
+    """The brick form at FULL size and by DEFAULT (no SAF_WIN_FORM): 256^3 x 320 fp32 (5.4 G elements: rows beyond 2^32
+    elements; a width the row kernel does not take), 20 frames 640x480 -- 12 of the random-depth scene, 8 of the coherent one
+    with missing depth, 5 of those from a camera at rest -- against the CPU oracle over ALL 16.8 M voxels: weights and
+    tsdf_weight exactly, tsdf and rgb within 1e-4, every touched feature row within 1e-4 of its largest magnitude."""
+    import bench
+    import psutil
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9 or psutil.virtual_memory().available < 60e9:
+        pytest.skip("needs 22 GB of device and 2 x 22 GB of host memory for the 256^3 x 320 fp32 volumes")
+    from test_gpu_parity import _close
+
+    monkeypatch.delenv("SAF_WIN_FORM", raising=False)
+    w, h, d = 640, 480, 320
+    grid = syn.make_grid(256)
+    npy, npx = syn.feature_map_shape(w, h)
+    frames = syn.make_frames(8181, 12, width=w, height=h, feat_dim=d, npy=npy, npx=npx, depth_kind="A")
+    fb = syn.make_frames(8182, 8, width=w, height=h, feat_dim=d, npy=npy, npx=npx, depth_kind="B", missing_depth_frac=0.1)
+    for i in range(4, 8):
+        fb[i] = dict(fb[i], depth=fb[3]["depth"], pose=fb[3]["pose"], K=fb[3]["K"])
+    frames += fb
+    fz = _fuse(_build(grid, d, False, _abi.SAF_RUNNING_MEAN, torch.float32), frames, False)
+    st = fz.stats()
+    assert st["window_rows"] > 0, "the windowed path did not run"
+    cat = lambda k: torch.cat([f[k] for f in frames])
+    oracle.set_threads(bench.host_cores())
+    try:
+        vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, d)
+        vol.integrate(cat("depth"), cat("rgb"), cat("pose"), cat("K"), cat("feat"))
+    finally:
+        oracle.set_threads(1)
+    assert torch.equal(fz.weight.cpu(), vol.weight) and torch.equal(fz.tsdf_weight.cpu(), vol.tsdf_weight)
+    assert int(vol.weight.sum()) == st["valid"]
+    _close(fz.tsdf, vol.tsdf, "tsdf, all voxels")
+    _close(fz.rgb, vol.rgb, "rgb, all voxels")
+    touched = torch.nonzero(vol.weight > 0)[:, 0]
+    assert int(touched[-1]) * d > 2 ** 32, "no touched row beyond 2^32 elements"
+    worst = 0.0
+    for s0 in range(0, touched.numel(), 1 << 20):  # (in pieces: the device copy of a piece, not of the volume)
+        rows = touched[s0:s0 + (1 << 20)]
+        got, want = fz.clip_feat[rows.cuda()].cpu(), vol.clip_feat[rows]
+        scale = want.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        worst = max(worst, float(((got - want).abs() / scale).max()))
+    assert worst <= 1e-4, f"clip_feat: {worst:.3g} of the row's largest magnitude"
+    untouched = torch.nonzero(vol.weight == 0)[:, 0]
+    sample = untouched[torch.randperm(untouched.numel(), generator=torch.Generator().manual_seed(1))[:200000]]
+    assert not bool(fz.clip_feat[sample.cuda()].any()), "an untouched row is not zero"
