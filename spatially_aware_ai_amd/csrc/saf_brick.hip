@@ -181,6 +181,7 @@ __device__ __forceinline__ int rank_in_frame(const uint32_t* __restrict__ mf_row
 }
 
 // CPL consecutive channels of a map row
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 template <int CPL>
 struct TapVec {
   float v[CPL];
@@ -267,12 +268,32 @@ __device__ __forceinline__ void walk_process(BrickLds<CPL>& L, const WalkCtx& cx
         const int li = l - c0;
         const float wnw = rl_f(w_nw, li), wne = rl_f(w_ne, li), wsw = rl_f(w_sw, li), wse = rl_f(w_se, li);
         const int idx = __builtin_amdgcn_readlane(rowbase, li) - li + cx.lane;  // the hit's row, this lane
+        // (two channels per instruction: v_pk_mul_f32 / v_pk_fma_f32 with the hit's weight broadcast from an SGPR; the same
+        //  products and FMAs, channel by channel, as the scalar form)
+        float sv[CPL];
+        if constexpr (CPL % 2 == 0) {
+#pragma unroll
+          for (int c = 0; c < CPL; c += 2) {
+            const v2f_t t0 = {tp[u][0].v[c], tp[u][0].v[c + 1]}, t1 = {tp[u][1].v[c], tp[u][1].v[c + 1]};
+            const v2f_t t2 = {tp[u][2].v[c], tp[u][2].v[c + 1]}, t3 = {tp[u][3].v[c], tp[u][3].v[c + 1]};
+            v2f_t s2 = t0 * (v2f_t){wnw, wnw};
+            s2 = __builtin_elementwise_fma(t1, (v2f_t){wne, wne}, s2);
+            s2 = __builtin_elementwise_fma(t2, (v2f_t){wsw, wsw}, s2);
+            s2 = __builtin_elementwise_fma(t3, (v2f_t){wse, wse}, s2);
+            sv[c] = s2.x; sv[c + 1] = s2.y;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            float s1 = tp[u][0].v[c] * wnw;
+            s1 = __builtin_fmaf(tp[u][1].v[c], wne, s1);
+            s1 = __builtin_fmaf(tp[u][2].v[c], wsw, s1);
+            sv[c] = __builtin_fmaf(tp[u][3].v[c], wse, s1);
+          }
+        }
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          float s = tp[u][0].v[c] * wnw;
-          s = __builtin_fmaf(tp[u][1].v[c], wne, s);
-          s = __builtin_fmaf(tp[u][2].v[c], wsw, s);
-          s = __builtin_fmaf(tp[u][3].v[c], wse, s);
+          const float s = sv[c];
 #ifdef SAF_BRICK_NOATOM  // ablation: a plain LDS store instead of the atomic add (wrong sums, same instruction count)
           if (true) {
             L.acc[idx + c * 64] = cvt_rpi(s);
