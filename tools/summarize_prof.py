@@ -28,6 +28,11 @@ if ks:
             short = r["Name"].split("saf::(anonymous namespace)::")[1].split("(")[0] if "saf::(anonymous namespace)::" in r["Name"] else r["Name"]
             short = short.split("<")[0] + ("<" + short.split("<", 1)[1] if "<" in short else "")
             print(f"{short:40s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.2f} pct {r['Percentage']}")
+kh = newest(f"{src}/trace_headline/*/*_kernel_stats.csv")
+if kh:
+    shutil.copy(kh[0], f"{dst}/kernel_stats_headline.csv")
+    if os.path.exists(f"{src}/bench_headline_under_rocprof.json"):
+        shutil.copy(f"{src}/bench_headline_under_rocprof.json", f"{dst}/bench_headline_under_rocprof.json")
 if os.path.exists(f"{src}/bench_under_rocprof.json"):
     shutil.copy(f"{src}/bench_under_rocprof.json", f"{dst}/bench_under_rocprof.json")
 
