@@ -26,7 +26,8 @@
 //
 // The sum of a row's samples is kept in 32-bit FIXED POINT.  gfx950's LDS adds floats atomically at about three lanes
 // per clock (ds_add_f32: 193 cycles per wave instruction, tools/lds_atomic_bench.hip -- the first form of this kernel
-// spent 70 % of its time there) and integers at full rate (ds_add_u32: 7 cycles).  A sample is a convex combination of
+// spent 70 % of its time there) and integers at the LDS's write rate (ds_add_u32: one wave instruction per 4 cycles and CU,
+// tools/valu_probe.hip).  A sample is a convex combination of
 // map values, so with M = the largest magnitude of the slab's channels in the window's maps (chan_max_kernel) and k_max =
 // the most hits any row of the brick takes in this round, |sum| <= k_max M: every sample is scaled by the power of two
 // 2^(30 - ceil(log2 k_max) - ceil(log2 M)) (exact; folded into the bilinear weights), rounded to the nearest integer (the
