@@ -16,7 +16,6 @@ fallback: tensors that are not on the HIP device raise.
 from __future__ import annotations
 
 import ctypes as C
-import math
 
 import numpy as np
 import torch
