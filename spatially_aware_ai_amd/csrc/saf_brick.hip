@@ -56,6 +56,10 @@ constexpr int kBThreads = kBWaves * 64;
 constexpr int kHitThreads = kWalkers * 64;
 constexpr int kBuildThreads = 128;        // the build kernel: two waves per brick, eight bricks per CU
 constexpr int kWindows = 4;                // 64-hit windows of a round, sorted one by one
+#ifndef SAF_BRICK_GROUP_CAP
+#define SAF_BRICK_GROUP_CAP 16
+#endif
+constexpr int kGroupCap = SAF_BRICK_GROUP_CAP;  // most hits of one group (a power of two, <= 64)
 constexpr int kHC = kWindows * 64;         // hit records of one round (a brick with more hits takes its frames in rounds)
 static_assert(kHC >= kBV, "a frame's hits fit a round");
 #ifndef SAF_BRICK_P
@@ -978,7 +982,12 @@ __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((a
           wave_lds_sync();
           const uint32_t skey = hv ? L.walk.rec_k[wb + lane] : 0xffffffffu;
           const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
-          const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
+          // (a group of more than kGroupCap hits is cut into pieces with the same four map rows: one wave walks a batch's
+          //  hits one after the other -- in a coherent scene a brick's 64 voxels fall into one cell of a frame, and the
+          //  other walkers would watch one of them walk them all)
+          const uint32_t pgc = (uint32_t)__shfl_up((int)gk, kGroupCap);
+          const unsigned long long heads =
+              __ballot(hv && (lane == 0 || gk != pg || (lane >= kGroupCap && (lane & (kGroupCap - 1)) == 0 && gk == pgc)));
           if (lane == 0) L.misc[16 + win] = (uint32_t)__popcll(heads);
         }
       }
@@ -993,7 +1002,12 @@ __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((a
           const bool hv = lane < cnt;
           const uint32_t skey = hv ? L.walk.rec_k[wb + lane] : 0xffffffffu;
           const uint32_t gk = skey >> 7, pg = (uint32_t)__shfl_up((int)gk, 1);
-          const unsigned long long heads = __ballot(hv && (lane == 0 || gk != pg));
+          // (a group of more than kGroupCap hits is cut into pieces with the same four map rows: one wave walks a batch's
+          //  hits one after the other -- in a coherent scene a brick's 64 voxels fall into one cell of a frame, and the
+          //  other walkers would watch one of them walk them all)
+          const uint32_t pgc = (uint32_t)__shfl_up((int)gk, kGroupCap);
+          const unsigned long long heads =
+              __ballot(hv && (lane == 0 || gk != pg || (lane >= kGroupCap && (lane & (kGroupCap - 1)) == 0 && gk == pgc)));
           const int gbase = win == 0 ? 0 : (win == 1 ? g_w0 : (win == 2 ? g_w0 + g_w1 : g_w0 + g_w1 + g_w2));
           if ((heads >> lane) & 1ull) {
             const int gi = gbase + __popcll(heads & lt_mask);
