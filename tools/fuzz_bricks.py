@@ -1,0 +1,78 @@
+"""Development check (GPU): random shapes through the brick form against the frame-after-frame path.
+Everything but clip_feat must be EQUAL (weights, tsdf, rgb, label counts, counters); clip_feat within 5e-6 of the row's
+largest magnitude (bf16 volumes: 8 bf16 roundings, against the fp32 volume of the frame-after-frame path).  usage: python tools/fuzz_bricks.py [n_cases] [seed]"""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from spatially_aware_ai_amd import _abi  # noqa: E402
+from spatially_aware_ai_amd import synthetic as syn  # noqa: E402
+import test_brick_form as tb  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    bad = 0
+    for case in range(n_cases):
+        nvox = (rnd.randint(5, 70), rnd.randint(5, 70), rnd.randint(5, 140))
+        dim = 64 * rnd.choice([1, 2, 3, 4, 5, 8, 10, 16])
+        seem = rnd.random() < 0.5
+        accum = rnd.choice([_abi.SAF_RUNNING_MEAN, _abi.SAF_RUNNING_MEAN, _abi.SAF_SUM])
+        n_frames = rnd.choice([1, 3, 20, 64, 65, 128, 129, 200, 300])
+        fdt = torch.bfloat16 if rnd.random() < 0.25 else torch.float32
+        kind = rnd.choice("AB")
+        rest = None
+        if n_frames > 30 and rnd.random() < 0.6:
+            a = rnd.randint(0, n_frames // 2)
+            rest = (a, a + rnd.randint(10, n_frames))
+        env = {}
+        if rnd.random() < 0.3:
+            env["SAF_BRICK_POOL_CAP"] = str(rnd.choice([0, 5, 50]))
+        if rnd.random() < 0.15:
+            env["SAF_BRICK_SPLIT"] = "0"
+        if rnd.random() < 0.2:
+            env["SAF_WIN_FRAMES"] = rnd.choice(["32", "64", "96"])
+        per_call = rnd.choice([None, None, 37, 150])
+        grid = syn.make_grid(nvox, side=2.56 * nvox[0] / max(nvox))
+        frames = tb._frames(rnd.randint(0, 1 << 30), n_frames, dim, kind, rest=rest)
+        for k in ("SAF_BRICK_POOL_CAP", "SAF_BRICK_SPLIT", "SAF_WIN_FRAMES", "SAF_WIN_FORM"):
+            os.environ.pop(k, None)
+        one = tb._fuse(tb._build(grid, dim, seem, accum, fdt, defer=False), frames, seem, per_call=7)
+        ref32 = tb._fuse(tb._build(grid, dim, seem, accum, torch.float32, defer=False), frames, seem, per_call=7) if fdt == torch.bfloat16 else None
+        os.environ["SAF_WIN_FORM"] = "bricks"
+        os.environ.update(env)
+        win = tb._fuse(tb._build(grid, dim, seem, accum, fdt), frames, seem, per_call=per_call)
+        s1, s2 = one.stats(), win.stats()
+        for s in (s1, s2):
+            s.pop("window_rows"), s.pop("window_tsdf_voxels")
+        ok = s1 == s2
+        what = [] if ok else [f"stats {s1} != {s2}"]
+        for name in tb.EXACT + (("labels_one_hot",) if seem else ()):
+            if not torch.equal(getattr(one, name), getattr(win, name)):
+                what.append(name)
+        ref = one
+        if fdt == torch.bfloat16:  # (the frame-after-frame path rounds to bf16 after EVERY hit: with dozens of hits per row it is
+            # farther from the fp32 result than the brick form, which rounds once per round -- compare with the fp32 result)
+            ref = ref32
+        a, b = ref.clip_feat.float().cpu(), win.clip_feat.float().cpu()
+        scale = a.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        err = float(((a - b).abs() / scale).max()) if a.numel() else 0.0
+        tol = 8 * 2.0 ** -8 if fdt == torch.bfloat16 else 5e-6
+        if err > tol:
+            what.append(f"clip_feat {err:.3g}")
+        print(f"case {case}: {nvox} D={dim} seem={seem} accum={accum} frames={n_frames} {fdt} depth {kind} rest={rest} "
+              f"per_call={per_call} {env} -> {'ok' if not what else 'FAILED ' + ', '.join(what)} (clip_feat {err:.2g})", flush=True)
+        bad += bool(what)
+        del one, win
+        torch.cuda.empty_cache()
+    print("failures:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
