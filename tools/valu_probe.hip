@@ -14,7 +14,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(unsigned long long* out, float seed) {
   __shared__ int lds[8192];
   const int lane = threadIdx.x & 63;
-  lds[threadIdx.x] = 0; lds[threadIdx.x + 256] = 0;
+  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = 0;
   __syncthreads();
   float a = seed + lane, b = seed * 0.5f, c = 1.0f, d = 2.0f, e = 3.f, f = 4.f, g = 5.f, h = 6.f;
   int addr = (threadIdx.x & 255) * 4, iv = lane;
@@ -32,6 +32,9 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float seed) {
     if (MODE == 11) asm volatile(REP16("ds_write_b32 %0, %1\n ds_write_b32 %0, %1 offset:1024\n ds_write_b32 %0, %1 offset:2048\n ds_write_b32 %0, %1 offset:3072\n") : : "v"(addr), "v"(iv) : "memory");
     if (MODE == 12) asm volatile(REP16("ds_write_b64 %0, %1\n ds_write_b64 %0, %1 offset:2048\n ds_write_b64 %0, %1 offset:4096\n ds_write_b64 %0, %1 offset:6144\n") : : "v"(addr * 2), "v"(lv) : "memory");
     if (MODE == 13) asm volatile(REP16("ds_write_b128 %0, %1\n ds_write_b128 %0, %1 offset:4096\n ds_write_b128 %0, %1 offset:8192\n ds_write_b128 %0, %1 offset:12288\n") : : "v"(addr * 4), "v"(qv) : "memory");
+    if (MODE == 14) asm volatile(REP16("ds_read_b128 v[40:43], %0\n ds_read_b128 v[44:47], %0 offset:4096\n ds_read_b128 v[48:51], %0 offset:8192\n ds_read_b128 v[52:55], %0 offset:12288\n") "s_waitcnt lgkmcnt(0)\n" : : "v"(addr * 4) : "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+    if (MODE == 15) asm volatile(REP16("ds_read_b64 v[40:41], %0\n ds_read_b64 v[44:45], %0 offset:2048\n ds_read_b64 v[48:49], %0 offset:4096\n ds_read_b64 v[52:53], %0 offset:6144\n") "s_waitcnt lgkmcnt(0)\n" : : "v"(addr * 2) : "memory", "v40", "v41", "v44", "v45", "v48", "v49", "v52", "v53");
+    if (MODE == 16) asm volatile(REP16("ds_read_b32 v40, %0\n ds_read_b32 v44, %0 offset:1024\n ds_read_b32 v48, %0 offset:2048\n ds_read_b32 v52, %0 offset:3072\n") "s_waitcnt lgkmcnt(0)\n" : : "v"(addr) : "memory", "v40", "v44", "v48", "v52");
     if (MODE == 9) asm volatile(REP16("ds_add_u32 %0, %1\n ds_add_u32 %0, %1 offset:1024\n ds_add_u32 %0, %1 offset:2048\n ds_add_u32 %0, %1 offset:3072\n") : : "v"(addr), "v"(iv) : "memory");
   }
   asm volatile("s_waitcnt lgkmcnt(0)");
@@ -127,6 +130,10 @@ int main() {
   hipLaunchKernelGGL(k<11>, dim3(1), dim3(256), 0, 0, out, 1.5f); report("ds_write_b32", 64);
   hipLaunchKernelGGL(k<12>, dim3(1), dim3(256), 0, 0, out, 1.5f); report("ds_write_b64", 64);
   hipLaunchKernelGGL(k<13>, dim3(1), dim3(256), 0, 0, out, 1.5f); report("ds_write_b128", 64);
+  hipLaunchKernelGGL(k<16>, dim3(1), dim3(256), 0, 0, out, 1.5f); report("ds_read_b32", 64);
+  hipLaunchKernelGGL(k<15>, dim3(1), dim3(256), 0, 0, out, 1.5f); report("ds_read_b64", 64);
+  hipLaunchKernelGGL(k<14>, dim3(1), dim3(256), 0, 0, out, 1.5f); report("ds_read_b128 (4 waves on the CU)", 64);
+  hipLaunchKernelGGL(k<14>, dim3(2), dim3(256), 0, 0, out, 1.5f); report("ds_read_b128 (two workgroups of 4 waves: same CU or not)", 64);
   hipLaunchKernelGGL(k<9>, dim3(1), dim3(64), 0, 0, out, 1.5f); CK(hipDeviceSynchronize()); CK(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost)); printf("%-64s %7.2f counter ticks per instruction\n", "ds_add_u32, ONE wave on the CU", (double)h[0] / (2000.0 * 64));
   hipLaunchKernelGGL(k<10>, dim3(1), dim3(64), 0, 0, out, 1.5f); CK(hipDeviceSynchronize()); CK(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost)); printf("%-64s %7.2f counter ticks per instruction\n", "ds_add_u64, ONE wave on the CU", (double)h[0] / (2000.0 * 64));
   hipLaunchKernelGGL(khit<0>, dim3(1), dim3(256), 0, 0, out, 1.5f); report("the walk's per-hit body, straight line (23 instructions; per HIT)", 16);
