@@ -1,6 +1,8 @@
 """Development check (GPU): random shapes through the brick form against the frame-after-frame path.
 Everything but clip_feat must be EQUAL (weights, tsdf, rgb, label counts, counters); clip_feat within 5e-6 of the row's
-largest magnitude (bf16 volumes: 8 bf16 roundings, against the fp32 volume of the frame-after-frame path).  usage: python tools/fuzz_bricks.py [n_cases] [seed]"""
+largest magnitude (bf16 volumes: 8 bf16 roundings, against the fp32 volume of the frame-after-frame path).
+With form = rows: the frame-ordered row kernel on the widths it takes -- clip_feat must be EQUAL too.
+usage: python tools/fuzz_bricks.py [n_cases] [seed] [bricks|rows]"""
 import os
 import random
 import sys
@@ -17,14 +19,17 @@ import test_brick_form as tb  # noqa: E402
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    form = sys.argv[3] if len(sys.argv) > 3 else "bricks"
     bad = 0
     for case in range(n_cases):
         nvox = (rnd.randint(5, 70), rnd.randint(5, 70), rnd.randint(5, 140))
-        dim = 64 * rnd.choice([1, 2, 3, 4, 5, 8, 10, 16])
+        dim = 64 * rnd.choice([1, 2, 3, 4, 5, 8, 10, 16]) if form == "bricks" else rnd.choice([256, 512, 768, 1024])
         seem = rnd.random() < 0.5
         accum = rnd.choice([_abi.SAF_RUNNING_MEAN, _abi.SAF_RUNNING_MEAN, _abi.SAF_SUM])
         n_frames = rnd.choice([1, 3, 20, 64, 65, 128, 129, 200, 300])
         fdt = torch.bfloat16 if rnd.random() < 0.25 else torch.float32
+        if form == "rows" and fdt == torch.bfloat16 and dim % 512:
+            dim = 512
         kind = rnd.choice("AB")
         rest = None
         if n_frames > 30 and rnd.random() < 0.6:
@@ -44,7 +49,7 @@ def main():
             os.environ.pop(k, None)
         one = tb._fuse(tb._build(grid, dim, seem, accum, fdt, defer=False), frames, seem, per_call=7)
         ref32 = tb._fuse(tb._build(grid, dim, seem, accum, torch.float32, defer=False), frames, seem, per_call=7) if fdt == torch.bfloat16 else None
-        os.environ["SAF_WIN_FORM"] = "bricks"
+        os.environ["SAF_WIN_FORM"] = form
         os.environ.update(env)
         win = tb._fuse(tb._build(grid, dim, seem, accum, fdt), frames, seem, per_call=per_call)
         s1, s2 = one.stats(), win.stats()
@@ -63,6 +68,9 @@ def main():
         scale = a.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
         err = float(((a - b).abs() / scale).max()) if a.numel() else 0.0
         tol = 8 * 2.0 ** -8 if fdt == torch.bfloat16 else 5e-6
+        if form == "rows":
+            err = 0.0 if torch.equal(one.clip_feat, win.clip_feat) else float(((one.clip_feat.float().cpu() - b).abs() / scale).max()) + 1e-30
+            tol = 0.0
         if err > tol:
             what.append(f"clip_feat {err:.3g}")
         print(f"case {case}: {nvox} D={dim} seem={seem} accum={accum} frames={n_frames} {fdt} depth {kind} rest={rest} "
