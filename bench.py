@@ -334,13 +334,13 @@ def main():
         w_sum = int(fusion.weight.sum(dtype=torch.int64))
         assert w_sum * a.steps == st["valid"], f"weight sum {w_sum} x {a.steps} steps != valid count {st['valid']}"
     else:
-        first, count = fusion._shard_range if fusion._shard_range is not None else (0, n_vox)
-        sums = torch.stack([fusion.weight[first:first + count].sum(dtype=torch.int64),
-                            fusion.tsdf_weight[first:first + count].sum(dtype=torch.int64),
+        own = fusion._shard_stripes if fusion._shard_stripes is not None else [(0, n_vox)]
+        sums = torch.stack([sum(fusion.weight[f:f + c].sum(dtype=torch.int64) for f, c in own),
+                            sum(fusion.tsdf_weight[f:f + c].sum(dtype=torch.int64) for f, c in own),
                             torch.tensor(st["valid"], device=device), torch.tensor(st["tsdf_valid"], device=device)])
         dist.all_reduce(sums)
         w_sum, tw_sum, valid_all, tsdf_all = (int(v) for v in sums.tolist())
-        if fusion._shard_range is None:  # all_reduce: every rank holds the whole volume
+        if fusion._shard_stripes is None:  # all_reduce: every rank holds the whole volume
             w_sum //= world
             tw_sum //= world
         assert w_sum * a.steps == valid_all, f"merged weight sum {w_sum} x {a.steps} steps != valid count of all ranks {valid_all}"
@@ -394,7 +394,6 @@ def main():
         if merge_state["mode"] == "all_reduce":
             w_all //= world
         assert w_all * a.steps == v_all, f"slab-pipelined merge: owned weights {w_all} x {a.steps} steps != valid hits {v_all}"
-        fusion.accum_mode = _abi.SAF_RUNNING_MEAN
         slab_pipe = {"value": round(total_frames / dt4, 2), "unit": "frames/s", "ms_per_step": round(dt4 / a.steps * 1e3, 3),
                      "slabs": n_slabs, "merge_check": {"owned_weight_sum_all_ranks": w_all, "valid_hits_all_ranks_per_step": v_all // a.steps},
                      "note": "the same single job as `value` (config 4's layout: frames sharded, one per-rank volume, one merge) with "
@@ -417,8 +416,12 @@ def main():
 
     # ---- N > 1: the merged shard of a small sharded job against a single-rank fusion of ALL its frames ----
     if world > 1 and a.check_frames > 0:
+        pipe_fn = None
+        if slab_pipe is not None:
+            pipe_fn = lambda fz, fr, c: sdist.fuse_merge_pipelined(fz, fr, c, ws, n_slabs=slab_pipe["slabs"], comm_stream=comm_stream,
+                                                                  mode=merge_state["mode"], stats_ptr=stats_ptr)
         merge_check.update(check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, (depth, rgb, poses, ks, feat, label_maps),
-                                       min(a.check_frames, uniq), world, rank, device))
+                                       min(a.check_frames, uniq), world, rank, device, pipelined=pipe_fn))
         merge_check["mode"] = merge_state["mode"]
 
     # ---- roofline of the dominant kernel (fuse_kernel), this rank ----
@@ -1271,15 +1274,17 @@ def bench_voxel_sharded(a, dist, sdist, grid, fusions, tensors, new_volume, worl
                     "the volume stays voxel-sharded; NOT BASELINE config 4's layout (that is `value`)"}
 
 
-def check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, tensors, c, world, rank, device):
+def check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, tensors, c, world, rank, device, pipelined=None):
     """Untimed proof of the merge on the full-size volumes.  Every rank fuses its first c frames in SAF_SUM mode and
     the ranks merge (the very collective that was timed); every rank then all-gathers the c frames of all ranks and
     fuses ALL world*c frames, rank after rank, into its second volume as running means -- what a single GPU would
-    have produced.  The two must agree on the voxel range this rank owns: integer weights exactly, means to 1e-4."""
+    have produced.  The two must agree on the voxel stripes this rank owns: integer weights exactly, means to 1e-4.
+    ``pipelined(fz, frames, c) -> stripes``: the slab-pipelined form of the same job is proved the same way (its stripes,
+    its finalize on the communication stream) -- a region may only become the headline after its VALUES were compared."""
     v0, v1 = fusions[0], fusions[1]
     v0.reset(accum_mode=_abi.SAF_SUM)
     fuse_into(v0, frames, c, None)
-    first, count = merge(v0)
+    stripes = merge(v0)
     # every rank's check frames, gathered (c x ~5 MB per rank)
     gathered = []
     for t in tensors:
@@ -1294,27 +1299,40 @@ def check_merge(a, dist, sdist, fusions, fuse_into, merge, frames, tensors, c, w
     arr, keep, _, _ = v1._make_frames(depth, rgb, poses, ks, feat, labs, a.labels)
     v1.reset(accum_mode=_abi.SAF_RUNNING_MEAN)
     fuse_into(v1, arr, world * c, None)
+    v1.flush()
     torch.cuda.synchronize()
-    sl = slice(first, first + count)
-    ok_w = bool(torch.equal(v0.weight[sl], v1.weight[sl])) and bool(torch.equal(v0.tsdf_weight[sl], v1.tsdf_weight[sl]))
-    if a.labels:
-        ok_w = ok_w and bool(torch.equal(v0.labels_one_hot[sl], v1.labels_one_hot[sl]))
-    worst = 0.0
-    for name in ("clip_feat", "rgb", "tsdf"):
-        x, y = getattr(v0, name)[sl], getattr(v1, name)[sl]
-        step = max(1, (1 << 22) // max(1, x[0].numel()))  # compare in pieces: no full-size temporaries
-        for s0 in range(0, x.shape[0], step):
-            xs, ys = x[s0:s0 + step].float(), y[s0:s0 + step].float()
-            worst = max(worst, float(((xs - ys).abs() / (ys.abs() * 1e-4 + 1e-6)).max()))
-    touched = int((v1.weight[sl] > 0).sum())
-    res = torch.tensor([int(ok_w), int(worst <= 1.0), touched], device=device, dtype=torch.int64)
-    dist.all_reduce(res, op=dist.ReduceOp.MIN)
-    all_ok_w, all_ok_f, min_touched = (int(v) for v in res.tolist())
-    assert all_ok_w, "merge check: merged integer weights differ from the single-rank fusion of the same frames"
-    assert all_ok_f, f"merge check: merged means differ from the single-rank fusion beyond 1e-4 (worst ratio {worst:.3g})"
-    assert min_touched > 0, "merge check: a rank's voxel shard was not touched by the check frames"
-    return {"check_frames_per_rank": c, "owned_voxel_range": [int(first), int(count)], "weights_exact": True,
-            "means_within_1e-4": True, "worst_error_over_tolerance": round(worst, 4), "touched_voxels_min_over_ranks": min_touched}
+
+    def compare(stripes, what):
+        ok_w, worst, touched = True, 0.0, 0
+        b0, b1 = v0._buffers, v1._buffers  # (raw buffers: v0 holds stripes only and must not be "looked at" as a whole)
+        for first, count in stripes:
+            sl = slice(first, first + count)
+            ok_w = ok_w and bool(torch.equal(b0["weight"][sl], b1["weight"][sl])) and bool(torch.equal(b0["tsdf_weight"][sl], b1["tsdf_weight"][sl]))
+            if a.labels:
+                ok_w = ok_w and bool(torch.equal(b0["labels_one_hot"][sl], b1["labels_one_hot"][sl]))
+            for name in ("clip_feat", "rgb", "tsdf"):
+                x, y = b0[name][sl], b1[name][sl]
+                step = max(1, (1 << 22) // max(1, x[0].numel()))  # compare in pieces: no full-size temporaries
+                for s0 in range(0, x.shape[0], step):
+                    xs, ys = x[s0:s0 + step].float(), y[s0:s0 + step].float()
+                    worst = max(worst, float(((xs - ys).abs() / (ys.abs() * 1e-4 + 1e-6)).max()))
+            touched += int((b1["weight"][sl] > 0).sum())
+        res = torch.tensor([int(ok_w), int(worst <= 1.0), touched], device=device, dtype=torch.int64)
+        dist.all_reduce(res, op=dist.ReduceOp.MIN)
+        all_ok_w, all_ok_f, min_touched = (int(v) for v in res.tolist())
+        assert all_ok_w, f"merge check ({what}): merged integer weights differ from the single-rank fusion of the same frames"
+        assert all_ok_f, f"merge check ({what}): merged means differ from the single-rank fusion beyond 1e-4 (worst ratio {worst:.3g})"
+        assert min_touched > 0, f"merge check ({what}): a rank's voxel stripes were not touched by the check frames"
+        cover = torch.tensor([sum(c_ for _, c_ in stripes)], device=device, dtype=torch.int64)
+        dist.all_reduce(cover)
+        return {"stripes_of_this_rank": len(stripes), "owned_voxels_all_ranks": int(cover), "weights_exact": True,
+                "means_within_1e-4": True, "worst_error_over_tolerance": round(worst, 4), "touched_voxels_min_over_ranks": min_touched}
+
+    out = {"check_frames_per_rank": c, "serial_merge_values": compare(stripes, "serial merge")}
+    if pipelined is not None:
+        v0.reset(accum_mode=_abi.SAF_SUM)
+        out["slab_pipelined_values"] = compare(pipelined(v0, frames, c), "slab-pipelined merge")
+    return out
 
 
 def host_cores():

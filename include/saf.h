@@ -109,6 +109,10 @@ int saf_abi_version(void);
 /* Bytes of device scratch saf_fuse_frame(s) needs for a volume of n_voxels and a feature map of
  * feat_dim x npy x npx (compact list of valid voxels + re-laid-out feature map + counters). */
 size_t saf_fuse_workspace_bytes(int64_t n_voxels, int32_t feat_dim, int32_t npy, int32_t npx);
+/* The same for ONE volume (its grid, width and feature dtype are known): the brick form's segment pools -- 6.5 GB at
+ * 256^3 -- are reserved only when that form would run for it (feat_dim a multiple of 64 that the row kernel does not
+ * take, or SAF_WIN_FORM=bricks); the default 512-channel f32 / bf16 volumes end at 0.55 GB.  0 for a bad descriptor. */
+size_t saf_fuse_workspace_bytes_for(const saf_volume* vol, int32_t npy, int32_t npx);
 
 /*
  * Fuse ONE frame into the volume: replaces the body of ClipFusion.integrate after the CLIP call

@@ -98,7 +98,7 @@ class _FusionVolumeMixin:
             ).reshape(-1, 3)
             self.register_buffer("xyz_world", xyz_world)
         self._workspace = None
-        self._shard_range = None  # (first, count) while the volume holds only a reduce-scattered shard
+        self._shard_stripes = None  # [(first, count)] while the volume holds only its reduce-scattered stripes of a merged job
         self.__dict__.setdefault("defer_frames", True)  # queue small integrate() calls into 128-frame windows
         self.__dict__["_pending_n"] = 0
         self.__dict__["_stage"] = None
@@ -129,7 +129,8 @@ class _FusionVolumeMixin:
     def _get_workspace(self, npy, npx):
         tsdf = self._buffers["tsdf"]
         n = tsdf.numel()
-        need = lib().saf_fuse_workspace_bytes(n, int(self.n_clip_feats), int(npy), int(npx))
+        # for THIS volume (width, dtype, SAF_WIN_FORM): the brick form's 6.5 GB of segment pools only where it would run
+        need = lib().saf_fuse_workspace_bytes_for(C.byref(self._c_volume(for_fuse=True)), int(npy), int(npx))
         ws = self._workspace
         if ws is None or ws.numel() < need or ws.device != tsdf.device:
             ws = torch.empty(need, dtype=torch.uint8, device=tsdf.device)
@@ -284,6 +285,13 @@ class _FusionVolumeMixin:
                       0 if lazy is not None else clip_feat_img.data_ptr())
             for i in range(bsz):
                 k = self.__dict__["_pending_n"]
+                if k >= self._QUEUE_FRAMES:
+                    # a full ring means an earlier flush failed and kept its frames: try again (it re-raises) -- never
+                    # stage into a slot beyond the ring
+                    self._flush_pending()
+                    k = self.__dict__["_pending_n"]
+                    if k >= self._QUEUE_FRAMES:
+                        raise SafError("the staging ring is full and could not be flushed")
                 if fast:  # one launch per frame (saf_stage_frame); addresses by arithmetic: no tensor views, no new descriptors
                     src.depth, src.rgb, src.pose = sp[0] + i * step[0], sp[1] + i * step[1], sp[2] + i * 64
                     src.K, src.feat_map = sp[3] + i * 36, (None if lazy is not None else sp[4] + i * fs[0] * 4)
@@ -330,7 +338,9 @@ class _FusionVolumeMixin:
         n = self.__dict__.get("_pending_n", 0)
         if not n:
             return
+        self._check_poisoned()
         self.__dict__["_pending_n"] = 0  # first: the buffer accesses below must not re-enter
+        self.__dict__["_fuse_launched"] = False
         st = self.__dict__["_stage"]
         try:
             labs = None if st["labels"] is None else st["labels"][:n]
@@ -342,15 +352,26 @@ class _FusionVolumeMixin:
                 if tuple(feat.shape) != (n,) + tuple(st["key"][2]):
                     raise SafError(f"the backbone returned {tuple(feat.shape)} for {n} frames, expected {(n,) + tuple(st['key'][2])}")
             self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], feat, labs, st["key"][4])
-        except BaseException:
-            # the backbone or the fuse call failed (out of memory, an unsupported tiling): the frames stay queued -- the next
-            # access raises again instead of reading a volume that silently lacks them
-            self.__dict__["_pending_n"] = n
+        except BaseException as exc:
+            if not self.__dict__.get("_fuse_launched"):
+                # the backbone, the descriptors or the argument checks at the entry of saf_fuse_frames failed (out of
+                # memory, an unsupported tiling) BEFORE any kernel touched the volume: the frames stay queued -- the next
+                # access raises again instead of reading a volume that silently lacks them
+                self.__dict__["_pending_n"] = n
+            else:
+                # saf_fuse_frames failed after launching some of its windows: fusing the same frames again would count them
+                # twice, dropping them would lose them silently.  Neither: the volume is unusable until reset().
+                self.__dict__["_poisoned"] = f"a flush of {n} queued frames failed part-way ({exc!r}); the volume is incomplete: reset() it"
             raise
         dev = self._buffers["tsdf"].device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)
             st["event"], st["stream"] = stream.record_event(), stream.cuda_stream
+
+    def _check_poisoned(self):
+        msg = self.__dict__.get("_poisoned")
+        if msg:
+            raise SafError(msg)
 
     @property
     def pending_frames(self):
@@ -360,6 +381,8 @@ class _FusionVolumeMixin:
     def __getattr__(self, name):
         # registered buffers live in _buffers, so every read of one comes through here
         if name in _VOLUME_BUFFERS:
+            if self.__dict__.get("_poisoned"):
+                self._check_poisoned()
             if name == "clip_feat" and self.__dict__.get("_feat_stale"):
                 self._sync_volume()  # queued frames AND the deferred clear: the rows are about to be looked at
             elif self.__dict__.get("_pending_n", 0):
@@ -395,10 +418,11 @@ class _FusionVolumeMixin:
         return super().named_buffers(*args, **kwargs)
 
     def _fuse_now(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False):
-        if getattr(self, "_shard_range", None) is not None:
+        if getattr(self, "_shard_stripes", None) is not None:
             raise SafError(
-                "this volume holds only its reduce-scattered voxel shard "
-                f"{self._shard_range} of a merged job; all_gather it (merge_volumes(..., gather=True)) before fusing more frames"
+                "this volume holds only its reduce-scattered voxel stripes "
+                f"({len(self._shard_stripes)} of them) of a merged job; all_gather it (distributed.gather_shards, or "
+                "merge_volumes(..., gather=True)) before fusing more frames"
             )
         arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
         vol = self._c_volume(for_fuse=True)
@@ -413,6 +437,9 @@ class _FusionVolumeMixin:
             rc = lib().saf_fuse_frames(
                 C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), stream.cuda_stream
             )
+            # SAF_E_INVALID / _WORKSPACE / _UNSUPPORTED come from the checks at the entry (every frame descriptor is validated
+            # before the first launch); a HIP error may have left some windows fused (see _flush_pending)
+            self.__dict__["_fuse_launched"] = rc == 0 or rc == _abi.SAF_E_HIP
             check(rc, "saf_fuse_frames")
             # the launches are asynchronous: keep inputs alive until the stream has consumed them
             for t in keep[:5]:
@@ -427,6 +454,7 @@ class _FusionVolumeMixin:
         with weight 0 has a zero row by contract and the windowed fuse path never reads such rows; the rows still
         unwritten are zeroed when something first looks (any buffer access, state_dict, the merge, flush())."""
         self.__dict__["_pending_n"] = 0  # frames still queued would be fused into a volume that is being discarded
+        self.__dict__["_poisoned"] = None
         self.__dict__["_feat_stale"] = False
         b = self._buffers
         lazy = bool(lazy) and b["clip_feat"].is_cuda
@@ -435,7 +463,7 @@ class _FusionVolumeMixin:
             if t is not None:
                 t.zero_()
         super().__setattr__("accum_mode", accum_mode)
-        self._shard_range = None
+        self._shard_stripes = None
         self.__dict__["_feat_stale"] = lazy
 
 

@@ -22,7 +22,7 @@
 // windowed path live in saf_fuse_dev.h.
 #include <mutex>
 
-#include "saf_fuse_dev.h"
+#include "saf_window_dev.h"
 
 namespace saf {
 
@@ -1008,7 +1008,18 @@ int saf_abi_version(void) { return SAF_ABI_VERSION; }
 
 size_t saf_fuse_workspace_bytes(int64_t n_vox, int32_t feat_dim, int32_t npy, int32_t npx) {
   if (n_vox <= 0 || feat_dim <= 0 || npy <= 0 || npx <= 0) return 0;
-  const size_t a = ws_layout(n_vox, feat_dim, npy * npx).total, b = window_workspace_bytes(n_vox, feat_dim, npy * npx);
+  // without the volume's dtype: room for the brick form wherever SOME dtype of this width would take it
+  const char* e = getenv("SAF_WIN_FORM");
+  const bool rows_always = feat_dim % 512 == 0 && feat_dim <= 1024;  // f32 and bf16 volumes both take the row kernel
+  const bool bricks = feat_dim % 64 == 0 && feat_dim <= 8192 && !(e && (e[0] == 'r' || e[0] == 's')) && (!rows_always || (e && e[0] == 'b'));
+  const size_t a = ws_layout(n_vox, feat_dim, npy * npx).total, b = window_workspace_bytes(n_vox, feat_dim, npy * npx, bricks);
+  return a > b ? a : b;
+}
+
+size_t saf_fuse_workspace_bytes_for(const saf_volume* vol, int32_t npy, int32_t npx) {
+  KVol kv;
+  if (!vol || npy <= 0 || npx <= 0 || make_kvol(vol, &kv)) return 0;
+  const size_t a = ws_layout(kv.N, kv.D, npy * npx).total, b = window_workspace_bytes(kv.N, kv.D, npy * npx, brick_form_ok(kv));
   return a > b ? a : b;
 }
 

@@ -111,14 +111,30 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_WIN_WPE
 #define SAF_WIN_WPE 2
 #endif
+#ifndef SAF_WIN_OF_SR2
+#define SAF_WIN_OF_SR2 5  // order-free form, D = 512: rows of a sub-chunk = accumulator sets in registers (8 VGPRs each)
+#endif
+#ifndef SAF_WIN_OF_P2
+#define SAF_WIN_OF_P2 2
+#endif
+#ifndef SAF_WIN_ABL
+#define SAF_WIN_ABL 0  // development: ablations of the order-free kernel (WRONG results): 1 taps "outside" (instructions issue, no
+#endif                 // request), 2 no tap instructions, 4 no row loads, 8 no row stores, 16 no multiply-adds
+#ifndef SAF_WIN_OF_WPE
+#define SAF_WIN_OF_WPE 2  // waves per SIMD the order-free kernel's register budget is set for
+#endif
 constexpr int kUnitVox = kPiece >> SAF_WIN_SPLIT_LOG2;  // voxels of a unit of work (a quarter piece)
-template <int CPL>
+// OF = the order-free form of the row kernel: a row's samples of the window are summed in
+// REGISTERS and the row is blended once, (w0 old + sum) / (w0 + k); no row lives in LDS.
+template <int CPL, bool OF = false>
 struct WinCfg {
-  static constexpr int SR = CPL == 1 ? 8 : (CPL == 2 ? SAF_WIN_SR2 : 3);  // rows of a sub-chunk (LDS resident)
-  static constexpr int P = CPL == 1 ? 6 : (CPL == 2 ? SAF_WIN_P2 : 2);  // tap groups in flight
+  static constexpr int SR = OF ? (CPL == 1 ? 8 : (CPL == 2 ? SAF_WIN_OF_SR2 : (CPL == 3 ? 3 : 2)))
+                               : (CPL == 1 ? 8 : (CPL == 2 ? SAF_WIN_SR2 : 3));  // rows of a sub-chunk (LDS resident / register sums)
+  static constexpr int P = OF ? (CPL == 1 ? 4 : (CPL == 2 ? SAF_WIN_OF_P2 : 1))
+                              : (CPL == 1 ? 6 : (CPL == 2 ? SAF_WIN_P2 : 2));  // tap groups in flight
   // dynamic LDS layout (bytes)
   static constexpr size_t rows_off = 0;
-  static constexpr size_t rows_bytes = (size_t)kWinWaves * SR * CPL * 64 * sizeof(float4);
+  static constexpr size_t rows_bytes = OF ? 0 : (size_t)kWinWaves * SR * CPL * 64 * sizeof(float4);
   static constexpr size_t stage_off = rows_off + rows_bytes;  // 6 arrays of kHitCap words per wave
   static constexpr size_t stage_bytes = (size_t)kWinWaves * 6 * kHitCap * 4;
   static constexpr size_t tm_off = stage_off + stage_bytes;
@@ -567,17 +583,102 @@ __device__ __forceinline__ void win_batch(const WinCtx<CPL>& cx, const int (&hl)
   }
 }
 
-template <int CPL, bool SUM, bool BF16>
-__global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(SAF_WIN_WPE, SAF_WIN_WPE))) void
+// ---- order-free form (OF): a row's samples of the window are summed in registers ----
+// A row hit k times in a window goes from `old` (weight w0) to (w0 old + the sum of its k samples) / (w0 + k): the running
+// mean of clipfusion.py:715-721 with the window's k updates folded into one (order-free up to fp32 rounding, SURVEY
+// section 7).  The accumulator of row r of the sub-chunk is acc[r]: loaded with the old row (global -> registers, no LDS),
+// scaled by w0 when it has landed, every hit adds nw t0 + ne t1 + sw t2 + se t3 with packed FMAs whose weights come from
+// SGPRs (v_readlane), one multiply by 1 / (w0 + k) on the way out.  Per hit: no LDS access, no blend.
+typedef float win_v2f __attribute__((ext_vector_type(2)));
+// (the accumulators are PAIRS of channels from end to end -- what v_pk_fma_f32 reads and writes: carried as float4 through
+//  the loops below, every loop entry and exit repacked them with v_mov copies into a second register set)
+template <int CPL>
+__device__ __forceinline__ void of_add_row(win_v2f (&a)[2 * CPL], const float4 (&tp)[4][CPL], float nw, float ne, float sw,
+                                           float se) {
+  const win_v2f w[4] = {{nw, nw}, {ne, ne}, {sw, sw}, {se, se}};
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a[2 * c] = __builtin_elementwise_fma((win_v2f){tp[t][c].x, tp[t][c].y}, w[t], a[2 * c]);
+      a[2 * c + 1] = __builtin_elementwise_fma((win_v2f){tp[t][c].z, tp[t][c].w}, w[t], a[2 * c + 1]);
+    }
+  }
+}
+// One batch of NB groups.  The hit's row must be a compile-time register set: a chain of compares on the (wave-uniform) row
+// number merges the sets behind phi copies (or, sunk into one body, behind a dynamically indexed array in scratch memory).
+// So the loops are turned inside out: for every group u and every row R of the sub-chunk (both unrolled), the lanes
+// rm[R] & [hl[u], hl[u + 1]) are that row's hits of that group -- usually none or one -- and each body adds into acc[R]
+// from tp[u] in place.  Within a row the hits stay in (frame, lane) order: the sum is reproducible.
+template <int NB, int CPL, bool SUM, bool BF16, int SR>
+__device__ __forceinline__ void win_batch_of(const WinCtx<CPL>& cx, const int (&hl)[NB + 1], int nb, const WinGroupOffs& go,
+                                             const WinHit& rec, const unsigned long long (&rm)[SR],
+                                             win_v2f (&acc)[SR][2 * CPL]) {
+  float4 tp[NB][4][CPL];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const bool real = u < nb && !(SAF_WIN_ABL & 1);  // (hl[u] = 64 for an empty group when the pass is full: no such lane to read)
+    const int hu = real ? hl[u] : 0;
+    // (distinct offsets for an empty group's taps: identical loads would be merged into one)
+    const int o_nw = real ? __builtin_amdgcn_readlane(go.nw, hu) : (int)(kTapOutside + 0x10000u * (4 * u));
+    const int o_ne = real ? __builtin_amdgcn_readlane(go.ne, hu) : (int)(kTapOutside + 0x10000u * (4 * u + 1));
+    const int o_sw = real ? __builtin_amdgcn_readlane(go.sw, hu) : (int)(kTapOutside + 0x10000u * (4 * u + 2));
+    const int o_se = real ? __builtin_amdgcn_readlane(go.se, hu) : (int)(kTapOutside + 0x10000u * (4 * u + 3));
+    const uint32_t lane_off = (uint32_t)(BF16 ? 2 * cx.lane : cx.lane) * 16u;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const uint32_t off = lane_off + (uint32_t)win_chunk_off<BF16>(c) * 16u;
+      if (SAF_WIN_ABL & 2) {
+        const float f = __builtin_bit_cast(float, (uint32_t)o_nw + off);
+        tp[u][0][c] = tp[u][1][c] = tp[u][2][c] = tp[u][3][c] = make_float4(f, f, f, f);
+        continue;
+      }
+      tp[u][0][c] = win_tap_load(cx.maps, (uint32_t)o_nw + off);
+      tp[u][1][c] = win_tap_load(cx.maps, (uint32_t)o_ne + off);
+      tp[u][2][c] = win_tap_load(cx.maps, (uint32_t)o_sw + off);
+      tp[u][3][c] = win_tap_load(cx.maps, (uint32_t)o_se + off);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    // lanes hl[u] .. hl[u + 1] - 1 (hl[u + 1] <= 64)
+    const unsigned long long below_hi = hl[u + 1] >= 64 ? ~0ull : ((1ull << hl[u + 1]) - 1ull);
+    const unsigned long long range = below_hi & ~((1ull << hl[u]) - 1ull);
+#pragma unroll
+    for (int R = 0; R < SR; ++R) {
+      unsigned long long m = rm[R] & range;
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const float nw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.nw), l));
+        const float ne = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.ne), l));
+        const float sw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.sw), l));
+        const float se = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.se), l));
+        if (SAF_WIN_ABL & 16) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(tp[u][t][c].x), "v"(tp[u][t][c].y), "v"(tp[u][t][c].z), "v"(tp[u][t][c].w), "s"(nw), "s"(ne), "s"(sw), "s"(se));
+        } else {
+          of_add_row<CPL>(acc[R], tp[u], nw, ne, sw, se);
+        }
+      }
+    }
+  }
+}
+
+template <int CPL, bool SUM, bool BF16, bool OF>
+__global__ __launch_bounds__(kWinThreads)
+__attribute__((amdgpu_waves_per_eu(OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE, OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE))) void
 fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, int img_vecs,
                    unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
                    const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc,
                    int xcd_order) {
-  using Cfg = WinCfg<CPL>;
+  using Cfg = WinCfg<CPL, OF>;
   constexpr int SR = Cfg::SR;
   // (s_setprio 1 / 3 here, ahead of the classification waves that share the SIMDs, changes nothing: 105.4 / 105.7 / 105.8 ms)
   // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
-  constexpr int P = BF16 && Cfg::P > 2 ? Cfg::P - 1 : (BF16 && CPL == 4 ? 1 : Cfg::P);  // (bf16, D = 1024: two groups of 64 tap registers in flight spilled)
+  constexpr int P = OF ? Cfg::P : (BF16 && Cfg::P > 2 ? Cfg::P - 1 : (BF16 && CPL == 4 ? 1 : Cfg::P));  // (bf16, D = 1024: two groups of 64 tap registers in flight spilled)
   extern __shared__ __align__(16) unsigned char s_dyn[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4* rows = reinterpret_cast<float4*>(s_dyn + Cfg::rows_off) + (size_t)wave * SR * CPL * 64;
@@ -815,6 +916,8 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         WinRaw<SR, UPL> raw;
         raw.nrows = nrows;
         const WinCtx<CPL> cx{maps_rsrc, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
+        // order-free form: acc[r] = the old row (never scaled: the hits' weights are, by 1 / w0), then the window's samples
+        win_v2f acc[OF ? SR : 1][2 * CPL];
         // Several rows with more than 64 hits between them (coherent scenes: ~15 hits per row): the staging entries of the
         // sub-chunk are brought into (frame, row) order first -- ranks from the rows' frame masks as below, for both blocks
         // of 64 hits, every staging field permuted through the free s_hw array -- and the passes then find them sorted.
@@ -875,6 +978,15 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
             const Bilin w = bilinear_setup(hit ? s_hgx[sj] : 0.0f, hit ? s_hgy[sj] : 0.0f, half_px, half_py);
             rec.nw = w.nw; rec.ne = w.ne; rec.sw = w.sw; rec.se = w.se;
           }
+          if constexpr (OF && !SUM && !BF16) {
+            // f32 running mean: the accumulator starts as the OLD row, unscaled (it is loaded straight into the registers and
+            // first touched by whichever hit comes first), so every sample of a row is weighted by 1 / w0 instead -- lane-
+            // parallel, on the hit's four tap weights -- and the row leaves as acc x w0 / (w0 + k).  A fresh row (w0 = 0)
+            // starts at zero: weight 1, leaves as acc / k.
+            const int w0h = __shfl(w0, (int)(hfl & 63u));
+            const float rs = w0h == 0 ? 1.0f : 1.0f / (float)w0h;
+            rec.nw *= rs; rec.ne *= rs; rec.sw *= rs; rec.se *= rs;
+          }
           int rank = 0;
           if (h0 == 0) {
             // (the staging reads above come BEFORE the LDS-DMA below: the compiler drains vmcnt ahead of any LDS
@@ -893,9 +1005,9 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
               low[w] = (uint32_t)w < fwd ? 0xffffffffu : ((uint32_t)w == fwd ? (1u << fbit) - 1u : 0u);
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
-              if (r < nrows && __builtin_amdgcn_readlane(w0, i0 + r) == 0) {
+              if (r < nrows && (__builtin_amdgcn_readlane(w0, i0 + r) == 0 || (OF && (SAF_WIN_ABL & 4)))) {
                 fresh |= 1u << r;
-                if (!BF16) {
+                if (!BF16 && !OF) {
 #pragma unroll
                   for (int c = 0; c < CPL; ++c) rows[(r * CPL + c) * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -930,12 +1042,30 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
                     raw.u[r * UPL + k] = make_uint4(__builtin_bit_cast(uint32_t, t.x), __builtin_bit_cast(uint32_t, t.y),
                                                     __builtin_bit_cast(uint32_t, t.z), __builtin_bit_cast(uint32_t, t.w));
                   }
+                } else if constexpr (OF) {  // the old row, global -> the accumulator registers (never through LDS)
+#pragma unroll
+                  for (int c = 0; c < CPL; ++c) {
+                    const float4 t = ld_stream(feat + row + chs[c]);
+                    acc[r][2 * c] = (win_v2f){t.x, t.y};
+                    acc[r][2 * c + 1] = (win_v2f){t.z, t.w};
+                  }
                 } else {
 #pragma unroll
                   for (int c = 0; c < CPL; ++c)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + row + chs[c]),
                                                      (__attribute__((address_space(3))) void*)(rows + (r * CPL + c) * 64),
                                                      16, 0, 2);
+                }
+              }
+              if constexpr (OF) {
+                // bf16: the accumulator holds the samples only, the old row waits in `raw`; f32: a fresh or absent row starts at 0
+                if (BF16 || r >= nrows || (fresh & (1u << r))) {
+#pragma unroll
+                  for (int c = 0; c < 2 * CPL; ++c) acc[r][c] = (win_v2f){0.f, 0.f};
+                }
+                if (BF16 && r >= nrows) {
+#pragma unroll
+                  for (int k = 0; k < UPL; ++k) raw.u[r * UPL + k] = make_uint4(0u, 0u, 0u, 0u);
                 }
               }
             }
@@ -964,6 +1094,11 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
           const int n_pass = nh - h0 < 64 ? nh - h0 : 64;
           WT(5);
           const WinGroupOffs go = win_group_offsets(cx, skey);
+          unsigned long long rm[OF ? SR : 1];  // order-free form: the lanes (hits in group order) of every row of the sub-chunk
+          if constexpr (OF) {
+#pragma unroll
+            for (int r = 0; r < SR; ++r) rm[r] = __ballot(lane < n_pass && srt.row == r);
+          }
           bool first = h0 == 0;
           while (heads) {
             int hl[P + 1];
@@ -979,13 +1114,19 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
               }
             }
             hl[P] = heads ? __ffsll((long long)heads) - 1 : n_pass;
+            if constexpr (OF) {
+              // ONE instantiation: a batch with fewer than P groups has empty groups at its end (hl[u] = hl[u + 1] = n_pass), whose
+              // taps are "outside the map" -- no memory request -- and whose hit loops find no lane
+              win_batch_of<P, CPL, SUM, BF16, SR>(cx, hl, nb, go, srt, rm, acc);
+            } else {
             switch (nb) {
-              case 1: { const int h1[2] = {hl[0], hl[1]}; win_batch<1, CPL, SUM, BF16, SR>(cx, h1, first, go, srt, raw); break; }
-              case 2: if constexpr (P >= 2) { const int h2[3] = {hl[0], hl[1], hl[2]}; win_batch<2, CPL, SUM, BF16, SR>(cx, h2, first, go, srt, raw); } break;
-              case 3: if constexpr (P >= 3) { const int h3[4] = {hl[0], hl[1], hl[2], hl[3]}; win_batch<3, CPL, SUM, BF16, SR>(cx, h3, first, go, srt, raw); } break;
-              case 4: if constexpr (P >= 4) { const int h4[5] = {hl[0], hl[1], hl[2], hl[3], hl[4]}; win_batch<4, CPL, SUM, BF16, SR>(cx, h4, first, go, srt, raw); } break;
-              case 5: if constexpr (P >= 5) { const int h5[6] = {hl[0], hl[1], hl[2], hl[3], hl[4], hl[5]}; win_batch<5, CPL, SUM, BF16, SR>(cx, h5, first, go, srt, raw); } break;
-              default: if constexpr (P >= 6) { const int h6[7] = {hl[0], hl[1], hl[2], hl[3], hl[4], hl[5], hl[6]}; win_batch<6, CPL, SUM, BF16, SR>(cx, h6, first, go, srt, raw); } break;
+                case 1: { const int h1[2] = {hl[0], hl[1]}; win_batch<1, CPL, SUM, BF16, SR>(cx, h1, first, go, srt, raw); break; }
+                case 2: if constexpr (P >= 2) { const int h2[3] = {hl[0], hl[1], hl[2]}; win_batch<2, CPL, SUM, BF16, SR>(cx, h2, first, go, srt, raw); } break;
+                case 3: if constexpr (P >= 3) { const int h3[4] = {hl[0], hl[1], hl[2], hl[3]}; win_batch<3, CPL, SUM, BF16, SR>(cx, h3, first, go, srt, raw); } break;
+                case 4: if constexpr (P >= 4) { const int h4[5] = {hl[0], hl[1], hl[2], hl[3], hl[4]}; win_batch<4, CPL, SUM, BF16, SR>(cx, h4, first, go, srt, raw); } break;
+                case 5: if constexpr (P >= 5) { const int h5[6] = {hl[0], hl[1], hl[2], hl[3], hl[4], hl[5]}; win_batch<5, CPL, SUM, BF16, SR>(cx, h5, first, go, srt, raw); } break;
+                default: if constexpr (P >= 6) { const int h6[7] = {hl[0], hl[1], hl[2], hl[3], hl[4], hl[5], hl[6]}; win_batch<6, CPL, SUM, BF16, SR>(cx, h6, first, go, srt, raw); } break;
+              }
             }
             first = false;
           }
@@ -993,14 +1134,51 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
         // compiler's wait-count pass so, or it would drain vmcnt -- i.e. the previous row's store -- before
         // each row's LDS read below
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        wave_lds_sync();
+        if constexpr (!OF) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          wave_lds_sync();
+        }
         WT(6);
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
           if (r < nrows) {
             const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
-            if (BF16) {
+            if constexpr (OF) {  // (w0 old + the window's samples) / (w0 + k), one rounding to bf16 per window
+              const int k_r = __builtin_amdgcn_readlane(h, i0 + r), w0_r = __builtin_amdgcn_readlane(w0, i0 + r);
+              const float inv = 1.0f / (float)(w0_r + k_r);
+              // f32: acc = old + (sum of samples) / w0 (or the plain sum for a fresh row); bf16: acc = the sum of samples
+              const float fac = SUM ? 1.0f : ((BF16 || w0_r == 0) ? inv : (float)w0_r * inv);
+              float4 o[CPL];
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) {
+                float4 a4 = make_float4(acc[r][2 * c].x, acc[r][2 * c].y, acc[r][2 * c + 1].x, acc[r][2 * c + 1].y);
+                if (BF16) {  // + w0 x old (SUM: + old)
+                  const uint4 w = raw.u[r * UPL + c / 2];
+                  const uint32_t u0 = (c & 1) ? w.z : w.x, u1 = (c & 1) ? w.w : w.y;
+                  const float f = SUM ? 1.0f : (float)w0_r;
+                  a4.x = __builtin_fmaf(bf16_lo(u0), f, a4.x); a4.y = __builtin_fmaf(bf16_hi(u0), f, a4.y);
+                  a4.z = __builtin_fmaf(bf16_lo(u1), f, a4.z); a4.w = __builtin_fmaf(bf16_hi(u1), f, a4.w);
+                }
+                o[c] = SUM ? a4 : make_float4(a4.x * fac, a4.y * fac, a4.z * fac, a4.w * fac);
+              }
+              if (BF16) {
+#pragma unroll
+                for (int k = 0; k < UPL; ++k) {
+                  float4 q;
+                  q.x = __builtin_bit_cast(float, pack_bf16(o[2 * k].x, o[2 * k].y));
+                  q.y = __builtin_bit_cast(float, pack_bf16(o[2 * k].z, o[2 * k].w));
+                  q.z = __builtin_bit_cast(float, pack_bf16(o[2 * k + 1].x, o[2 * k + 1].y));
+                  q.w = __builtin_bit_cast(float, pack_bf16(o[2 * k + 1].z, o[2 * k + 1].w));
+                  st_stream(featb + (row / 2) + lane + k * 64, q);
+                }
+              } else if (SAF_WIN_ABL & 8) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) asm volatile("" ::"v"(o[c].x), "v"(o[c].y), "v"(o[c].z), "v"(o[c].w));
+              } else {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) st_stream(&feat[row + chs[c]], o[c]);
+              }
+            } else if (BF16) {
 #pragma unroll
               for (int k = 0; k < UPL; ++k) {
                 const float4 lo = rows[(r * CPL + 2 * k) * 64 + lane], hi = rows[(r * CPL + 2 * k + 1) * 64 + lane];
@@ -1017,7 +1195,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
             }
           }
         }
-        wave_lds_sync();  // the row buffer is rewritten by the next sub-chunk
+        if constexpr (!OF) wave_lds_sync();  // the row buffer is rewritten by the next sub-chunk
         WT(7);
         i0 += nrows;
       }
@@ -1042,33 +1220,47 @@ struct WinLayout {
   size_t img_bytes, maps_bytes, mask_bytes, cmax_off, total;
   uint32_t mask_plane;
 };
-WinLayout win_layout(int64_t n_vox, int D, int P) {
+WinLayout win_layout(int64_t n_vox, int D, int P, bool bricks = false) {
   WinLayout w;
   w.img_bytes = ((size_t)D * (P + 1) * sizeof(float) + 255) & ~(size_t)255;
   w.maps_bytes = (size_t)kWin * w.img_bytes;
   w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
   w.cmax_off = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;  // the brick form's channel maxima and camera table
-  w.total = w.cmax_off + brick_aux_bytes_est(n_vox, D);
+  // the brick form's segment pools (6.5 GB at 256^3) only where that form can run: the row forms end at cmax_off
+  w.total = w.cmax_off + (bricks ? brick_aux_bytes_est(n_vox, D) : 0);
   return w;
 }
 
 using WinFn = void (*)(KVol, WinArgs, const WinTable*, const float*, int, unsigned long long*, unsigned int*, const uint32_t*,
                        uint32_t, const unsigned long long*, int);
-template <int CPL>
+template <int CPL, bool OF>
 WinFn pick_win(bool sum, bool bf16) {
   if (bf16) {
     if (CPL % 2 != 0) return nullptr;
     constexpr int C2 = CPL % 2 == 0 ? CPL : 2;
-    return sum ? fuse_window_kernel<C2, true, true> : fuse_window_kernel<C2, false, true>;
+    return sum ? fuse_window_kernel<C2, true, true, OF> : fuse_window_kernel<C2, false, true, OF>;
   }
-  return sum ? fuse_window_kernel<CPL, true, false> : fuse_window_kernel<CPL, false, false>;
+  return sum ? fuse_window_kernel<CPL, true, false, OF> : fuse_window_kernel<CPL, false, false, OF>;
+}
+template <int CPL>
+WinFn pick_win(bool sum, bool bf16, bool of, size_t* lds) {
+  *lds = of ? WinCfg<CPL, true>::total : WinCfg<CPL, false>::total;
+  return of ? pick_win<CPL, true>(sum, bf16) : pick_win<CPL, false>(sum, bf16);
 }
 
 // Shapes the windowed path takes; everything else runs the per-frame pipeline.
 }  // namespace
 
-size_t window_workspace_bytes(int64_t n_vox, int D, int P) { return win_layout(n_vox, D, P).total; }
+size_t window_workspace_bytes(int64_t n_vox, int D, int P, bool bricks) { return win_layout(n_vox, D, P, bricks).total; }
+
+// SAF_WIN_FORM (read per call): "rows" = the frame-ordered row kernel (bit-identical to fusing frame after frame), "sums" =
+// its order-free form (a row's samples of the window summed in registers, one blend per row: feature values within fp32
+// rounding of the sequential path, everything else exact), "bricks" = saf_brick.hip.  Default: sums.
+bool window_form_sums() {
+  const char* e = getenv("SAF_WIN_FORM");
+  return !e || e[0] == 's';
+}
 
 // Frames per window: 128 (SAF_WINDOW_FRAMES) unless SAF_WIN_FRAMES=64 asks for the shorter form (read per call).
 int window_frames() {
@@ -1099,7 +1291,7 @@ bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
   if (f0.npx + 3 > 255 || f0.npy + 3 > 255) return false;  // a hit's map cell travels as two bytes
   const WinLayout wl = win_layout(kv.N, kv.D, f0.npy * f0.npx);
   if (wl.maps_bytes >= (size_t)kTapOutside) return false;  // the taps are buffer loads with 31-bit byte offsets
-  return workspace_bytes >= wl.total;
+  return workspace_bytes >= wl.cmax_off;  // (the brick form's own region was checked above: brick_aux_fits)
 }
 
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
@@ -1122,11 +1314,12 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const int split = brick_form && brick_split() ? 1 : 0;
   WinFn fn = nullptr;
   size_t win_lds = 0;
+  const bool of = window_form_sums();
   if (!brick_form) switch (kv.D / 256) {
-    case 1: fn = pick_win<1>(sum, kv.bf16 != 0); win_lds = WinCfg<1>::total; break;
-    case 2: fn = pick_win<2>(sum, kv.bf16 != 0); win_lds = WinCfg<2>::total; break;
-    case 3: fn = pick_win<3>(sum, kv.bf16 != 0); win_lds = WinCfg<3>::total; break;
-    default: fn = pick_win<4>(sum, kv.bf16 != 0); win_lds = WinCfg<4>::total; break;
+    case 1: fn = pick_win<1>(sum, kv.bf16 != 0, of, &win_lds); break;
+    case 2: fn = pick_win<2>(sum, kv.bf16 != 0, of, &win_lds); break;
+    case 3: fn = pick_win<3>(sum, kv.bf16 != 0, of, &win_lds); break;
+    default: fn = pick_win<4>(sum, kv.bf16 != 0, of, &win_lds); break;
   }
   if (!brick_form) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1135,7 +1328,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   }
   float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
   const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
-  uint32_t grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : 2);
+  uint32_t grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : (of ? SAF_WIN_OF_WPE : 2));
   const uint32_t n_pieces = (uint32_t)(((int64_t)kv.N + kPiece - 1) / kPiece);
   const uint32_t n_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
   if (grid > n_wgs) grid = n_wgs;

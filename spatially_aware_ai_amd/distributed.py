@@ -28,7 +28,8 @@ import torch.distributed as dist
 from . import _abi
 from ._lib import SafError, check, current_stream_ptr, lib
 
-_CHUNK_ELEMS = 1 << 28  # collectives are issued in <= 1 GiB (fp32) pieces
+_CHUNK_ELEMS = 1 << 28  # all_reduce / frame exchange are issued in <= 1 GiB (fp32) pieces
+_PIECE_BYTES = 4 << 30  # the striped reduce-scatter / all-gather work IN PLACE (no staging copy): pieces of <= 4 GiB
 
 
 def shard_frames(n_frames: int, rank: int, world: int) -> range:
@@ -39,12 +40,65 @@ def shard_frames(n_frames: int, rank: int, world: int) -> range:
 
 
 def voxel_shard(n_voxels: int, rank: int, world: int):
-    """(first, count) of the voxel range rank owns after a reduce-scatter merge: equal blocks of
-    n_voxels // world, the remainder goes to the last rank."""
+    """(first, count) of rank's part when n_voxels are cut into ``world`` equal contiguous blocks (the remainder goes to the
+    last rank): how ``query_sharded`` splits a volume that is whole on every rank, and the ownership inside ONE piece of
+    the striped merge (``stripe_plan``)."""
     per = n_voxels // world
     first = rank * per
     count = per if rank < world - 1 else n_voxels - first
     return first, count
+
+
+# ---- striped ownership: the merge's collectives run in place, piece by piece ---------------------------------------------
+#
+# RCCL's reduce-scatter wants ONE contiguous send buffer of world equal parts and leaves part k on rank k.  Round 3 kept
+# "rank k owns voxel range k of the whole volume", which made every <= 1 GiB piece a strided gather of world slices into a
+# staging buffer (+ 34 GB read + 34 GB written per merge, and one staging buffer serialising copy j + 1 behind collective j).
+# Now the OWNERSHIP follows the pieces: the rows of a volume (or of one slab of it) are cut into contiguous pieces of
+# `piece_rows` rows (a multiple of world; <= 4 GiB of the widest tensor), and inside every piece rank k owns the k-th of
+# world equal parts.  A piece is then exactly what reduce_scatter_tensor / all_gather_into_tensor take in place:
+#   reduce_scatter_tensor(piece[k c : (k + 1) c], piece)        all_gather_into_tensor(piece, piece[k c : (k + 1) c])
+# No staging buffer, no copy.  Rank k ends with a list of STRIPES, one per piece; every tensor of the volume uses the same
+# row boundaries, so a voxel's features, colours, weights and label counts are finalised on the same rank.
+
+
+def piece_rows_for(row_bytes: int, world: int, piece_bytes: int | None = None) -> int:
+    """Rows of one piece for tensors whose widest row has ``row_bytes`` bytes: a multiple of world, at least world."""
+    piece_bytes = _PIECE_BYTES if piece_bytes is None else piece_bytes
+    return max(world, (piece_bytes // max(1, row_bytes)) // world * world)
+
+
+def stripe_plan(n_rows: int, world: int, piece_rows: int, row0: int = 0):
+    """[(first_row, rows, c)] of the pieces that tile rows [row0, row0 + n_rows): inside a piece rank k owns rows
+    [first_row + k c, first_row + (k + 1) c); the piece's last rows - world c (fewer than world, and only in the LAST piece)
+    belong to the last rank."""
+    if piece_rows % world != 0 or piece_rows <= 0:
+        raise ValueError("piece_rows must be a positive multiple of the world size")
+    plan, r = [], 0
+    while r < n_rows:
+        rows = min(piece_rows, n_rows - r)
+        plan.append((row0 + r, rows, rows // world))
+        r += rows
+    return plan
+
+
+def stripes_of_rank(plan, rank: int, world: int):
+    """The (first, count) row ranges ``rank`` owns under ``plan`` (adjacent ranges merged), ascending."""
+    out = []
+
+    def add(f, c):
+        if c <= 0:
+            return
+        if out and out[-1][0] + out[-1][1] == f:
+            out[-1] = (out[-1][0], out[-1][1] + c)
+        else:
+            out.append((f, c))
+
+    for first, rows, c in plan:
+        add(first + rank * c, c)
+        if rank == world - 1:
+            add(first + world * c, rows - world * c)
+    return out
 
 
 def _chunks(t: torch.Tensor):
@@ -59,85 +113,82 @@ def _all_reduce(t, group):
 
 
 def _rows_per_piece(t, world):
-    """Rows of one rank block that one collective moves: world * rows * row_bytes <= _CHUNK_ELEMS * 4 bytes."""
-    row_elems = max(1, t[0].numel()) if t.dim() > 1 else 1
+    """Rows of one rank block that one staged collective of the frame exchange moves (<= 1 GiB in all)."""
+    row_elems = max(1, t[0].numel()) if t.dim() > 1 and t.shape[0] > 0 else 1
     return max(1, _CHUNK_ELEMS // (world * row_elems))
 
 
-def _reduce_scatter_rows(t, group, rank, world, _force_collective=False):
-    """Sum dim-0 row blocks across ranks so that rank k holds the reduced rows of voxel_shard(k);
-    other rows keep this rank's partial sums.
-
-    nccl (RCCL): issued in pieces of at most 1 GiB.  A piece is rows [j, j + c) of EVERY rank's block; RCCL wants the send
-    buffer contiguous, so the world slices are copied into a staging buffer (one strided device copy of 1 GiB, reused),
-    ``reduce_scatter_tensor`` sums them straight into this rank's slice of the volume.  (The earlier form handed the whole
-    34 GB volume to one in-place collective.)"""
-    n = t.shape[0]
-    per = n // world
-    backend = dist.get_backend(group)
-    if per > 0:
-        main = t[: per * world]
-        if backend == "nccl" or _force_collective:
-            blocks = main.view((world, per) + tuple(main.shape[1:]))
-            c = min(per, _rows_per_piece(t, world))
-            stage = torch.empty((world, c) + tuple(main.shape[1:]), dtype=t.dtype, device=t.device)
-            for j in range(0, per, c):
-                cj = min(c, per - j)
-                src = stage[:, :cj] if cj == c else stage.view(-1)[: world * cj * blocks[0, 0].numel()].view((world, cj) + tuple(main.shape[1:]))
-                src.copy_(blocks[:, j : j + cj])
-                dist.reduce_scatter_tensor(blocks[rank, j : j + cj], src, op=dist.ReduceOp.SUM, group=group)
-        else:  # gloo has no reduce_scatter: one rooted reduce per destination
-            for k in range(world):
-                dist.reduce(main[k * per : (k + 1) * per], dst=dist.get_global_rank(group, k) if group else k,
-                            op=dist.ReduceOp.SUM, group=group)
-    if n > per * world:  # remainder rows belong to the last rank
-        tail = t[per * world :]
-        dst = world - 1
-        dist.reduce(tail, dst=dist.get_global_rank(group, dst) if group else dst, op=dist.ReduceOp.SUM, group=group)
+def _global_rank(group, k):
+    return dist.get_global_rank(group, k) if group else k
 
 
-def _all_gather_rows(t, group, rank, world, _force_collective=False):
-    """Every rank's reduced block to every rank, in pieces of at most 1 GiB (nccl: ``all_gather_into_tensor`` into a
-    staging buffer, one strided copy back into the world blocks)."""
-    n = t.shape[0]
-    per = n // world
-    if per > 0:
-        main = t[: per * world]
-        if dist.get_backend(group) == "nccl" or _force_collective:
-            blocks = main.view((world, per) + tuple(main.shape[1:]))
-            c = min(per, _rows_per_piece(t, world))
-            stage = torch.empty((world, c) + tuple(main.shape[1:]), dtype=t.dtype, device=t.device)
-            for j in range(0, per, c):
-                cj = min(c, per - j)
-                dst = stage[:, :cj] if cj == c else stage.view(-1)[: world * cj * blocks[0, 0].numel()].view((world, cj) + tuple(main.shape[1:]))
-                dist.all_gather_into_tensor(dst, blocks[rank, j : j + cj].contiguous(), group=group)
-                blocks[:, j : j + cj].copy_(dst)
-        else:
-            outs = [main[k * per : (k + 1) * per] for k in range(world)]
-            dist.all_gather(outs, main[rank * per : (rank + 1) * per].clone(), group=group)
-    if n > per * world:
-        src = world - 1
-        dist.broadcast(t[per * world :], src=dist.get_global_rank(group, src) if group else src, group=group)
+def _reduce_scatter_striped(t, plan, group, rank, world):
+    """SUM the rows of ``t`` across the ranks, piece by piece and in place: rank k ends with the reduced rows of its stripes
+    (``stripes_of_rank``), the other rows keep this rank's partial sums.  The same calls on every backend (RCCL, gloo)."""
+    for first, rows, c in plan:
+        if c > 0:
+            piece = t[first : first + world * c]
+            dist.reduce_scatter_tensor(piece[rank * c : (rank + 1) * c], piece, op=dist.ReduceOp.SUM, group=group)
+        if rows > world * c:  # fewer than world rows at the very end: they belong to the last rank
+            dist.reduce(t[first + world * c : first + rows], dst=_global_rank(group, world - 1), op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather_striped(t, plan, group, rank, world):
+    """Every rank's stripes to every rank, piece by piece and in place."""
+    for first, rows, c in plan:
+        if c > 0:
+            piece = t[first : first + world * c]
+            dist.all_gather_into_tensor(piece, piece[rank * c : (rank + 1) * c], group=group)
+        if rows > world * c:
+            dist.broadcast(t[first + world * c : first + rows], src=_global_rank(group, world - 1), group=group)
+
+
+def _plan_for(tensors: dict, n_rows: int, world: int, row0: int = 0, piece_bytes: int | None = None):
+    widest = max(max(1, t[0].numel()) * t.element_size() if t.shape[0] else 1 for t in tensors.values())
+    return stripe_plan(n_rows, world, piece_rows_for(widest, world, piece_bytes), row0)
+
+
+def _agree(ok: bool, device, group) -> bool:
+    """True when ``ok`` on EVERY rank (one small all_reduce: the ranks decide together before the next collective)."""
+    flag = torch.tensor([0.0 if ok else 1.0], device=device)
+    dist.all_reduce(flag, group=group)
+    return float(flag) == 0.0
 
 
 def probe_collectives(device, group=None):
-    """Run the reduce-scatter / all-gather forms ``merge_sums`` would use on a small tensor and check the sums: decides the
-    merge mode BEFORE any volume is touched (a collective that raises half-way through a volume cannot be retried with
-    another one -- the rows that were already summed would be summed twice).  Returns None, or what went wrong."""
+    """Run the striped reduce-scatter / all-gather ``merge_sums`` would use on a small tensor -- several pieces, a ragged
+    last piece, a tail of fewer than world rows -- and check the sums: decides the merge mode BEFORE any volume is touched
+    (a collective that raises half-way through a volume cannot be retried with another one: the rows that were already
+    summed would be summed twice).  After every step the ranks agree on the outcome with an all_reduce of a flag, so a rank
+    that failed and a rank that did not never issue different collectives next.  Returns None, or what went wrong."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = 5 * world + world // 2 + 3  # three pieces of 2 * world rows; the last one ragged, with a tail
+    base = torch.arange(n * 6, dtype=torch.float32, device=device).view(n, 6) + 1.0
+    t, want = base * (rank + 1), base * (world * (world + 1) / 2)
+    plan = stripe_plan(n, world, 2 * world)
+    why = None
     try:
-        n = 4 * world + 3
-        t = (torch.arange(n * 6, dtype=torch.float32, device=device).view(n, 6) + 1.0) * (rank + 1)
-        want = (torch.arange(n * 6, dtype=torch.float32, device=device).view(n, 6) + 1.0) * (world * (world + 1) / 2)
-        _reduce_scatter_rows(t, group, rank, world)
-        first, count = voxel_shard(n, rank, world)
-        if not torch.equal(t[first : first + count], want[first : first + count]):
-            return "reduce-scatter probe: wrong sums"
-        _all_gather_rows(t, group, rank, world)
-        if not torch.equal(t, want):
-            return "all-gather probe: wrong rows"
+        _reduce_scatter_striped(t, plan, group, rank, world)
+        if any(not torch.equal(t[f : f + c], want[f : f + c]) for f, c in stripes_of_rank(plan, rank, world)):
+            why = "reduce-scatter probe: wrong sums"
     except Exception as e:  # noqa: BLE001 -- whatever the backend raises is the answer
-        return f"{type(e).__name__}: {e}"[:200]
+        why = f"{type(e).__name__}: {e}"[:200]
+    try:
+        if not _agree(why is None, device, group):
+            return why or "reduce-scatter probe failed on another rank"
+    except Exception as e:  # noqa: BLE001
+        return why or f"{type(e).__name__}: {e}"[:200]
+    try:
+        _all_gather_striped(t, plan, group, rank, world)
+        if not torch.equal(t, want):
+            why = "all-gather probe: wrong rows"
+    except Exception as e:  # noqa: BLE001
+        why = f"{type(e).__name__}: {e}"[:200]
+    try:
+        if not _agree(why is None, device, group):
+            return why or "all-gather probe failed on another rank"
+    except Exception as e:  # noqa: BLE001
+        return why or f"{type(e).__name__}: {e}"[:200]
     return None
 
 
@@ -178,6 +229,9 @@ def gather_frames(tensors, group=None):
             continue
         t = t.contiguous()
         full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if t.shape[0] == 0:  # nothing to exchange (every rank holds the same number of frames: none)
+            out.append(full)
+            continue
         if dist.get_backend(group) == "nccl":
             out_blocks = full.view((world, t.shape[0]) + tuple(t.shape[1:]))
             c = min(t.shape[0], _rows_per_piece(t, world))
@@ -208,17 +262,36 @@ VOLUME_TENSORS = ("clip_feat", "rgb", "tsdf", "weight", "tsdf_weight", "labels_o
 # the k-th part of EVERY slab (stripes), which is as good a voxel sharding for the query scan as one range.
 
 
-def slab_bounds(nx: int, n_slabs: int, align: int = 16):
+def slab_bounds(nx: int, n_slabs: int, align: int = 16, ramp: bool = False):
     """x-plane ranges [(x0, count)] of n_slabs slabs; boundaries on multiples of ``align`` planes (the row kernel's tile)
-    when nx allows it."""
+    when nx allows it.  ``ramp``: small slabs at both ends, large ones in the middle (256 planes, 8 slabs: 16 32 32 48 48 32
+    32 16) -- the communication stream of the slab-pipelined merge starts after one SMALL slab's fusion instead of 1/8 of
+    the job, and the collective left exposed at the end is a small slab's."""
     unit = align if nx % align == 0 and nx // align >= n_slabs else 1
     blocks = nx // unit
+    n_slabs = max(1, min(n_slabs, blocks)) if blocks else 0
+    if ramp and n_slabs >= 3 and blocks > n_slabs:
+        w = [min(i + 1, n_slabs - i) for i in range(n_slabs)]
+        ideal = [blocks * x / sum(w) for x in w]
+        cnts = [max(1, int(v + 0.5)) for v in ideal]
+        mid_out = sorted(range(n_slabs), key=lambda i: abs(i - (n_slabs - 1) / 2))  # what rounding left over: middle slabs first
+        k = 0
+        while sum(cnts) < blocks:
+            cnts[mid_out[k % n_slabs]] += 1
+            k += 1
+        k = 0
+        while sum(cnts) > blocks:
+            i = mid_out[k % n_slabs]
+            if cnts[i] > 1:
+                cnts[i] -= 1
+            k += 1
+    else:
+        cnts = [blocks // n_slabs + (1 if i < blocks % n_slabs else 0) for i in range(n_slabs)] if n_slabs else []
     out, x = [], 0
-    for s in range(n_slabs):
-        cnt = (blocks // n_slabs + (1 if s < blocks % n_slabs else 0)) * unit
-        if cnt:
-            out.append((x, cnt))
-        x += cnt
+    for c in cnts:
+        if c:
+            out.append((x, c * unit))
+        x += c * unit
     return out
 
 
@@ -250,31 +323,43 @@ def slab_rows(fusion, x0: int, count: int):
     return x0 * ny * nz, count * ny * nz
 
 
-def merge_slab_sums(tensors: dict, first_row: int, n_rows: int, group=None, mode: str = "reduce_scatter"):
+def merge_slab_sums(tensors: dict, first_row: int, n_rows: int, group=None, mode: str = "reduce_scatter", piece_bytes=None):
     """SUM rows [first_row, first_row + n_rows) of every tensor across the ranks; with ``reduce_scatter`` rank k ends with
-    the k-th part of the slab (returned as (first, count) in volume rows), the other rows keep partial sums."""
+    its stripes of the slab (returned as a list of (first, count) in volume rows: the k-th part of every piece of the slab),
+    the other rows keep partial sums."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return first_row, n_rows
+        return [(first_row, n_rows)]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    for t in tensors.values():
-        part = t[first_row : first_row + n_rows]
-        if mode == "all_reduce":
-            _all_reduce(part, group)
-        else:
-            _reduce_scatter_rows(part, group, rank, world)
     if mode == "all_reduce":
-        return first_row, n_rows
-    f, c = voxel_shard(n_rows, rank, world)
-    return first_row + f, c
+        for t in tensors.values():
+            _all_reduce(t[first_row : first_row + n_rows], group)
+        return [(first_row, n_rows)]
+    plan = _plan_for(tensors, n_rows, world, first_row, piece_bytes)
+    for t in tensors.values():
+        _reduce_scatter_striped(t, plan, group, rank, world)
+    return stripes_of_rank(plan, rank, world)
+
+
+def _require_f32_sums(fusion, what):
+    if fusion._buffers["clip_feat"].dtype != torch.float32:
+        raise SafError(
+            f"{what} needs an f32 feature volume (got {fusion._buffers['clip_feat'].dtype}): per-rank SUMS kept in bf16 would "
+            "round every addition to 8 bits; fuse the per-rank shards in f32 and convert after the merge"
+        )
 
 
 def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, group=None, comm_stream=None, mode="reduce_scatter",
-                         stats_ptr=None, profiler=None):
+                         stats_ptr=None, profiler=None, ramp=True):
     """One frame-sharded job with the merge hidden behind the fusion: the rank's frames are fused slab by slab (SUM mode)
-    and each finished slab is reduce-scattered + finalised on ``comm_stream`` while the next one is fused.  Returns the list
-    of (first_row, count) stripes that hold final means on this rank.  The caller's stream ends ordered after the last
-    collective."""
+    and each finished slab is reduce-scattered (in place, striped: ``merge_slab_sums``) + finalised on ``comm_stream`` while
+    the next one is fused.  Returns the list of (first_row, count) stripes that hold final means on this rank, and leaves the
+    module in running-mean mode with those stripes recorded (``_shard_stripes``): it refuses further ``integrate`` calls
+    until ``gather_shards``.  The caller's stream ends ordered after the last collective."""
+    _require_f32_sums(fusion, "fuse_merge_pipelined")
+    if getattr(fusion, "_shard_stripes", None) is not None:
+        raise SafError("this volume was already merged and holds only its voxel stripes")
+    fusion.flush()  # frames still queued behind integrate() belong to the volume (and finish the deferred clear of reset())
     if fusion.accum_mode != _abi.SAF_SUM:
         raise SafError("fuse_merge_pipelined fuses sums: set accum_mode = SAF_SUM (reset(accum_mode=SAF_SUM))")
     L = lib()
@@ -283,11 +368,10 @@ def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, grou
     comm = comm_stream if comm_stream is not None else main
     tensors = {k: fusion._buffers[k] for k in VOLUME_TENSORS if fusion._buffers.get(k) is not None}
     stats_ptr = fusion._buffers["fuse_stats"].data_ptr() if stats_ptr is None else stats_ptr
-    if fusion.__dict__.get("_feat_stale"):
-        fusion.flush()  # (slabs are fused one by one: the deferred clear of reset() is finished first)
     stripes = []
     nx = int(fusion.nvox[0])
-    for x0, cnt in slab_bounds(nx, n_slabs):
+    n = fusion._buffers["tsdf"].numel()
+    for x0, cnt in slab_bounds(nx, n_slabs, ramp=ramp):
         vol = slab_descriptor(fusion, x0, cnt)
         check(L.saf_fuse_frames_profiled(C.byref(vol), frame_arr, n_frames, workspace.data_ptr(), workspace.numel(), stats_ptr,
                                          profiler, main.cuda_stream), "saf_fuse_frames (slab)")
@@ -295,37 +379,42 @@ def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, grou
         with torch.cuda.stream(comm):
             comm.wait_event(fused)
             r0, nr = slab_rows(fusion, x0, cnt)
-            first, count = merge_slab_sums(tensors, r0, nr, group, mode)
             vdesc = fusion._c_volume(for_fuse=True)
-            check(L.saf_merge_finalize(C.byref(vdesc), first, count, comm.cuda_stream), "saf_merge_finalize")
-            stripes.append((first, count))
+            for first, count in merge_slab_sums(tensors, r0, nr, group, mode):
+                check(L.saf_merge_finalize(C.byref(vdesc), first, count, comm.cuda_stream), "saf_merge_finalize")
+                stripes.append((first, count))
     if comm is not main:
         main.wait_event(comm.record_event())
+    # the volume now holds means on this rank's stripes (partial sums elsewhere): no longer a SUM volume
+    torch.nn.Module.__setattr__(fusion, "accum_mode", _abi.SAF_RUNNING_MEAN)
+    whole = sum(c for _, c in stripes) == n  # one rank, or all_reduce: every slab is complete here
+    fusion._shard_stripes = None if whole else list(stripes)
     return stripes
 
 
-def merge_sums(tensors: dict, group=None, mode: str = "reduce_scatter", gather: bool = False):
+def merge_sums(tensors: dict, group=None, mode: str = "reduce_scatter", gather: bool = False, piece_bytes=None):
     """Element-wise SUM of per-rank volume tensors (dict name -> tensor with voxels on dim 0).
-    Device-agnostic (RCCL on GPUs, gloo in the CPU tests).  Returns (first, count): the voxel range
-    that is fully reduced on this rank."""
+    Device-agnostic (RCCL on GPUs, gloo in the CPU tests).  Returns the list of (first, count) voxel ranges that are fully
+    reduced on this rank: its stripes (``stripe_plan``), or [(0, n)]."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = next(iter(tensors.values())).shape[0]
     if world == 1:
-        return 0, n
+        return [(0, n)]
     if mode == "all_reduce":
         for t in tensors.values():
             _all_reduce(t, group)
-        return 0, n
+        return [(0, n)]
     if mode != "reduce_scatter":
         raise ValueError(mode)
+    plan = _plan_for(tensors, n, world, 0, piece_bytes)
     for t in tensors.values():
-        _reduce_scatter_rows(t, group, rank, world)
+        _reduce_scatter_striped(t, plan, group, rank, world)
     if gather:
         for t in tensors.values():
-            _all_gather_rows(t, group, rank, world)
-        return 0, n
-    return voxel_shard(n, rank, world)
+            _all_gather_striped(t, plan, group, rank, world)
+        return [(0, n)]
+    return stripes_of_rank(plan, rank, world)
 
 
 def _volume_tensors(fusion):
@@ -352,18 +441,14 @@ def means_to_sums(fusion):
     fusion.accum_mode = _abi.SAF_SUM
 
 
-def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool = False):
+def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool = False, piece_bytes=None):
     """The single merge step of the frame-sharded job: RCCL SUM of the per-rank sum volumes, then
     the local divide.  ``fusion`` must have been fused with ``accum_mode = SAF_SUM`` (call
-    ``means_to_sums`` first otherwise).  Returns the (first, count) voxel range that holds final
-    means on this rank."""
-    if fusion.clip_feat.dtype != torch.float32:
-        raise SafError(
-            f"merge_volumes needs an f32 feature volume (got {fusion.clip_feat.dtype}): per-rank SUMS kept in bf16 would "
-            "round every addition to 8 bits; fuse the per-rank shards in f32 and convert after the merge"
-        )
-    if getattr(fusion, "_shard_range", None) is not None:
-        raise SafError("this volume was already merged and holds only its voxel shard")
+    ``means_to_sums`` first otherwise).  Returns the list of (first, count) voxel ranges that hold final
+    means on this rank ([(0, n)] after ``gather`` / ``all_reduce``)."""
+    _require_f32_sums(fusion, "merge_volumes")
+    if getattr(fusion, "_shard_stripes", None) is not None:
+        raise SafError("this volume was already merged and holds only its voxel stripes")
     flush = getattr(fusion, "flush", None)
     if flush is not None:
         flush()  # frames still queued behind integrate() belong to this job
@@ -371,33 +456,40 @@ def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool
         means_to_sums(fusion)
     tensors = _volume_tensors(fusion)
     n = fusion.tsdf.numel()
-    first, count = merge_sums(tensors, group=group, mode=mode, gather=False)
-    finalize_sums(fusion, first, count)
-    if (first, count) == (0, n):
-        return first, count
-    if gather:
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        for t in tensors.values():
-            _all_gather_rows(t, group, rank, world)
-        fusion.accum_mode = _abi.SAF_RUNNING_MEAN
-        return 0, n
-    # voxel-sharded result: only [first, first+count) holds the job's means; the other rows hold this rank's
-    # partial sums.  integrate() refuses to fuse into it (clipfusion._fuse) until gather_shards() is called.
+    stripes = merge_sums(tensors, group=group, mode=mode, gather=False, piece_bytes=piece_bytes)
+    for first, count in stripes:
+        finalize_sums(fusion, first, count)
+    if stripes == [(0, n)]:
+        return stripes
+    # voxel-sharded result: only the stripes hold the job's means; the other rows hold this rank's partial sums.
+    # integrate() refuses to fuse into it (clipfusion._fuse_now) until gather_shards() has made it whole.
     fusion.accum_mode = _abi.SAF_RUNNING_MEAN
-    fusion._shard_range = (first, count)
-    return first, count
+    fusion._shard_stripes = list(stripes)
+    if gather:
+        gather_shards(fusion, group)
+        return [(0, n)]
+    return stripes
 
 
 def gather_shards(fusion, group=None):
-    """All-gather a voxel-sharded merged volume (merge_volumes(..., gather=False)) so that every rank holds
-    the whole merged volume and may fuse further frames."""
-    if getattr(fusion, "_shard_range", None) is None:
-        return 0, fusion.tsdf.numel()
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    for t in _volume_tensors(fusion).values():
-        _all_gather_rows(t, group, rank, world)
-    fusion._shard_range = None
-    return 0, fusion.tsdf.numel()
+    """All-gather a voxel-sharded merged volume (``merge_volumes(..., gather=False)`` or ``fuse_merge_pipelined``) so that every
+    rank holds the whole merged volume and may fuse further frames.  Every rank's stripes travel as they lie: the ranks
+    exchange their stripe lists (a few integers) and each stripe is broadcast in place by its owner."""
+    n = fusion.tsdf.numel()
+    mine = getattr(fusion, "_shard_stripes", None)
+    if mine is None:
+        return [(0, n)]
+    world = dist.get_world_size(group)
+    every = [None] * world
+    dist.all_gather_object(every, [tuple(int(v) for v in st) for st in mine], group=group)
+    tensors = _volume_tensors(fusion)
+    for k, stripes in enumerate(every):
+        for first, count in stripes:
+            for t in tensors.values():
+                for c in _chunks(t[first : first + count]):
+                    dist.broadcast(c, src=_global_rank(group, k), group=group)
+    fusion._shard_stripes = None
+    return [(0, n)]
 
 
 # --------------------------------------------------------------------------------------------
@@ -423,64 +515,82 @@ def shard_features_16(fusion, first, count, dtype=torch.float16):
     return feats
 
 
+def _stripes_for_query(fusion, n, rank, world):
+    st = getattr(fusion, "_shard_stripes", None)
+    return ([tuple(x) for x in st], True) if st is not None else ([voxel_shard(n, rank, world)], False)
+
+
 def query_sharded(fusion, text, epilogue="row_argmax", group=None, gather=True, dtype=torch.float16, scan_fn=None, **kw):
     """BASELINE config 5: many text queries over the merged volume, voxel-sharded over the ranks.
 
-    After ``merge_volumes(..., gather=False)`` rank k holds the means of voxel range k (its ``_shard_range``); a
-    volume that is whole on every rank is split by ``voxel_shard``.  Each rank scans ONLY its range with
-    ``query_scan_wide`` (no data-path collective: the volume never moves) and the small results are combined:
+    After ``merge_volumes(..., gather=False)`` / ``fuse_merge_pipelined`` rank k holds the means of its STRIPES
+    (``_shard_stripes``: one per piece of the merge); a volume that is whole on every rank is split by ``voxel_shard``.
+    Each rank scans ONLY its stripes with ``query_scan_wide`` (no data-path collective: the volume never moves) and the
+    small results are combined:
 
     * ``"query_max"``   -> (value [Q], voxel [Q]) identical on every rank: an all-gather of Q (score, voxel) pairs and a
       max -- equal scores resolve to the smaller voxel index, as a single-rank scan would;
-    * ``"row_argmax"``  -> (index, value) of this rank's voxel range, or of all N voxels when ``gather`` (all-gather of
-      4 + 4 bytes per voxel);
-    * ``"scores"`` / ``"vs_background"`` -> this rank's [count, Q] block (33 GB in all at config 5: it stays sharded).
+    * ``"row_argmax"``  -> (index, value) of this rank's stripes (in stripe order), or of all N voxels in voxel order when
+      ``gather`` (all-gather of 4 + 4 bytes per voxel);
+    * ``"scores"`` / ``"vs_background"`` -> this rank's [count, Q] rows, stripe after stripe (33 GB in all at config 5: it
+      stays sharded).
 
     ``scan_fn(feats, text, epilogue, row_offset=..., **kw)`` defaults to the HIP scan; the CPU tests inject an
     oracle-backed one to exercise the sharding and the reductions under gloo."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = fusion.tsdf.numel()
-    rng = getattr(fusion, "_shard_range", None)
-    first, count = rng if rng is not None else voxel_shard(n, rank, world)
-    if scan_fn is None:
+    stripes, from_merge = _stripes_for_query(fusion, n, rank, world)
+    hip = scan_fn is None
+    if hip:
         from .clipfusion import query_scan_wide
 
         scan_fn = query_scan_wide
-        feats = shard_features_16(fusion, first, count, dtype)
-    else:
-        feats = fusion.clip_feat[first:first + count]
-    res = scan_fn(feats, text, epilogue, row_offset=first, **kw)
-    if world == 1:
-        return res
+    parts = []
+    for first, count in stripes:
+        feats = shard_features_16(fusion, first, count, dtype) if hip else fusion.clip_feat[first:first + count]
+        parts.append(scan_fn(feats, text, epilogue, row_offset=first, **kw))
+    big = torch.iinfo(torch.int64).max
+
+    def best_of(vals, rows):  # [k, Q] candidates -> the maximum; among equals the smallest voxel index
+        best = vals.max(dim=0).values
+        cand = torch.where((vals == best[None]) & (rows >= 0), rows, torch.full_like(rows, big))
+        pick = cand.min(dim=0).values
+        return best, torch.where(pick == big, torch.full_like(pick, -1), pick)
+
     if epilogue == "query_max":
-        val, row = res
+        val, row = parts[0] if len(parts) == 1 else best_of(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+        if world == 1:
+            return val, row
         vals = [torch.empty_like(val) for _ in range(world)]
         rows = [torch.empty_like(row) for _ in range(world)]
         dist.all_gather(vals, val.contiguous(), group=group)
         dist.all_gather(rows, row.contiguous(), group=group)
-        vals, rows = torch.stack(vals), torch.stack(rows)
-        best = vals.max(dim=0).values
-        # among the ranks that reach the maximum, the smallest voxel index (ranks own ascending ranges)
-        big = torch.iinfo(torch.int64).max
-        cand = torch.where((vals == best[None]) & (rows >= 0), rows, torch.full_like(rows, big))
-        pick = cand.min(dim=0).values
-        return best, torch.where(pick == big, torch.full_like(pick, -1), pick)
+        return best_of(torch.stack(vals), torch.stack(rows))
+    if isinstance(parts[0], tuple):
+        res = tuple(torch.cat([p[i] for p in parts]) for i in range(len(parts[0]))) if len(parts) > 1 else parts[0]
+    else:
+        res = torch.cat(parts) if len(parts) > 1 else parts[0]
+    if world == 1:
+        return res
     if epilogue == "row_argmax" and gather:
         idx, val = res
-        counts = [voxel_shard(n, k, world)[1] for k in range(world)] if rng is None else None
-        if counts is None:  # ranges came from the merge: exchange their sizes
-            c = torch.tensor([count], dtype=torch.int64, device=idx.device)
-            cs = [torch.empty_like(c) for _ in range(world)]
-            dist.all_gather(cs, c, group=group)
-            counts = [int(x) for x in cs]
+        every = [None] * world
+        dist.all_gather_object(every, stripes, group=group)
+        counts = [sum(c for _, c in st) for st in every]
         pad = max(counts)
         out = []
         for t in (idx, val):
             mine = torch.zeros(pad, dtype=t.dtype, device=t.device)
-            mine[:count] = t
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine, group=group)
-            out.append(torch.cat([p[:c] for p, c in zip(parts, counts)]))
+            mine[: t.numel()] = t
+            got = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(got, mine, group=group)
+            full = torch.empty(n, dtype=t.dtype, device=t.device)
+            for k, st in enumerate(every):  # rank k's results lie stripe after stripe
+                o = 0
+                for first, count in st:
+                    full[first : first + count] = got[k][o : o + count]
+                    o += count
+            out.append(full)
         return tuple(out)
     return res

@@ -42,7 +42,7 @@ def _tensors(vol):
     return t
 
 
-def _worker(rank, world, port, mode, gather, out_dir):
+def _worker(rank, world, port, mode, gather, out_dir, piece_bytes=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,15 +54,14 @@ def _worker(rank, world, port, mode, gather, out_dir):
         mine = sdist.shard_frames(len(frames), rank, world)
         vol = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM, 143, _abi.SAF_SUM)
         _fuse(vol, [frames[i] for i in mine], seem=True)
-        first, count = sdist.merge_sums(_tensors(vol), mode=mode, gather=gather)
-        # local divide over the range this rank owns (the HIP path calls saf_merge_finalize here)
+        stripes = sdist.merge_sums(_tensors(vol), mode=mode, gather=gather, piece_bytes=piece_bytes)
+        # local divide over the stripes this rank owns (the HIP path calls saf_merge_finalize here)
         c = vol.c_volume()
         import ctypes as C
 
-        assert O.lib().saf_oracle_merge_finalize(C.byref(c), first, count) == 0
-        if gather and mode == "reduce_scatter":
-            pass  # gathered tensors are sums; finalize the rest too for comparison
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), first=first, count=count,
+        for first, count in stripes:
+            assert O.lib().saf_oracle_merge_finalize(C.byref(c), first, count) == 0
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), stripes=np.asarray(stripes, dtype=np.int64).reshape(-1, 2),
                  **{k: v.numpy() for k, v in _tensors(vol).items()})
     finally:
         dist.destroy_process_group()
@@ -86,10 +85,13 @@ def test_shard_frames_partitions():
     assert sdist.voxel_shard(315, 0, 2) == (0, 157) and sdist.voxel_shard(315, 1, 2) == (157, 158)
 
 
-@pytest.mark.parametrize("mode", ["reduce_scatter", "all_reduce"])
-def test_two_rank_merge_equals_single_process(tmp_path, oracle, mode):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), mode, False, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("mode,world,piece_bytes", [("reduce_scatter", 2, None), ("all_reduce", 2, None),
+                                                    # several pieces per tensor, a ragged last piece, a tail of < world rows:
+                                                    # the layout arithmetic of the striped in-place collectives at world 2, 4, 8
+                                                    ("reduce_scatter", 2, 143 * 4 * 20), ("reduce_scatter", 4, 143 * 4 * 24),
+                                                    ("reduce_scatter", 8, 143 * 4 * 32)])
+def test_merge_equals_single_process(tmp_path, oracle, mode, world, piece_bytes):
+    mp.spawn(_worker, args=(world, _free_port(), mode, False, str(tmp_path), piece_bytes), nprocs=world, join=True)
     grid = syn.make_grid(NVOX, side=1.2)
     frames, _ = _frames()
     ref = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM, 143)
@@ -98,19 +100,23 @@ def test_two_rank_merge_equals_single_process(tmp_path, oracle, mode):
     covered = np.zeros(n, dtype=np.int32)
     for r in range(world):
         g = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
-        first, count = int(g["first"]), int(g["count"])
+        stripes = [tuple(int(v) for v in st) for st in g["stripes"]]
         if mode == "all_reduce":
-            assert (first, count) == (0, n)
+            assert stripes == [(0, n)]
+        elif piece_bytes is None:  # one piece: the k-th of world equal parts, the remainder on the last rank
+            assert stripes == [sdist.voxel_shard(n, r, world)]
         else:
-            assert (first, count) == sdist.voxel_shard(n, r, world)
-        sl = slice(first, first + count)
-        covered[sl] += 1
-        assert np.array_equal(g["weight"][sl], ref.weight.numpy()[sl]), "merged valid counts differ"
-        assert np.array_equal(g["tsdf_weight"][sl], ref.tsdf_weight.numpy()[sl])
-        assert np.array_equal(g["labels_one_hot"][sl], ref.labels_one_hot.numpy()[sl])
-        np.testing.assert_allclose(g["clip_feat"][sl], ref.clip_feat.numpy()[sl], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(g["rgb"][sl], ref.rgb.numpy()[sl], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(g["tsdf"][sl], ref.tsdf.numpy()[sl], rtol=1e-4, atol=2e-6)
+            plan = sdist.stripe_plan(n, world, sdist.piece_rows_for(143 * 4, world, piece_bytes))
+            assert len(plan) >= 3 and stripes == sdist.stripes_of_rank(plan, r, world)
+        for first, count in stripes:
+            sl = slice(first, first + count)
+            covered[sl] += 1
+            assert np.array_equal(g["weight"][sl], ref.weight.numpy()[sl]), "merged valid counts differ"
+            assert np.array_equal(g["tsdf_weight"][sl], ref.tsdf_weight.numpy()[sl])
+            assert np.array_equal(g["labels_one_hot"][sl], ref.labels_one_hot.numpy()[sl])
+            np.testing.assert_allclose(g["clip_feat"][sl], ref.clip_feat.numpy()[sl], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(g["rgb"][sl], ref.rgb.numpy()[sl], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(g["tsdf"][sl], ref.tsdf.numpy()[sl], rtol=1e-4, atol=2e-6)
     expect = world if mode == "all_reduce" else 1
     assert (covered == expect).all(), "every voxel must be finalised by exactly the ranks that own it"
     assert int(ref.weight.sum()) > 0
@@ -131,7 +137,10 @@ def _query_worker(rank, world, port, out_dir, from_merge):
         frames, _ = _frames()
         vol = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM)
         _fuse(vol, frames, seem=False)
-        vol._shard_range = sdist.voxel_shard(vol.n, rank, world) if from_merge else None
+        if from_merge == "striped":  # the stripes a merge in several pieces leaves (5 pieces of 64 rows, a ragged last one)
+            vol._shard_stripes = sdist.stripes_of_rank(sdist.stripe_plan(vol.n, world, 32 * world), rank, world)
+        else:
+            vol._shard_stripes = [sdist.voxel_shard(vol.n, rank, world)] if from_merge else None
         text = torch.randn(Q_TEXT, DIM, generator=torch.Generator().manual_seed(5))
         text[3] = text[11]  # two queries with identical scores everywhere
         res = {}
@@ -145,9 +154,8 @@ def _query_worker(rank, world, port, out_dir, from_merge):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("from_merge", [False, True])
-def test_two_rank_sharded_query_equals_single_process(tmp_path, oracle, from_merge):
-    world = 2
+@pytest.mark.parametrize("from_merge,world", [(False, 2), (True, 2), ("striped", 2), ("striped", 4)])
+def test_sharded_query_equals_single_process(tmp_path, oracle, from_merge, world):
     mp.spawn(_query_worker, args=(world, _free_port(), str(tmp_path), from_merge), nprocs=world, join=True)
     grid = syn.make_grid(NVOX, side=1.2)
     frames, _ = _frames()
@@ -164,8 +172,13 @@ def test_two_rank_sharded_query_equals_single_process(tmp_path, oracle, from_mer
         # every rank ends with the same per-query answer as one scan over the whole volume (ties -> smaller voxel)
         assert np.array_equal(g["query_max_0"], qv.numpy()) and np.array_equal(g["query_max_1"], qr.numpy())
         assert np.array_equal(g["row_argmax_0"], ri.numpy()) and np.array_equal(g["row_argmax_1"], rv.numpy())
-        first, count = sdist.voxel_shard(ref.n, r, world)
-        np.testing.assert_allclose(g["vs_background_0"], vb.numpy()[first:first + count], rtol=1e-6, atol=1e-7)
+        if from_merge == "striped":
+            stripes = sdist.stripes_of_rank(sdist.stripe_plan(ref.n, world, 32 * world), r, world)
+            assert len(stripes) >= 3
+        else:
+            stripes = [sdist.voxel_shard(ref.n, r, world)]
+        want = np.concatenate([vb.numpy()[f:f + c] for f, c in stripes])
+        np.testing.assert_allclose(g["vs_background_0"], want, rtol=1e-6, atol=1e-7)
 
 
 def _gather_worker(rank, world, port, out_dir):
@@ -210,7 +223,7 @@ def test_balanced_planes_partition_the_grid():
     assert sdist.slab_planes_of_rank(33, 1, 3).tolist() == list(range(11, 22))  # no blocks of 16: the contiguous slab
 
 
-def _slab_merge_worker(rank, world, port, out):
+def _slab_merge_worker(rank, world, port, out, piece_bytes=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -226,7 +239,7 @@ def _slab_merge_worker(rank, world, port, out):
         assert why is None, why
         stripes = []
         for x0, cnt in sdist.slab_bounds(7, 3):
-            stripes.append(sdist.merge_slab_sums(mine, x0 * 15, cnt * 15))
+            stripes += sdist.merge_slab_sums(mine, x0 * 15, cnt * 15, piece_bytes=piece_bytes)
         covered = torch.zeros(n_rows, dtype=torch.int32)
         for f, c in stripes:
             assert torch.equal(mine["weight"][f:f + c], total["weight"][f:f + c])
@@ -240,16 +253,17 @@ def _slab_merge_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_slab_wise_merge_leaves_every_rank_its_part_of_every_slab():
-    """The slab-pipelined merge (distributed.fuse_merge_pipelined): each slab's rows are reduce-scattered on their own; rank k
-    must end with the exact sums of the k-th part of every slab, and the ranks' stripes must tile the volume."""
-    world = 2
+@pytest.mark.parametrize("world,piece_bytes", [(2, None), (4, 6 * 4 * 8), (8, 6 * 4 * 8)])
+def test_slab_wise_merge_leaves_every_rank_its_part_of_every_slab(world, piece_bytes):
+    """The slab-pipelined merge (distributed.fuse_merge_pipelined): each slab's rows are reduce-scattered on their own, piece
+    by piece and in place; rank k must end with the exact sums of the k-th part of every piece of every slab, and the ranks'
+    stripes must tile the volume."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_slab_merge_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_slab_merge_worker, args=(world, port, out, piece_bytes), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world))
 
 
@@ -260,3 +274,60 @@ def test_slab_bounds_tile_the_x_axis():
         assert all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
         if nx % 16 == 0 and nx // 16 >= s:
             assert all(x % 16 == 0 and c % 16 == 0 for x, c in b)
+
+
+def test_stripe_plan_tiles_and_ramp():
+    """The layout arithmetic by itself: stripes of all ranks tile the rows exactly once for every world size and piece size;
+    ramped slabs are small at both ends, aligned, and tile the x axis."""
+    for n, world, piece in ((1000, 8, 64), (1000, 8, 8), (7, 8, 8), (4096, 4, 1024), (315, 2, 40), (16777216, 8, 2097152)):
+        plan = sdist.stripe_plan(n, world, piece, row0=11)
+        assert plan[0][0] == 11 and sum(r for _, r, _ in plan) == n
+        seen = []
+        for k in range(world):
+            for f, c in sdist.stripes_of_rank(plan, k, world):
+                assert c > 0
+                seen.append((f, c))
+        seen.sort()
+        assert seen[0][0] == 11 and all(seen[i][0] + seen[i][1] == seen[i + 1][0] for i in range(len(seen) - 1))
+        assert seen[-1][0] + seen[-1][1] == 11 + n
+    assert sdist.piece_rows_for(2048, 8) == (4 << 30) // 2048 and sdist.piece_rows_for(1 << 40, 8) == 8
+    b = sdist.slab_bounds(256, 8, ramp=True)
+    assert [c for _, c in b] == [16, 32, 32, 48, 48, 32, 32, 16] and b[0][0] == 0 and sum(c for _, c in b) == 256
+    for nx, k in ((256, 8), (128, 8), (64, 4), (48, 3), (33, 5), (16, 8), (255, 8)):
+        b = sdist.slab_bounds(nx, k, ramp=True)
+        assert b[0][0] == 0 and sum(c for _, c in b) == nx and all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+        assert all(c > 0 for _, c in b) and b[0][1] <= max(c for _, c in b) and b[-1][1] <= max(c for _, c in b)
+
+
+def _gather_shards_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 157
+
+        class Vol:  # the attributes gather_shards reads
+            pass
+
+        v = Vol()
+        full = {"clip_feat": torch.arange(n * 3, dtype=torch.float32).view(n, 3), "tsdf": torch.arange(n, dtype=torch.float32) * 0.5,
+                "weight": torch.arange(n, dtype=torch.int32)}
+        plan = sdist.stripe_plan(n, world, 8 * world)
+        mine = sdist.stripes_of_rank(plan, rank, world)
+        for k, t in full.items():
+            x = torch.full_like(t, -1)  # rows a rank does not own hold garbage
+            for f, c in mine:
+                x[f:f + c] = t[f:f + c]
+            setattr(v, k, x)
+        v._shard_stripes = mine
+        assert sdist.gather_shards(v) == [(0, n)] and v._shard_stripes is None
+        out[rank] = all(torch.equal(getattr(v, k), t) for k, t in full.items())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_shards_makes_a_striped_volume_whole(world):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_shards_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world))

@@ -1013,6 +1013,65 @@ def test_deferred_window_queue_is_invisible(oracle, seem, fdt):
     assert que.pending_frames == 0 and int(que.weight.sum()) == 0
 
 
+def test_failed_flush_never_stages_past_the_ring_and_never_fuses_twice():
+    """a flush that fails BEFORE any launch keeps its frames queued -- and a full ring then refuses
+    further frames instead of staging into slot 512 (a device write past the ring); a flush that fails AFTER
+    saf_fuse_frames has launched poisons the volume (re-fusing would count the frames twice) until reset()."""
+    from spatially_aware_ai_amd import ClipFusion
+    from spatially_aware_ai_amd._lib import SafError
+
+    w, h, dim, nvox = 64, 48, 256, (16, 16, 64)
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid(nvox)
+    f = syn.make_frames(5, 1, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="B")[0]
+    fus = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, FakeClip(dim), None, 10, 10,
+                     keep_xyz_world=False).cuda()
+    args = [f[k].cuda() for k in ("depth", "rgb", "pose", "K")]
+    feat = f["feat"].cuda()
+    real = fus._fuse_now
+    calls = []
+
+    def failing_before_launch(*a, **k):
+        calls.append(len(a[0]))
+        raise RuntimeError("backbone out of memory")
+
+    fus._fuse_now = failing_before_launch
+    n_ring = fus._QUEUE_FRAMES
+    raised = 0
+    for _ in range(n_ring + 5):  # every completed window tries to flush, fails, and keeps its frames
+        try:
+            fus.integrate_features(*args, feat)
+        except RuntimeError as e:
+            assert "out of memory" in str(e)
+            raised += 1
+    assert raised >= 5 and fus.pending_frames == n_ring, "the failed flush must keep exactly the ring's frames"
+    with pytest.raises(RuntimeError, match="out of memory"):
+        fus.integrate_features(*args, feat)  # full ring: flushes again (raises), stages nothing
+    assert fus.pending_frames == n_ring
+    fus._fuse_now = real
+    assert int(fus.weight.max()) == n_ring, "once the flush works the queued frames are fused exactly once"
+    # a failure after the launch
+    fus.reset()
+    fus.integrate_features(*args, feat)
+
+    def failing_after_launch(*a, **k):
+        real(*a, **k)
+        raise RuntimeError("device lost")
+
+    fus._fuse_now = failing_after_launch
+    with pytest.raises(RuntimeError, match="device lost"):
+        fus.flush()
+    fus._fuse_now = real
+    assert fus.pending_frames == 0
+    with pytest.raises(SafError, match="incomplete"):
+        fus.weight
+    with pytest.raises(SafError, match="incomplete"):
+        fus.integrate_features(*args, feat)
+        fus.flush()
+    fus.reset()
+    assert int(fus.weight.sum()) == 0
+
+
 # ---- wide scan with fused epilogues (saf_query_scan_wide_ex; BASELINE config 5) ----
 @pytest.mark.parametrize("dt,dim,out_dt,n,q", [
     (torch.float16, 512, torch.float16, 1000, 203), (torch.bfloat16, 512, torch.bfloat16, 777, 64),

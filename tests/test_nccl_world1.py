@@ -1,8 +1,10 @@
 """RCCL has to execute the collectives of the merge at least once on the hardware the tests see: one GPU.  A child process
-brings up backend ``nccl`` with world_size 1 and drives the nccl-only branches of distributed.py (staged, chunked
-reduce-scatter / all-gather into the volume, the frame exchange) with the ``world == 1`` early return of ``merge_sums``
-bypassed; with one rank every sum is the identity, so the tensors must come back unchanged -- what is tested is that torch's
-and RCCL's argument checks accept the calls (in-place views, staging shapes, several pieces, a remainder tail)."""
+brings up backend ``nccl`` with world_size 1 and drives the collectives of distributed.py (the striped IN-PLACE
+reduce-scatter / all-gather into the volume, piece by piece; the staged frame exchange) with the ``world == 1`` early return
+of ``merge_sums`` bypassed; with one rank every sum is the identity, so the tensors must come back unchanged -- what is
+tested is that torch's and RCCL's argument checks accept the calls (output aliasing its input's slice, several pieces, a
+ragged last piece).  The layout arithmetic itself is tested at world 2, 4 and 8 under gloo (tests/test_distributed_cpu.py:
+the same calls -- gloo implements reduce_scatter_tensor / all_gather_into_tensor)."""
 import os
 import subprocess
 import sys
@@ -29,9 +31,10 @@ _CHILD = textwrap.dedent('''
         if shape == (130, 143):
             t = torch.randint(0, 9, shape, generator=g, device=dev, dtype=torch.int32)
         ref = t.clone()
-        sd._reduce_scatter_rows(t, None, 0, 1)
+        plan = sd.stripe_plan(t.shape[0], 1, 61)   # many pieces, a ragged last one
+        sd._reduce_scatter_striped(t, plan, None, 0, 1)
         assert torch.equal(t, ref), ("reduce-scatter changed a one-rank tensor", shape)
-        sd._all_gather_rows(t, None, 0, 1)
+        sd._all_gather_striped(t, plan, None, 0, 1)
         assert torch.equal(t, ref), ("all-gather changed a one-rank tensor", shape)
     fr = [torch.randn((9, 16, 12), generator=g, device=dev), None, torch.randn((9, 4, 4), generator=g, device=dev)]
     out = sd.gather_frames(fr)

@@ -1,0 +1,96 @@
+"""GPU parity of the ORDER-FREE form of the window's row kernel (csrc/saf_window.hip, `fuse_window_kernel<.., OF = true>`,
+SAF_WIN_FORM=sums): a row's samples of one window are summed in registers and the row is blended once,
+(w0 old + sum) / (w0 + k) -- the running mean of clipfusion.py:715-721 with the window's k updates folded into one.
+
+Bar (SURVEY section 7 / VERDICT round 3 item 1b): which voxels are touched, weights, tsdf, rgb, label counts and the kernels'
+counters EXACTLY as the frame-after-frame path; feature values within 1e-4 (of the row's largest magnitude) of the oracle's
+fp32 running mean and within 5e-6 of the sequential device path; reproducible bit for bit from run to run (the hits of a
+row are added in a fixed (frame, lane) order)."""
+import pytest
+import torch
+
+from spatially_aware_ai_amd import _abi
+from spatially_aware_ai_amd import synthetic as syn
+
+from test_brick_form import EXACT, _build, _feat_close, _frames, _fuse
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # nvox, D, seem, accum, frames, dtype, depth, camera at rest
+    ((33, 30, 41), 512, True, _abi.SAF_RUNNING_MEAN, 40, torch.float32, "B", None),
+    ((33, 30, 41), 256, False, _abi.SAF_SUM, 150, torch.float32, "B", (11, 112)),       # two windows, rows with > 64 hits: passes
+    ((64, 64, 64), 256, False, _abi.SAF_RUNNING_MEAN, 75, torch.float32, "A", None),
+    ((32, 16, 128), 1024, True, _abi.SAF_RUNNING_MEAN, 17, torch.float32, "A", None),   # four pieces per row
+    ((31, 26, 29), 768, False, _abi.SAF_RUNNING_MEAN, 33, torch.float32, "B", None),    # three pieces per row; ragged grid
+    ((31, 26, 29), 512, True, _abi.SAF_RUNNING_MEAN, 300, torch.float32, "A", (40, 100)),  # three windows: rows written, then read
+    ((29, 33, 27), 512, False, _abi.SAF_SUM, 20, torch.float32, "B", None),
+    ((61, 60, 59), 512, True, _abi.SAF_RUNNING_MEAN, 48, torch.float32, "B", None),     # a grid size of the reference (voxel_grid_compare.md)
+    ((33, 30, 41), 512, True, _abi.SAF_RUNNING_MEAN, 36, torch.bfloat16, "B", None),
+    ((40, 24, 56), 1024, False, _abi.SAF_RUNNING_MEAN, 131, torch.bfloat16, "A", (3, 90)),
+    ((16, 16, 64), 512, False, _abi.SAF_RUNNING_MEAN, 260, torch.bfloat16, "B", (0, 260)),  # a camera at rest: weights up to 260
+]
+
+
+@pytest.mark.parametrize("nvox,dim,seem,accum,n_frames,fdt,kind,rest", CASES)
+def test_sums_form_against_the_sequential_path_and_the_oracle(oracle, monkeypatch, nvox, dim, seem, accum, n_frames, fdt, kind, rest):
+    grid = syn.make_grid(nvox, side=2.56 * nvox[0] / max(nvox))
+    frames = _frames(9000 + dim + n_frames, n_frames, dim, kind, rest=rest)
+    # the sequential reference: calls of 7 frames take the per-frame pipeline (bit-identical to frame after frame)
+    one = _fuse(_build(grid, dim, seem, accum, fdt, defer=False), frames, seem, per_call=7)
+    monkeypatch.setenv("SAF_WIN_FORM", "sums")
+    win = _fuse(_build(grid, dim, seem, accum, fdt), frames, seem)
+    s1, s2 = one.stats(), win.stats()
+    assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0, "the windowed path did not run"
+    s1.pop("window_tsdf_voxels"), s2.pop("window_tsdf_voxels")
+    assert s1 == s2, (s1, s2)
+    for name in EXACT + (("labels_one_hot",) if seem else ()):
+        assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs from the sequential path"
+    # bf16: the sequential path (and the oracle's bf16 mode) round to bf16 after EVERY hit, this form once per window -- it is
+    # compared with the fp32 oracle within a handful of bf16 roundings (2^-8 each); per-hit rounding is no closer
+    tol = 8 * 2.0 ** -8 if fdt == torch.bfloat16 else 1e-4
+    vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, dim, 143 if seem else 0, accum)
+    cat = lambda k: torch.cat([f[k] for f in frames])
+    vol.integrate(cat("depth"), cat("rgb"), cat("pose"), cat("K"), cat("feat"),
+                  [f["labels"].float() for f in frames] if seem else None, rgb_bilinear=seem)
+    assert torch.equal(win.weight.cpu(), vol.weight) and torch.equal(win.tsdf_weight.cpu(), vol.tsdf_weight)
+    _feat_close(win.clip_feat, vol.clip_feat, tol, "clip_feat vs the oracle")
+    if fdt == torch.float32:
+        _feat_close(win.clip_feat, one.clip_feat, 5e-6, "clip_feat vs the sequential device path")
+    again = _fuse(_build(grid, dim, seem, accum, fdt), frames, seem)
+    assert torch.equal(again.clip_feat, win.clip_feat), "two runs of the order-free form differ"
+
+
+@pytest.mark.parametrize("env", [{"SAF_WIN_OVERLAP": "0"}, {"SAF_WIN_FRAMES": "64"}, {"SAF_WIN_XCD": "0"}])
+def test_sums_form_schedules_agree(env, monkeypatch):
+    """Stream overlap, window length and unit order change the schedule, not the sums of a window... except the window
+    length, which changes which samples are folded together: that one is compared at 5e-6 instead of bit for bit."""
+    nvox, dim, n_frames = (32, 32, 64), 512, 140
+    grid = syn.make_grid(nvox)
+    frames = _frames(4242, n_frames, dim, "B")
+    monkeypatch.setenv("SAF_WIN_FORM", "sums")
+    base = _fuse(_build(grid, dim, False, _abi.SAF_RUNNING_MEAN, torch.float32), frames, False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = _fuse(_build(grid, dim, False, _abi.SAF_RUNNING_MEAN, torch.float32), frames, False)
+    for name in EXACT:
+        assert torch.equal(getattr(base, name), getattr(other, name)), name
+    if "SAF_WIN_FRAMES" in env:
+        _feat_close(other.clip_feat, base.clip_feat, 5e-6, "64- vs 128-frame windows")
+    else:
+        assert torch.equal(other.clip_feat, base.clip_feat)
+
+
+def test_sums_form_nan_inf_in_the_maps_reach_exactly_the_rows_they_reach_frame_after_frame(monkeypatch):
+    nvox, dim, n_frames = (24, 20, 64), 256, 40
+    grid = syn.make_grid(nvox)
+    frames = _frames(77, n_frames, dim, "B")
+    frames[5]["feat"][0, 3, 1, 2] = float("nan")
+    frames[9]["feat"][0, 100, 2, 3] = float("inf")
+    one = _fuse(_build(grid, dim, False, _abi.SAF_RUNNING_MEAN, torch.float32, defer=False), frames, False, per_call=7)
+    monkeypatch.setenv("SAF_WIN_FORM", "sums")
+    win = _fuse(_build(grid, dim, False, _abi.SAF_RUNNING_MEAN, torch.float32), frames, False)
+    a, b = one.clip_feat, win.clip_feat
+    assert torch.equal(torch.isnan(a), torch.isnan(b)), "NaN reaches other elements"
+    assert torch.equal(torch.isinf(a), torch.isinf(b)) and torch.equal(a[torch.isinf(a)], b[torch.isinf(b)])
+    assert int(torch.isnan(a).sum()) > 0 and int(torch.isinf(a).sum()) > 0

@@ -1,0 +1,133 @@
+// gather_probe.hip -- what the L2 -> L1 path of an MI355X delivers for the row kernel's OWN access shape
+// (VERDICT round 3, item 1a): rows of ROWB bytes (2 KiB = the 512 fp32 channels of one map position) gathered from a
+// table that fits the XCDs' L2s, `buffer_load_dwordx4` (64 lanes x 16 B = one 1 KiB piece per wave instruction), NB
+// pieces in flight per wave, 8 / 12 / 16 waves per CU, results discarded.  The ceiling quoted in DESIGN.md section 4.6 so
+// far was borrowed from MI355X_MICROARCH.md (1152-byte rows, one 256-thread workgroup per CU: 16.8-18.8 TB/s, "lower
+// bound"); this measures it for the shape fuse_window_kernel has.
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/gather_probe.hip -o gpurun_out/gather_probe && gpurun_out/gather_probe
+//
+// Output: one line per (table bytes, waves per CU, pieces in flight): TB/s chip-wide of gathered bytes.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                                   \
+  do {                                                                                          \
+    hipError_t e_ = (x);                                                                        \
+    if (e_ != hipSuccess) {                                                                     \
+      fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));         \
+      exit(1);                                                                                  \
+    }                                                                                           \
+  } while (0)
+
+typedef unsigned int v4u __attribute__((vector_size(16)));
+
+// One wave gathers `iters` batches of NB pieces.  A ROW is PPR consecutive pieces (PPR = 2: 2 KiB); a batch is NB / PPR
+// random rows (wave-uniform row index from a scalar LCG, as the row kernel's tap rows are wave-uniform).
+// MODE 0: buffer loads through a descriptor (the row kernel's taps); MODE 1: global_load_dwordx4; MODE 2: nontemporal global.
+template <int NB, int PPR, int MODE>
+__global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ table, uint32_t n_rows, uint32_t table_bytes,
+                                                     int iters, uint32_t seed, float* __restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+  uint32_t s = seed ^ (wave_id * 2654435761u);
+  s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(table), 0, (int)table_bytes, 0x00020000);
+  float acc = 0.0f;
+  for (int it = 0; it < iters; ++it) {
+    float4 t[NB];
+#pragma unroll
+    for (int r = 0; r < NB / PPR; ++r) {
+      s = s * 1664525u + 1013904223u;
+      const uint32_t row = (uint32_t)(((uint64_t)(s >> 4) * n_rows) >> 28);  // uniform in [0, n_rows)
+#pragma unroll
+      for (int p = 0; p < PPR; ++p) {
+        const uint32_t off = (row * (uint32_t)PPR + (uint32_t)p) * 1024u + (uint32_t)lane * 16u;
+        if (MODE == 0) {
+          const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+          t[r * PPR + p] = __builtin_bit_cast(float4, v);
+        } else if (MODE == 1) {
+          t[r * PPR + p] = table[off / 16u];
+        } else {
+          typedef float v4f __attribute__((vector_size(16)));
+          const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(table) + off / 16u);
+          t[r * PPR + p] = __builtin_bit_cast(float4, v);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) asm volatile("" ::"v"(t[k].x), "v"(t[k].y), "v"(t[k].z), "v"(t[k].w));
+    acc += t[0].x;
+  }
+  if (acc == 12345.678f) sink[0] = acc;  // never true: keeps the loop alive without a store
+}
+
+using Fn = void (*)(const float4*, uint32_t, uint32_t, int, uint32_t, float*);
+
+struct Variant {
+  const char* name;
+  Fn fn;
+  int nb, ppr;
+};
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  printf("# device %s, %d CUs, clock %d MHz\n", prop.name, cus, prop.clockRate / 1000);
+  const size_t max_table = 64u << 20;
+  float4* table;
+  float* sink;
+  CK(hipMalloc(&table, max_table));
+  CK(hipMalloc(&sink, 64));
+  CK(hipMemset(table, 0, max_table));
+  const Variant vars[] = {
+      {"buffer_load x 8 pieces (2 KiB rows)", gather_kernel<8, 2, 0>, 8, 2},
+      {"buffer_load x 16 pieces (2 KiB rows: the row kernel's 2 tap groups)", gather_kernel<16, 2, 0>, 16, 2},
+      {"buffer_load x 32 pieces (2 KiB rows)", gather_kernel<32, 2, 0>, 32, 2},
+      {"global_load x 16 pieces (2 KiB rows)", gather_kernel<16, 2, 1>, 16, 2},
+      {"global_load nt x 16 pieces (2 KiB rows)", gather_kernel<16, 2, 2>, 16, 2},
+      {"buffer_load x 16 pieces (1 KiB rows)", gather_kernel<16, 1, 0>, 16, 1},
+      {"buffer_load x 16 pieces (4 KiB rows)", gather_kernel<16, 4, 0>, 16, 4},
+  };
+  const size_t tables[] = {256u << 10, 1u << 20, 2u << 20, 3u << 20, 4u << 20, 9437184u /* 128 maps of 36 x 2 KiB */, 32u << 20};
+  const int wpcs[] = {4, 8, 12, 16};
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (const Variant& v : vars) {
+    for (size_t tb : tables) {
+      for (int wpc : wpcs) {
+        const uint32_t row_bytes = 1024u * (uint32_t)v.ppr;
+        const uint32_t n_rows = (uint32_t)(tb / row_bytes);
+        const int grid = cus * wpc / 4;
+        // ~ 24 GB gathered per launch
+        const double bytes_per_iter = (double)grid * 4 * v.nb * 1024.0;
+        int iters = (int)(24e9 / bytes_per_iter);
+        if (iters < 4) iters = 4;
+        hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, 0, table, n_rows, (uint32_t)tb, iters / 4, 1u, sink);  // warm
+        CK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+          CK(hipEventRecord(e0, 0));
+          hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, 0, table, n_rows, (uint32_t)tb, iters, 7u + rep, sink);
+          CK(hipEventRecord(e1, 0));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (ms < best) best = ms;
+        }
+        const double gb = bytes_per_iter * iters / 1e9;
+        printf("%-70s table %8.2f MB  waves/CU %2d  %7.3f ms  %6.2f TB/s  (%5.1f GB/s per CU)\n", v.name, tb / 1048576.0, wpc, best,
+               gb / best, gb / best * 1000.0 / cus);
+        fflush(stdout);
+      }
+    }
+  }
+  return 0;
+}
