@@ -461,7 +461,10 @@ def main():
             sweep_bytes = nt_per * 16 + a.height * a.width * 4 + nv_per * 4
             frame_bytes = (nv_per * (2 * a.dim * esz + 32 + lab) + nt_per * 16 + a.height * a.width * (16 + (4 if a.labels else 0))
                            + a.dim * npy * npx * 4)
-        avg_fuse_s = ms["fuse"][0] / n_launch * 1e-3
+        # windowed: fuse_bytes are those of ONE WINDOW, and a window's row kernel may run as several launches (the first window
+        # of a call is fused slab by slab so that its classification hides behind its own rows): the time that goes with
+        # those bytes is the SUM of the window's launches = total kernel time / windows
+        avg_fuse_s = ms["fuse"][0] / (n_windows if windowed else n_launch) * 1e-3
         achieved = fuse_bytes / avg_fuse_s / 1e9
         # HBM traffic of this kernel: PMC counters cannot be read from inside this process, so the figure comes
         # from the committed rocprofv3 --pmc passes of this same command (tools/profile.sh, newest round first)
@@ -486,7 +489,8 @@ def main():
             "volume_state": "fresh (every step starts from a zeroed volume: a row is not read in the window that first "
                             "touches it, but its bytes are counted as algorithmic)",
             "algorithmic_bytes_per_launch": int(fuse_bytes), "avg_launch_us": round(avg_fuse_s * 1e6, 2),
-            "launches": int(n_launch), "valid_voxels_per_frame": round(nv_per, 1),
+            "launches": int(n_launch), "windows": int(n_windows) if windowed else None,
+            "valid_voxels_per_frame": round(nv_per, 1),
             "tsdf_voxels_per_frame": round(nt_per, 1),
         }
         if windowed:
@@ -520,11 +524,17 @@ def main():
                                   "MI355X_MICROARCH.md, gathers of L2-resident rows"}
             except Exception:
                 pass
+            form = os.environ.get("SAF_WIN_FORM", "sums")
+            roofline["form"] = form
             roofline["note"] = ("voxel-major window kernel: reads and writes every touched feature row once per window of %d " % WIN +
-                                "frames (hits applied in frame order: bit-identical to frame-by-frame fusion); the NEXT window's "
-                                "classification + TSDF (classify kernels, kernel_breakdown.sweep_us per 32 frames) run beside it on "
-                                "a second stream, so this launch duration is that of a kernel sharing the chip: `isolated` is the "
-                                "same kernel alone")
+                                ("frames (order-free form: a row's samples of the window are summed in registers and blended once -- "
+                                 "feature values within fp32 rounding of frame-by-frame fusion, everything else bit-identical)"
+                                 if form[0] == "s" else "frames (hits applied in frame order: bit-identical to frame-by-frame fusion)") +
+                                "; `avg_launch_us` = the row kernel's time per WINDOW (the first window of a call runs as four slab "
+                                "launches, so that its classification hides behind its own rows: `launches` / `windows`); the NEXT "
+                                "unit's classification + TSDF (classify kernels, kernel_breakdown.sweep_us per launch of 32 frames) "
+                                "run beside it on a second stream, so this duration is that of a kernel sharing the chip: `isolated` "
+                                "is the same kernel alone")
         breakdown = {
             "prep_us": round(ms["prep"][0] / max(1, ms["prep"][1]) * 1e3, 2),
             "sweep_us": round(ms["sweep"][0] / max(1, ms["sweep"][1]) * 1e3, 2),
@@ -575,7 +585,7 @@ def main():
             nwin = (a.frames + WIN - 1) // WIN
             wb = (st3["window_rows"] / nwin * (2 * a.dim * esz + 2 * 12 + 2 * 4 + lab)
                   + a.frames / nwin * (a.height * a.width * (12 + (4 if a.labels else 0)) + a.dim * npy * npx * 4))
-            ws_ = tot.value / n.value * 1e-3
+            ws_ = tot.value / nwin * 1e-3  # (per window: the first window runs as several launches)
             roofline["warm_volume"] = {"avg_launch_us": round(ws_ * 1e6, 2), "achieved": round(wb / ws_ / 1e9, 1),
                                        "frac": round(wb / ws_ / 1e9 / HBM_PEAK_GBS, 4), "launches": int(n.value),
                                        "algorithmic_bytes_per_launch": int(wb),
@@ -660,7 +670,9 @@ def main():
     slabwise = None
     if rank == 0 and world == 1 and windowed_headline(st) and not a.no_side:
         n_slabs = 8
-        bounds = sdist.slab_bounds(int(grid.nvox[0]), n_slabs)
+        bounds = sdist.slab_bounds(int(grid.nvox[0]), n_slabs, ramp=True)
+        x0s = (C.c_int32 * len(bounds))(*[b[0] for b in bounds])
+        nxs = (C.c_int32 * len(bounds))(*[b[1] for b in bounds])
 
         def whole():
             fusion.reset()
@@ -670,10 +682,9 @@ def main():
         def by_slab():
             fusion.reset()
             fusion.flush()
-            for x0, cnt in bounds:
-                vol = sdist.slab_descriptor(fusion, x0, cnt)
-                check(L.saf_fuse_frames_profiled(C.byref(vol), frames, a.frames, ws.data_ptr(), ws.numel(), stats_ptr, None, stream),
-                      "slab-wise fuse")
+            vol = fusion._c_volume(for_fuse=True)
+            check(L.saf_fuse_frames_slabs(C.byref(vol), frames, a.frames, x0s, nxs, len(bounds), None, ws.data_ptr(), ws.numel(),
+                                          stats_ptr, None, stream), "slab-wise fuse")
 
         def timed2(fn):
             fn()
@@ -688,8 +699,10 @@ def main():
         fusion.fuse_stats.zero_()
         slabwise = {"slabs": len(bounds), "ms_whole_volume": round(t_whole * 1e3, 2), "ms_slab_by_slab": round(t_slab * 1e3, 2),
                     "ratio": round(t_slab / t_whole, 3),
-                    "note": "the rank's 512 frames fused into x-slabs of the ONE per-rank volume, one saf_fuse_frames call per slab "
-                            "(up-front clear in both): between two such calls the N > 1 job starts the finished slab's reduce-scatter"}
+                    "planes_per_slab": [b[1] for b in bounds],
+                    "note": "the rank's 512 frames fused into x-slabs of the ONE per-rank volume by saf_fuse_frames_slabs (one call: a "
+                            "slab's first window is classified beside the last row kernel of the slab before it; small slabs at both "
+                            "ends; up-front clear in both): behind every slab's event the N > 1 job starts that slab's reduce-scatter"}
 
     # ---- the other configurations and the copy rate of this box, measured in this run (rank 0, N = 1) ----
     side, copy_rate = None, None
@@ -836,15 +849,15 @@ def side_workloads(a, device, L, frames_A, npy, npx):
         uv = st["window_rows"] / n_win
         fuse_bytes = (uv * (2 * a.dim * esz + 2 * 12 + 2 * 4 + lab)
                       + n_frames / n_win * (a.height * a.width * (12 + (4 if labels else 0)) + a.dim * npy * npx * 4))
-        kern = tot.value / max(1, n.value) * 1e-3
+        kern = tot.value / max(1, n_win) * 1e-3  # per WINDOW (its first window runs as several slab launches)
         out[name] = {
             "value": round(n_frames / dt, 1), "unit": "frames/s", "ms_per_job": round(dt * 1e3, 2), "frames": n_frames,
             "workload": note, "valid_voxels_per_frame": round(st["valid"] / n_frames, 1),
             "hits_per_row": round(st["valid"] / max(1, st["window_rows"]), 2),
-            "roofline": {"kernel": "fuse_window_kernel" if os.environ.get("SAF_WIN_FORM", "r")[0] != "b" else "fuse_brick_kernel",
+            "roofline": {"kernel": "fuse_window_kernel" if os.environ.get("SAF_WIN_FORM", "s")[0] != "b" else "fuse_brick_kernel",
                          "bound": "hbm", "achieved": round(fuse_bytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(fuse_bytes / kern / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "avg_launch_us": round(kern * 1e6, 1), "launches": int(n.value),
+                         "avg_launch_us": round(kern * 1e6, 1), "launches": int(n.value), "windows": int(n_win),
                          "algorithmic_bytes_per_launch": int(fuse_bytes)}}
         del fz, ws, keep
         torch.cuda.empty_cache()

@@ -183,6 +183,18 @@ int saf_fuse_frames_profiled(const saf_volume* vol, const saf_frame* frames, int
                              void* workspace, size_t workspace_bytes, uint64_t* stats,
                              saf_profiler* profiler, void* stream);
 
+/* saf_fuse_frames slab by slab (new capability: the frame-sharded multi-GPU job with its merge pipelined behind the fusion,
+ * SURVEY 8e): EVERY frame is fused into x-planes [slab_x0[k], slab_x0[k] + slab_nx[k]) of the volume for k = 0 .. n_slabs - 1
+ * in turn -- a slab of x-planes is a contiguous range of the flat voxel index and every decision is that of the full volume's
+ * voxels (clipfusion.py:617-622: the same axis table), so the slabs together equal saf_fuse_frames bit for bit; a finished
+ * slab is never touched again.  slab_done_events (may be NULL, entries may be NULL): hipEvent_t handles, event k is recorded
+ * on `stream` behind the last kernel that writes slab k -- the caller's reduce-scatter of that slab waits for it on its own
+ * stream.  One call: the first window of slab k + 1 is classified beside the last row kernel of slab k.  Slabs must not
+ * overlap; multiples of 16 x-planes keep the fast unit orders.  profiler may be NULL. */
+int saf_fuse_frames_slabs(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, const int32_t* slab_x0,
+                          const int32_t* slab_nx, int32_t n_slabs, void* const* slab_done_events, void* workspace,
+                          size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream);
+
 /*
  * Depth un-projection of a lattice of pixels to world points: the per-frame body of
  * backproject_pcd (clipfusion.py:541-565) with get_pix_vecs (:497-507) folded in.

@@ -79,6 +79,11 @@ PROTOTYPES = {
     ),
     "saf_poll_async_error": (C.c_int, []),
     "saf_stage_frame": (C.c_int, [C.POINTER(SafFrame), C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.POINTER(SafFrame), _fp]),
+    "saf_fuse_frames_slabs": (
+        C.c_int,
+        [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+         C.POINTER(C.c_void_p), _fp, C.c_size_t, _fp, C.c_void_p, C.c_void_p],
+    ),
     "saf_fuse_path": (C.c_int, [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, C.c_size_t]),
     "saf_clear_unwritten_rows": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_profiler_create": (_fp, [C.c_int32]),

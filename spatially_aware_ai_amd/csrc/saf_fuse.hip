@@ -938,21 +938,31 @@ int poll_latch() {
 // Everything is ordered after what the caller already queued on `s` (fork event), and complete,
 // as far as `s` is concerned, when the last fuse kernel is (it has waited for every sweep).
 int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
-              uint64_t* stats, saf_profiler* prof, hipStream_t s) {
+              uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinSlabs* slabs = nullptr) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
   if (window_ok(kv, frames, n_frames, workspace_bytes)) {
     // SAF_WIN_OVERLAP=0: every kernel of the windowed path on the caller's stream (read per call: same-process A/Bs)
+    // (a call of one window overlaps too: its first window is classified slab by slab beside its own row kernels)
     const char* ov_env = getenv("SAF_WIN_OVERLAP");
-    PipeRes* pr = (ov_env && ov_env[0] == '0') || n_frames <= window_frames() ? nullptr : pipe_acquire();
-    if (!pr) return fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, nullptr);
+    PipeRes* pr = (ov_env && ov_env[0] == '0') ? nullptr : pipe_acquire();
+    if (!pr) return fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, nullptr, slabs);
     WinOverlap ov;
     ov.aux = pr->aux; ov.fork = pr->fork; ov.join = pr->join;
     ov.cls_done[0] = pr->fused[0]; ov.cls_done[1] = pr->fused[1]; ov.fuse_done[0] = pr->fused[2]; ov.fuse_done[1] = pr->fused[3];
-    rc = fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, &ov);
+    rc = fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, &ov, slabs);
     pipe_release(pr);
     return rc;
+  }
+  if (slabs && slabs->n > 0) {  // the per-frame pipeline, slab after slab (every (slab, frame) pair counts as a frame in stats[2])
+    for (int k = 0; k < slabs->n; ++k) {
+      if (slabs->x0[k] < 0 || slabs->nx[k] <= 0 || slabs->x0[k] + slabs->nx[k] > kv.nx) return fail(SAF_E_INVALID, "slab %d outside the volume", k);
+      if ((rc = fuse_many(slab_kvol(kv, slabs->x0[k], slabs->nx[k]), frames, n_frames, workspace, workspace_bytes, stats, prof, s))) return rc;
+      if (slabs->done && slabs->done[k] && hipEventRecord(static_cast<hipEvent_t>(slabs->done[k]), s) != hipSuccess)
+        return fail(SAF_E_HIP, "hipEventRecord(slab done)");
+    }
+    return SAF_OK;
   }
   // counters and the completion counter start at zero; afterwards every sweep zeroes its successor's set
   if (hipMemsetAsync(ws, 0, kHdrBytes, s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
@@ -1033,6 +1043,21 @@ int saf_fuse_frames_profiled(const saf_volume* vol, const saf_frame* frames, int
   if ((rc = poll_latch())) return rc;
   ensure_latch();
   return fuse_many(kv, frames, n_frames, workspace, workspace_bytes, stats, profiler, static_cast<hipStream_t>(stream));
+}
+
+int saf_fuse_frames_slabs(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, const int32_t* slab_x0,
+                          const int32_t* slab_nx, int32_t n_slabs, void* const* slab_done_events, void* workspace,
+                          size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream) {
+  KVol kv;
+  int rc = make_kvol(vol, &kv);
+  if (rc) return rc;
+  if (n_frames < 0 || (n_frames > 0 && !frames)) return fail(SAF_E_INVALID, "bad frame array");
+  if (n_slabs <= 0 || !slab_x0 || !slab_nx) return fail(SAF_E_INVALID, "bad slab list");
+  if (n_frames == 0) return SAF_OK;
+  if ((rc = poll_latch())) return rc;
+  ensure_latch();
+  const WinSlabs sl{n_slabs, slab_x0, slab_nx, slab_done_events};
+  return fuse_many(kv, frames, n_frames, workspace, workspace_bytes, stats, profiler, static_cast<hipStream_t>(stream), &sl);
 }
 
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,

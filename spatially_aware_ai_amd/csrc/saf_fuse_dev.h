@@ -295,7 +295,15 @@ struct WinOverlap {
   hipStream_t aux;
   hipEvent_t fork, join, cls_done[2], fuse_done[2];
 };
+// saf_fuse_frames_slabs: every frame into x-planes [x0[k], x0[k] + nx[k]) for k = 0 .. n - 1 in turn; done[k] (may be NULL):
+// a hipEvent_t recorded on the caller's stream behind slab k's last row kernel.
+struct WinSlabs {
+  int n;
+  const int32_t *x0, *nx;
+  void* const* done;
+};
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
-                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov);
+                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs = nullptr);
+KVol slab_kvol(const KVol& kv, int x0, int nx);
 
 }  // namespace saf

@@ -3,6 +3,7 @@
 // row kernel that reads and writes every touched feature row once.  Bit-identical to the per-frame pipeline of
 // saf_fuse.hip; selected by saf_fuse_frames for calls of 16 or more frames of one shape.
 #include <chrono>
+#include <vector>
 
 #include "saf_window_dev.h"
 
@@ -53,6 +54,7 @@ constexpr int kPiece = 256;
 struct ClsArgs {
   int n, H, W;  // frames of this launch (<= kClsFrames), image size
   int slot;     // index of the launch's first frame within the window (0, 32, 64, 96)
+  int count;    // 1: this launch counts its frames in stats[2] (a window classified slab by slab counts them once)
   const float* depth[kClsFrames];
   const float* rgb[kClsFrames];
   const float* pose[kClsFrames];
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
   if (tid < wa.n) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
   file_frames(wa, tab, tid);
   __syncthreads();
-  if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)wa.n);
+  if (stats && wa.count && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)wa.n);
   const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
   uint32_t piece = blockIdx.x * 4u + (uint32_t)wave;
   const bool on = piece < n_pieces;  // (no early return: the workgroup meets again in cls_accumulate)
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   if (tid < n_f) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
   file_frames(wa, tab, tid);
   __syncthreads();
-  if (stats && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_f);
+  if (stats && wa.count && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_f);
   const uint32_t nbx = (uint32_t)v.nx / kBrickX, nby = (uint32_t)v.ny / kBrickY, nbz = (uint32_t)v.nz / kBrickZ;
   const uint32_t q_raw = blockIdx.x * 4u + (uint32_t)wave;
   const bool on = q_raw < nbx * nby * nbz;  // (no early return: the workgroup meets again in cls_accumulate)
@@ -1016,21 +1018,45 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
               if (r < nrows) {
-                const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
                 // the hit's place in (frame, row) order, from the rows' frame masks: hits of earlier frames in this row,
                 // plus this frame's hit of it if the row comes first
-                {
-                  uint32_t m[kMaskWords], at_f = 0u;
+                uint32_t m[kMaskWords], at_f = 0u;
 #pragma unroll
-                  for (int w = 0; w < kMaskWords; ++w) {
-                    m[w] = (uint32_t)__builtin_amdgcn_readlane((int)mk[w], i0 + r);
-                    rank += __popc(m[w] & low[w]);
-                    at_f = fwd == (uint32_t)w ? m[w] : at_f;
-                  }
-                  rank += (r < rec.row && ((at_f >> fbit) & 1u)) ? 1 : 0;
+                for (int w = 0; w < kMaskWords; ++w) {
+                  m[w] = (uint32_t)__builtin_amdgcn_readlane((int)mk[w], i0 + r);
+                  rank += __popc(m[w] & low[w]);
+                  at_f = fwd == (uint32_t)w ? m[w] : at_f;
                 }
+                rank += (r < rec.row && ((at_f >> fbit) & 1u)) ? 1 : 0;
+              }
+            }
+            if constexpr (OF) {
+              // The registers the old rows are loaded into are the ones the previous sub-chunk STORED from, and a store's data
+              // registers may not be rewritten before the store has left: the compiler guards every such write with a
+              // vmcnt wait -- placed between the rows' loads it serialises them (load, wait for it AND the stores, load, ...:
+              // five memory latencies per sub-chunk, 15 % of the kernel).  ONE wait here, after the rank arithmetic above has
+              // given the stores time to leave, and the loads below are issued back to back.
+              __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+              // (zeroes first, loads after: a register write behind a load in flight waits for the load)
+#pragma unroll
+              for (int r = 0; r < SR; ++r) {
+                // bf16: the accumulator holds the samples only, the old row waits in `raw`; f32: a fresh or absent row starts at 0
+                if (BF16 || r >= nrows || (fresh & (1u << r))) {
+#pragma unroll
+                  for (int c = 0; c < 2 * CPL; ++c) acc[r][c] = (win_v2f){0.f, 0.f};
+                }
+                if (BF16 && (r >= nrows || (fresh & (1u << r)))) {
+#pragma unroll
+                  for (int k = 0; k < UPL; ++k) raw.u[r * UPL + k] = make_uint4(0u, 0u, 0u, 0u);
+                }
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+              if (r < nrows) {
+                const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
                 if (fresh & (1u << r)) {
-                  if (BF16) {
+                  if (BF16 && !OF) {
 #pragma unroll
                     for (int k = 0; k < UPL; ++k) raw.u[r * UPL + k] = make_uint4(0u, 0u, 0u, 0u);
                   }
@@ -1043,9 +1069,13 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
                                                     __builtin_bit_cast(uint32_t, t.z), __builtin_bit_cast(uint32_t, t.w));
                   }
                 } else if constexpr (OF) {  // the old row, global -> the accumulator registers (never through LDS)
+                  // through a buffer descriptor of the ROW (four SGPRs): the per-lane offset is one register, the same for every
+                  // row and never rewritten -- with 64-bit addresses in VGPRs every row's loads and stores would wait for the
+                  // previous row's to leave before their address registers may be recomputed
+                  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(feat + row, 0, v.D * 4, 0x00020000);
 #pragma unroll
                   for (int c = 0; c < CPL; ++c) {
-                    const float4 t = ld_stream(feat + row + chs[c]);
+                    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16 + c * 1024, 0, 2));
                     acc[r][2 * c] = (win_v2f){t.x, t.y};
                     acc[r][2 * c + 1] = (win_v2f){t.z, t.w};
                   }
@@ -1055,17 +1085,6 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + row + chs[c]),
                                                      (__attribute__((address_space(3))) void*)(rows + (r * CPL + c) * 64),
                                                      16, 0, 2);
-                }
-              }
-              if constexpr (OF) {
-                // bf16: the accumulator holds the samples only, the old row waits in `raw`; f32: a fresh or absent row starts at 0
-                if (BF16 || r >= nrows || (fresh & (1u << r))) {
-#pragma unroll
-                  for (int c = 0; c < 2 * CPL; ++c) acc[r][c] = (win_v2f){0.f, 0.f};
-                }
-                if (BF16 && r >= nrows) {
-#pragma unroll
-                  for (int k = 0; k < UPL; ++k) raw.u[r * UPL + k] = make_uint4(0u, 0u, 0u, 0u);
                 }
               }
             }
@@ -1134,49 +1153,53 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
         // compiler's wait-count pass so, or it would drain vmcnt -- i.e. the previous row's store -- before
         // each row's LDS read below
-        if constexpr (!OF) {
-          __builtin_amdgcn_s_waitcnt(0x0F70);
-          wave_lds_sync();
-        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // (order-free form: see below -- nothing is outstanding either)
+        if constexpr (!OF) wave_lds_sync();
         WT(6);
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
           if (r < nrows) {
             const int64_t row = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)n_l, i0 + r) * DV;
             if constexpr (OF) {  // (w0 old + the window's samples) / (w0 + k), one rounding to bf16 per window
+              // IN PLACE, and stored from the row's own registers through the row's buffer descriptor: through shared data or
+              // address temporaries every row's stores would wait for the previous row's to leave (a store's registers may not
+              // be rewritten before that): five store latencies per sub-chunk, 17 % of the kernel.  The explicit vmcnt(0)
+              // above (free: every tap load has been consumed) tells the compiler's wait-count pass that no older store -- the
+              // chunk's rgb / weight stores -- still reads the scratch registers of the arithmetic below.
               const int k_r = __builtin_amdgcn_readlane(h, i0 + r), w0_r = __builtin_amdgcn_readlane(w0, i0 + r);
               const float inv = 1.0f / (float)(w0_r + k_r);
               // f32: acc = old + (sum of samples) / w0 (or the plain sum for a fresh row); bf16: acc = the sum of samples
               const float fac = SUM ? 1.0f : ((BF16 || w0_r == 0) ? inv : (float)w0_r * inv);
-              float4 o[CPL];
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) {
-                float4 a4 = make_float4(acc[r][2 * c].x, acc[r][2 * c].y, acc[r][2 * c + 1].x, acc[r][2 * c + 1].y);
-                if (BF16) {  // + w0 x old (SUM: + old)
-                  const uint4 w = raw.u[r * UPL + c / 2];
-                  const uint32_t u0 = (c & 1) ? w.z : w.x, u1 = (c & 1) ? w.w : w.y;
-                  const float f = SUM ? 1.0f : (float)w0_r;
-                  a4.x = __builtin_fmaf(bf16_lo(u0), f, a4.x); a4.y = __builtin_fmaf(bf16_hi(u0), f, a4.y);
-                  a4.z = __builtin_fmaf(bf16_lo(u1), f, a4.z); a4.w = __builtin_fmaf(bf16_hi(u1), f, a4.w);
-                }
-                o[c] = SUM ? a4 : make_float4(a4.x * fac, a4.y * fac, a4.z * fac, a4.w * fac);
-              }
               if (BF16) {
+                const float f = SUM ? 1.0f : (float)w0_r;
 #pragma unroll
                 for (int k = 0; k < UPL; ++k) {
-                  float4 q;
-                  q.x = __builtin_bit_cast(float, pack_bf16(o[2 * k].x, o[2 * k].y));
-                  q.y = __builtin_bit_cast(float, pack_bf16(o[2 * k].z, o[2 * k].w));
-                  q.z = __builtin_bit_cast(float, pack_bf16(o[2 * k + 1].x, o[2 * k + 1].y));
-                  q.w = __builtin_bit_cast(float, pack_bf16(o[2 * k + 1].z, o[2 * k + 1].w));
-                  st_stream(featb + (row / 2) + lane + k * 64, q);
+                  const uint4 w = raw.u[r * UPL + k];  // + w0 x old (SUM: + old), then the mean, packed into the same registers
+                  const win_v2f a0 = acc[r][4 * k], a1 = acc[r][4 * k + 1], a2 = acc[r][4 * k + 2], a3 = acc[r][4 * k + 3];
+                  uint4 q;
+                  q.x = pack_bf16(__builtin_fmaf(bf16_lo(w.x), f, a0.x) * fac, __builtin_fmaf(bf16_hi(w.x), f, a0.y) * fac);
+                  q.y = pack_bf16(__builtin_fmaf(bf16_lo(w.y), f, a1.x) * fac, __builtin_fmaf(bf16_hi(w.y), f, a1.y) * fac);
+                  q.z = pack_bf16(__builtin_fmaf(bf16_lo(w.z), f, a2.x) * fac, __builtin_fmaf(bf16_hi(w.z), f, a2.y) * fac);
+                  q.w = pack_bf16(__builtin_fmaf(bf16_lo(w.w), f, a3.x) * fac, __builtin_fmaf(bf16_hi(w.w), f, a3.y) * fac);
+                  raw.u[r * UPL + k] = q;
+                  if (!(SAF_WIN_ABL & 8))
+                    st_stream(featb + (row / 2) + lane + k * 64, make_float4(__builtin_bit_cast(float, q.x), __builtin_bit_cast(float, q.y),
+                                                                             __builtin_bit_cast(float, q.z), __builtin_bit_cast(float, q.w)));
                 }
-              } else if (SAF_WIN_ABL & 8) {
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) asm volatile("" ::"v"(o[c].x), "v"(o[c].y), "v"(o[c].z), "v"(o[c].w));
               } else {
+                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(feat + row, 0, v.D * 4, 0x00020000);
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) st_stream(&feat[row + chs[c]], o[c]);
+                for (int c = 0; c < CPL; ++c) {
+                  if (!SUM) {
+                    acc[r][2 * c] = acc[r][2 * c] * (win_v2f){fac, fac};
+                    acc[r][2 * c + 1] = acc[r][2 * c + 1] * (win_v2f){fac, fac};
+                  }
+                  const float4 o = make_float4(acc[r][2 * c].x, acc[r][2 * c].y, acc[r][2 * c + 1].x, acc[r][2 * c + 1].y);
+                  if (SAF_WIN_ABL & 8)
+                    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+                  else
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(win_v4u, o), rr, lane * 16 + c * 1024, 0, 2);
+                }
               }
             } else if (BF16) {
 #pragma unroll
@@ -1294,8 +1317,41 @@ bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
   return workspace_bytes >= wl.cmax_off;  // (the brick form's own region was checked above: brick_aux_fits)
 }
 
+// x-planes [x0, x0 + nx) of a volume as a volume of their own: the same buffers, offset (a slab of x-planes is a contiguous
+// range of the flat voxel index; the axis table starts at x0, so every decision is that of the full volume's voxels).
+KVol slab_kvol(const KVol& kv, int x0, int nx) {
+  KVol o = kv;
+  const int64_t rows = (int64_t)x0 * kv.ny * kv.nz;
+  o.nx = nx;
+  o.N = (uint32_t)((int64_t)nx * kv.ny * kv.nz);
+  o.ax = kv.ax + x0;
+  o.tsdf = kv.tsdf + rows;
+  o.tsdf_w = kv.tsdf_w + rows;
+  o.weight = kv.weight + rows;
+  o.rgb = kv.rgb + 3 * rows;
+  o.feat = kv.feat + rows * (kv.bf16 ? kv.D / 2 : kv.D);
+  if (kv.labels) o.labels = kv.labels + rows * kv.n_classes;
+  return o;
+}
+
+// The schedule of a windowed call is a list of UNITS, each a (sub-volume, window of frames) pair with its own
+// classification launches and its own row kernel; unit u + 1 is classified (auxiliary stream) beside unit u's row
+// kernel.  Units of one call:
+//   * default: one unit per window over the whole volume (SAF_WIN_SLABS / SAF_WIN_W0_SLABS: windows cut into slabs of
+//     x-planes -- nothing hides a unit's classification except the row kernel of the unit before it);
+//   * `slabs` (saf_fuse_frames_slabs): every frame into slab 0, then every frame into slab 1, ...: a finished slab is
+//     never touched again (its event is recorded behind its last row kernel: the merge of the slab-pipelined
+//     multi-GPU job starts there), and the first classification of slab s + 1 runs beside the last row kernel of slab s.
+struct WinUnit {
+  KVol kv;
+  int f0, F;     // frames [f0, f0 + F) of the call
+  int count;     // counts its frames in stats[2]
+  int done;      // index of the slab whose event is recorded behind this unit's row kernel, or -1
+  int window;    // index of the window (units of one window in a row share its map images)
+};
+
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
-                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov) {
+                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   KFrame kf0;
@@ -1328,38 +1384,73 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   }
   float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
   const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
-  uint32_t grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : (of ? SAF_WIN_OF_WPE : 2));
-  const uint32_t n_pieces = (uint32_t)(((int64_t)kv.N + kPiece - 1) / kPiece);
-  const uint32_t n_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
-  if (grid > n_wgs) grid = n_wgs;
   const int tile_env = getenv("SAF_WIN_TILE") ? atoi(getenv("SAF_WIN_TILE")) : -1;
-  int tile = tile_env >= 0 ? tile_env : 32;
-  {
-    const int64_t plane = (int64_t)kv.ny * kv.nz;
-    const int64_t ppx = plane / kPiece;
-    if (plane % kPiece != 0) tile = 0;
-    while (tile >= 8 && (ppx % tile != 0 || kv.nx % tile != 0)) tile >>= 1;
-    if (tile < 8) tile = 0;  // linear order
-  }
   // grids that tile into 4 x 4 x 16 bricks classify brick by brick (SAF_WIN_BRICKS=0: always the linear pieces)
   const bool bricks_on = !(getenv("SAF_WIN_BRICKS") && getenv("SAF_WIN_BRICKS")[0] == '0');
-  const bool bricks = bricks_on && kv.nx % kBrickX == 0 && kv.ny % kBrickY == 0 && kv.nz % kBrickZ == 0;
-  const int brick_tiles = (kv.nx / kBrickX) % 8 == 0 && (kv.ny / kBrickY) % 8 == 0 ? 1 : 0;
+  const char* xcd_env = getenv("SAF_WIN_XCD");
   static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kDmaxOff + 32 * sizeof(float) <= kClsAccOff,
                 "workspace header layout");
   const int wlen = window_frames();
   const int n_win = (n_frames + wlen - 1) / wlen;
-  // units of the row kernel in XCD-compact order (see the kernel); SAF_WIN_XCD=0: linear order
-  const char* xcd_env = getenv("SAF_WIN_XCD");
-  const int xcd_order = !(xcd_env && xcd_env[0] == '0') && kv.nx % 16 == 0 && kv.ny % 16 == 0 && kv.nz % kUnitVox == 0 &&
-                                kv.N % kPiece == 0 ? 1 : 0;
+  auto win_frames = [&](int w) { return n_frames - w * wlen < wlen ? n_frames - w * wlen : wlen; };
 
-  // Two streams.  The classification (VALU-bound; TSDF, depth images, one mask plane per 32 frames) of window w + 1 runs
-  // on `cs` while the row kernel (memory-bound) of window w runs on the caller's stream: the row kernel leaves LDS and
-  // registers free (5-row sub-chunks, 2 tap groups in flight) for classification workgroups beside it.  Masks and header
-  // (counters, frame table) are double-buffered by window parity:
-  //   classify(w) -> fuse(w)       event cls_done[w & 1]
-  //   fuse(w) -> classify(w + 2)   event fuse_done[w & 1]  (same mask buffer and header)
+  // ---- the units of this call
+  std::vector<WinUnit> units;
+  if (slabs && slabs->n > 0) {
+    for (int k = 0; k < slabs->n; ++k) {
+      if (slabs->x0[k] < 0 || slabs->nx[k] <= 0 || slabs->x0[k] + slabs->nx[k] > kv.nx) return fail(SAF_E_INVALID, "slab %d outside the volume", k);
+      for (int w = 0; w < n_win; ++w)
+        units.push_back(WinUnit{slab_kvol(kv, slabs->x0[k], slabs->nx[k]), w * wlen, win_frames(w), k == 0, w + 1 == n_win ? k : -1, k * n_win + w});
+    }
+  } else {
+    // SAF_WIN_SLABS (read per call; default 1 = off): EVERY window slab by slab, window after window -- units of one size, so
+    // that unit u + 1's classification is as long as unit u's row kernel is; SAF_WIN_W0_SLABS: only the first window (measured:
+    // no gain -- the second window's whole classification then has only the last slab's row kernel to hide behind).  Slabs are
+    // whole multiples of 16 x-planes (the row kernel's XCD-compact unit order, the classification's bricks).
+    const char* e0 = getenv("SAF_WIN_W0_SLABS");
+    const char* e1 = getenv("SAF_WIN_SLABS");
+    auto fit = [&](int n) {
+      if (!ov || brick_form || n < 2 || kv.nx % 16 != 0) return 1;
+      while (n > 1 && (kv.nx / 16) % n != 0) --n;
+      return n;
+    };
+    const int ns = fit(e1 ? atoi(e1) : 1), n0 = ns > 1 ? ns : fit(e0 ? atoi(e0) : 1);
+    for (int w = 0; w < n_win; ++w) {
+      const int n = w == 0 ? n0 : ns;
+      for (int k = 0; k < n; ++k)
+        units.push_back(WinUnit{n == 1 ? kv : slab_kvol(kv, k * (kv.nx / n), kv.nx / n), w * wlen, win_frames(w), k == 0, -1, w});
+    }
+  }
+  const int n_units = (int)units.size();
+
+  struct Geom {
+    uint32_t n_wgs, grid;
+    int tile, bricks, brick_tiles, xcd_order;
+  };
+  auto geom = [&](const KVol& u) {
+    Geom g;
+    const uint32_t n_pieces = (uint32_t)(((int64_t)u.N + kPiece - 1) / kPiece);
+    g.n_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
+    g.grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : (of ? SAF_WIN_OF_WPE : 2));
+    if (g.grid > g.n_wgs) g.grid = g.n_wgs;
+    g.tile = tile_env >= 0 ? tile_env : 32;
+    const int64_t plane = (int64_t)u.ny * u.nz, ppx = plane / kPiece;
+    if (plane % kPiece != 0) g.tile = 0;
+    while (g.tile >= 8 && (ppx % g.tile != 0 || u.nx % g.tile != 0)) g.tile >>= 1;
+    if (g.tile < 8) g.tile = 0;  // linear order
+    g.bricks = bricks_on && u.nx % kBrickX == 0 && u.ny % kBrickY == 0 && u.nz % kBrickZ == 0;
+    g.brick_tiles = (u.nx / kBrickX) % 8 == 0 && (u.ny / kBrickY) % 8 == 0 ? 1 : 0;
+    // units of the row kernel in XCD-compact order (see the kernel); SAF_WIN_XCD=0: linear order
+    g.xcd_order = !(xcd_env && xcd_env[0] == '0') && u.nx % 16 == 0 && u.ny % 16 == 0 && u.nz % kUnitVox == 0 && u.N % kPiece == 0 ? 1 : 0;
+    return g;
+  };
+
+  // Two streams.  The classification (VALU-bound; TSDF, depth images, one mask plane per 32 frames) of unit u + 1 runs
+  // on `cs` while the row kernel (memory-bound) of unit u runs on the caller's stream: the row kernel leaves LDS and
+  // registers free for classification workgroups beside it.  Masks and header (counters, frame table) are double-
+  // buffered by unit parity:
+  //   classify(u) -> fuse(u)       event cls_done[u & 1]
+  //   fuse(u) -> classify(u + 2)   event fuse_done[u & 1]  (same mask buffer and header)
   // Without `ov` everything is queued on the caller's stream in order.
   hipStream_t cs = ov ? ov->aux : s;
   if (ov) {
@@ -1373,46 +1464,47 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       fprintf(stderr, "[win trace] %8.3f ms  %s %d\n",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), what, w);
   };
-  auto win_frames = [&](int w) { return n_frames - w * wlen < wlen ? n_frames - w * wlen : wlen; };
-  auto classify = [&](int w) -> int {
-    const int F = win_frames(w), f0 = w * wlen, par = w & 1;
+  auto classify = [&](int ui) -> int {
+    const WinUnit& u = units[ui];
+    const Geom g = geom(u.kv);
+    const int F = u.F, f0 = u.f0, par = ui & 1;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
     float* dmax = reinterpret_cast<float*>(hdr + kDmaxOff);
     unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
     WinTable* tab = reinterpret_cast<WinTable*>(hdr + kTableOff);
-    mark("classify: begin", w);
-    if (ov && w >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
+    mark("classify: begin", ui);
+    if (ov && ui >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
     // header: unit counters, dmax, the classification launches' counter shards, the frame table
     if (hipMemsetAsync(hdr, 0, kHdrBytes, cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
-    mark("classify: header memset queued", w);
+    mark("classify: header memset queued", ui);
     for (int fb = 0; fb < F; fb += kClsFrames) {
       ClsArgs ca;
       ca.n = fb + kClsFrames < F ? kClsFrames : F - fb;
-      ca.H = kf0.H; ca.W = kf0.W; ca.slot = fb;
+      ca.H = kf0.H; ca.W = kf0.W; ca.slot = fb; ca.count = u.count;
       for (int k = 0; k < kClsFrames; ++k) {
         const saf_frame& fr = frames[f0 + fb + (k < ca.n ? k : 0)];
         ca.depth[k] = fr.depth; ca.rgb[k] = fr.rgb; ca.pose[k] = fr.pose; ca.K[k] = fr.K; ca.label_map[k] = fr.label_map;
         ca.feat_map[k] = fr.feat_map;
       }
       uint32_t* plane = masks + (size_t)(fb / kClsFrames) * wl.mask_plane;
-      if (bricks) {  // the frames' largest depths feed the bricks' frame cull
+      if (g.bricks) {  // the frames' largest depths feed the bricks' frame cull
         if (hipMemsetAsync(dmax, 0, kClsFrames * sizeof(float), cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(dmax)");
         hipLaunchKernelGGL(depth_max_kernel, dim3(32, ca.n), dim3(256), 0, cs, ca, kf0.H * kf0.W, reinterpret_cast<int*>(dmax));
       }
       ScopedPair t(prof, 1, f0 + fb, cs);
-      if (bricks) {
+      if (g.bricks) {
         if (sum)
-          hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(n_wgs), dim3(256), 0, cs, kv, ca, brick_tiles, dmax, plane,
+          hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(g.n_wgs), dim3(256), 0, cs, u.kv, ca, g.brick_tiles, dmax, plane,
                              reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
         else
-          hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(n_wgs), dim3(256), 0, cs, kv, ca, brick_tiles, dmax, plane,
+          hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(g.n_wgs), dim3(256), 0, cs, u.kv, ca, g.brick_tiles, dmax, plane,
                              reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
       } else if (sum) {
-        hipLaunchKernelGGL(classify_window_kernel<true>, dim3(n_wgs), dim3(256), 0, cs, kv, ca, tile, plane,
+        hipLaunchKernelGGL(classify_window_kernel<true>, dim3(g.n_wgs), dim3(256), 0, cs, u.kv, ca, g.tile, plane,
                            reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
       } else {
-        hipLaunchKernelGGL(classify_window_kernel<false>, dim3(n_wgs), dim3(256), 0, cs, kv, ca, tile, plane,
+        hipLaunchKernelGGL(classify_window_kernel<false>, dim3(g.n_wgs), dim3(256), 0, cs, u.kv, ca, g.tile, plane,
                            reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
       }
     }
@@ -1422,47 +1514,53 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       WinArgs wa;
       wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
       ScopedPair t(prof, 3, f0, cs);
-      if ((r = launch_brick_build(kv, wa, tab, wl.img_bytes, reinterpret_cast<unsigned long long*>(stats), masks, wl.mask_plane,
+      if ((r = launch_brick_build(u.kv, wa, tab, wl.img_bytes, reinterpret_cast<unsigned long long*>(stats), masks, wl.mask_plane,
                                   ws + wl.cmax_off, aux_bytes, par, cs)))
         return r;
     }
-    mark("classify: launches queued", w);
+    mark("classify: launches queued", ui);
     if (ov && hipEventRecord(ov->cls_done[par], cs) != hipSuccess) return fail(SAF_E_HIP, "hipEventRecord");
     return SAF_OK;
   };
   if ((rc = classify(0))) return rc;
-  for (int w = 0; w < n_win && rc == SAF_OK; ++w) {
-    const int F = win_frames(w), f0 = w * wlen, par = w & 1;
+  int maps_of = -1;  // the window whose map images the workspace holds
+  for (int ui = 0; ui < n_units && rc == SAF_OK; ++ui) {
+    const WinUnit& u = units[ui];
+    const Geom g = geom(u.kv);
+    const int F = u.F, f0 = u.f0, par = ui & 1;
     WinArgs wa;
     wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     const WinTable* tab = reinterpret_cast<const WinTable*>(hdr + kTableOff);
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
-    if (ov && w + 1 < n_win && (rc = classify(w + 1))) break;  // queued now: it runs beside this window's row kernel
+    if (ov && ui + 1 < n_units && (rc = classify(ui + 1))) break;  // queued now: it runs beside this unit's row kernel
     if (ov && hipStreamWaitEvent(s, ov->cls_done[par], 0) != hipSuccess) { rc = fail(SAF_E_HIP, "hipStreamWaitEvent"); break; }
-    {
+    if (maps_of != u.window) {  // (the slabs of one window share its map images)
       ScopedPair t(prof, 0, f0, s);
       hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, maps,
                          (int)(wl.img_bytes / sizeof(float)), kv.D, P);
+      if ((rc = check_launch("prep_rows_kernel"))) break;
+      maps_of = u.window;
     }
-    if ((rc = check_launch("prep_rows_kernel"))) break;
     if (brick_form) {
       ScopedPair t(prof, 2, f0, s);
-      rc = launch_fuse_bricks(kv, wa, tab, maps, wl.img_bytes, reinterpret_cast<unsigned long long*>(stats),
+      rc = launch_fuse_bricks(u.kv, wa, tab, maps, wl.img_bytes, reinterpret_cast<unsigned long long*>(stats),
                               reinterpret_cast<unsigned int*>(hdr), masks, wl.mask_plane,
                               reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff),
                               ws + wl.cmax_off, aux_bytes, par, split, s);
     } else {
       ScopedPair t(prof, 2, f0, s);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(kWinThreads), win_lds, s, kv, wa, tab, maps, img_vecs,
+      hipLaunchKernelGGL(fn, dim3(g.grid), dim3(kWinThreads), win_lds, s, u.kv, wa, tab, maps, img_vecs,
                          reinterpret_cast<unsigned long long*>(stats), reinterpret_cast<unsigned int*>(hdr), masks, wl.mask_plane,
-                         reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff), xcd_order);
+                         reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff), g.xcd_order);
       rc = check_launch("fuse_window_kernel");
     }
     if (rc) break;
-    mark("rows: queued", w);
+    mark("rows: queued", ui);
+    if (u.done >= 0 && slabs && slabs->done && slabs->done[u.done] &&
+        hipEventRecord(static_cast<hipEvent_t>(slabs->done[u.done]), s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord(slab done)"); break; }
     if (ov && hipEventRecord(ov->fuse_done[par], s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord"); break; }
-    if (!ov && w + 1 < n_win) rc = classify(w + 1);
+    if (!ov && ui + 1 < n_units) rc = classify(ui + 1);
   }
   if (ov) {  // whatever was queued on the classification stream is ordered before later work of the caller (error paths too)
     if (hipEventRecord(ov->join, cs) == hipSuccess) (void)hipStreamWaitEvent(s, ov->join, 0);

@@ -371,18 +371,27 @@ def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, grou
     stripes = []
     nx = int(fusion.nvox[0])
     n = fusion._buffers["tsdf"].numel()
-    for x0, cnt in slab_bounds(nx, n_slabs, ramp=ramp):
-        vol = slab_descriptor(fusion, x0, cnt)
-        check(L.saf_fuse_frames_profiled(C.byref(vol), frame_arr, n_frames, workspace.data_ptr(), workspace.numel(), stats_ptr,
-                                         profiler, main.cuda_stream), "saf_fuse_frames (slab)")
-        fused = main.record_event()
+    slabs = slab_bounds(nx, n_slabs, ramp=ramp)
+    k = len(slabs)
+    # ONE C call fuses every frame into slab 0, slab 1, ... (the first window of a slab is classified beside the last row
+    # kernel of the slab before it) and records an event behind each slab; the collectives wait for those on `comm`
+    with torch.cuda.device(dev):
+        events = [torch.cuda.Event() for _ in slabs]
+        for ev in events:
+            ev.record(main)  # (torch creates the HIP event at its first record; the C call records it again, for real)
+        x0s = (C.c_int32 * k)(*[s_[0] for s_ in slabs])
+        nxs = (C.c_int32 * k)(*[s_[1] for s_ in slabs])
+        handles = (C.c_void_p * k)(*[int(ev.cuda_event) for ev in events])
+        vol = fusion._c_volume(for_fuse=True)
+        check(L.saf_fuse_frames_slabs(C.byref(vol), frame_arr, n_frames, x0s, nxs, k, handles, workspace.data_ptr(), workspace.numel(),
+                                      stats_ptr, profiler, main.cuda_stream), "saf_fuse_frames_slabs")
         with torch.cuda.stream(comm):
-            comm.wait_event(fused)
-            r0, nr = slab_rows(fusion, x0, cnt)
-            vdesc = fusion._c_volume(for_fuse=True)
-            for first, count in merge_slab_sums(tensors, r0, nr, group, mode):
-                check(L.saf_merge_finalize(C.byref(vdesc), first, count, comm.cuda_stream), "saf_merge_finalize")
-                stripes.append((first, count))
+            for (x0, cnt), ev in zip(slabs, events):
+                comm.wait_event(ev)
+                r0, nr = slab_rows(fusion, x0, cnt)
+                for first, count in merge_slab_sums(tensors, r0, nr, group, mode):
+                    check(L.saf_merge_finalize(C.byref(vol), first, count, comm.cuda_stream), "saf_merge_finalize")
+                    stripes.append((first, count))
     if comm is not main:
         main.wait_event(comm.record_event())
     # the volume now holds means on this rank's stripes (partial sums elsewhere): no longer a SUM volume

@@ -26,3 +26,10 @@ def oracle():
 
     O.build()
     return O
+
+
+@pytest.fixture
+def rows_form(monkeypatch):
+    """The frame-ordered form of the window's row kernel (SAF_WIN_FORM=rows): bit-identical to fusing frame after frame.  The
+    default is the order-free form (sums), whose feature values agree within fp32 rounding (tests/test_sums_form.py)."""
+    monkeypatch.setenv("SAF_WIN_FORM", "rows")

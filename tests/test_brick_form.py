@@ -166,8 +166,9 @@ def test_brick_form_propagates_non_finite_map_values(monkeypatch):
 
 
 def test_default_form_by_feature_width(monkeypatch):
-    """Without SAF_WIN_FORM: the frame-ordered row kernel where it applies (bit-identical to frame after frame), the brick
-    form for the widths it does not take (they used to fall back to the per-frame pipeline)."""
+    """Without SAF_WIN_FORM: a row kernel where one applies -- the order-free form (features within fp32 rounding of frame after
+    frame; SAF_WIN_FORM=rows: the frame-ordered form, bit-identical) --, the brick form for the widths they do not take (those
+    used to fall back to the per-frame pipeline)."""
     monkeypatch.delenv("SAF_WIN_FORM", raising=False)
     nvox, n_frames = (33, 30, 41), 20
     grid = syn.make_grid(nvox, side=2.56 * nvox[0] / max(nvox))
@@ -177,7 +178,11 @@ def test_default_form_by_feature_width(monkeypatch):
         win = _fuse(_build(grid, dim, False, _abi.SAF_RUNNING_MEAN, torch.float32), frames, False)
         assert win.stats()["window_rows"] > 0, f"D = {dim} did not take the windowed path"
         if exact:
-            assert torch.equal(one.clip_feat, win.clip_feat)
+            _feat_close(win.clip_feat, one.clip_feat, 5e-6, f"D = {dim} (order-free rows)")
+            monkeypatch.setenv("SAF_WIN_FORM", "rows")
+            rows = _fuse(_build(grid, dim, False, _abi.SAF_RUNNING_MEAN, torch.float32), frames, False)
+            monkeypatch.delenv("SAF_WIN_FORM")
+            assert torch.equal(one.clip_feat, rows.clip_feat)
         else:
             assert not torch.equal(one.clip_feat, win.clip_feat), "expected the brick form (folded updates)"
             _feat_close(win.clip_feat, one.clip_feat, 5e-6, f"D = {dim}")

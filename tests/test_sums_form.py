@@ -61,10 +61,10 @@ def test_sums_form_against_the_sequential_path_and_the_oracle(oracle, monkeypatc
     assert torch.equal(again.clip_feat, win.clip_feat), "two runs of the order-free form differ"
 
 
-@pytest.mark.parametrize("env", [{"SAF_WIN_OVERLAP": "0"}, {"SAF_WIN_FRAMES": "64"}, {"SAF_WIN_XCD": "0"}])
+@pytest.mark.parametrize("env", [{"SAF_WIN_OVERLAP": "0"}, {"SAF_WIN_FRAMES": "64"}, {"SAF_WIN_XCD": "0"}, {"SAF_WIN_W0_SLABS": "1"}])
 def test_sums_form_schedules_agree(env, monkeypatch):
-    """Stream overlap, window length and unit order change the schedule, not the sums of a window... except the window
-    length, which changes which samples are folded together: that one is compared at 5e-6 instead of bit for bit."""
+    """Stream overlap, unit order and the first window's slabs change the schedule, not the sums of a window... except the
+    window length, which changes which samples are folded together: that one is compared at 5e-6 instead of bit for bit."""
     nvox, dim, n_frames = (32, 32, 64), 512, 140
     grid = syn.make_grid(nvox)
     frames = _frames(4242, n_frames, dim, "B")
