@@ -148,6 +148,18 @@ int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_st
  * with weight 0), 0 = per-frame pipeline, -1 = invalid arguments.  Host-only, launches nothing. */
 int saf_fuse_path(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes);
 
+/*
+ * The 7 x 7 depthwise convolution of a ConvNeXt block, channels-last (backbone op of BASELINE config 3's panoptic encoder:
+ * kMaX-DeepLab's ConvNeXt-L behind KmaxSegmentationModel.run_on_image, handy_utils.py:29-161; in PyTorch
+ * nn.Conv2d(C, C, 7, padding=3, groups=C)).  MIOpen runs these through naive_conv; the op is tiny and L2 bound.
+ *   x, y    [batch, H, W, C] of `dtype` (SAF_F32 / SAF_BF16 / SAF_F16), C contiguous and a multiple of 8, 16-byte aligned
+ *   w_kkc   [7, 7, C] f32: PyTorch's weight [C, 1, 7, 7] permuted once by the host
+ *   bias    [C] f32 or NULL
+ * fp32 accumulation, one rounding to `dtype` on the way out; zero padding of 3 pixels.
+ */
+int saf_dwconv7x7_nhwc(const void* x, const float* w_kkc, const float* bias, void* y, int32_t batch, int32_t height,
+                       int32_t width, int32_t channels, int32_t dtype, void* stream);
+
 /* Zero the clip_feat rows of voxels [first, first + n) whose weight is 0.  A volume recycled for a new scan may skip the
  * up-front clear of its 4*D*N feature bytes: zero `weight` (and the other small buffers), fuse through the windowed path
  * only, and call this before anything else reads clip_feat (the Python host does all of that behind reset()). */

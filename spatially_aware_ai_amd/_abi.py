@@ -137,6 +137,7 @@ PROTOTYPES = {
          C.POINTER(C.c_float), C.POINTER(C.c_float), _fp, C.c_int32, _fp],
     ),
     "saf_save_npy": (C.c_int, [_fp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_char_p, _fp]),
+    "saf_dwconv7x7_nhwc": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "saf_mesh_json": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "saf_free": (None, [C.c_void_p]),
     "saf_save_ply": (C.c_int, [C.c_char_p, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int32]),

@@ -112,6 +112,41 @@ class _LayerNorm2d(nn.Module):
         return self.ln(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
 
+def dwconv7x7(x, weight, bias=None, _cache=None):
+    """``F.conv2d(x, weight, bias, padding=3, groups=C)`` for a 7 x 7 depthwise convolution on a channels-last HIP tensor
+    (``saf_dwconv7x7_nhwc``, csrc/saf_dwconv.hip: MIOpen runs this shape through naive_conv -- 46 % of the default bench's
+    kernel time in round 3).  fp32 accumulation, output in x's dtype and memory format.  ``_cache``: a dict that keeps the
+    re-laid [7, 7, C] f32 weight across calls (keyed by the weight's version)."""
+    import ctypes as C
+
+    from . import _abi
+    from ._lib import check, current_stream_ptr, lib
+
+    n, c, h, w = x.shape
+    dt = {torch.float32: _abi.SAF_F32, torch.bfloat16: _abi.SAF_BF16, torch.float16: _abi.SAF_F16}[x.dtype]
+    key = (weight.data_ptr(), weight._version, x.device)
+    if _cache is not None and _cache.get("key") == key:
+        w_kkc, b32 = _cache["w"], _cache["b"]
+    else:
+        w_kkc = weight.detach()[:, 0].permute(1, 2, 0).contiguous().to(device=x.device, dtype=torch.float32)
+        b32 = None if bias is None else bias.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        if _cache is not None:
+            _cache.update(key=key, w=w_kkc, b=b32)
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        check(lib().saf_dwconv7x7_nhwc(x.data_ptr(), w_kkc.data_ptr(), None if b32 is None else b32.data_ptr(), y.data_ptr(),
+                                       n, h, w, c, dt, current_stream_ptr()), "saf_dwconv7x7_nhwc")
+    return y
+
+
+def _dwconv_ok(x, conv):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and conv.kernel_size == (7, 7) and conv.padding == (3, 3)
+            and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == x.shape[1] == conv.out_channels
+            # inference only (no autograd through the HIP op)
+            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)))
+
+
 class _ConvNeXtBlock(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -120,9 +155,18 @@ class _ConvNeXtBlock(nn.Module):
         self.fc1 = nn.Linear(c, 4 * c)
         self.fc2 = nn.Linear(4 * c, c)
         self.gamma = nn.Parameter(torch.full((c,), 1e-6))
+        self.__dict__["_dw_cache"] = {}
+
+    def _depthwise(self, x):
+        # under autocast the library convolution would compute in the autocast dtype: so does this one
+        if torch.is_autocast_enabled("cuda") and x.is_cuda and x.dtype == torch.float32:
+            x = x.to(torch.get_autocast_dtype("cuda"))
+        if _dwconv_ok(x, self.dw):
+            return dwconv7x7(x, self.dw.weight, self.dw.bias, self.__dict__["_dw_cache"])
+        return self.dw(x)
 
     def forward(self, x):
-        y = self.dw(x).permute(0, 2, 3, 1)
+        y = self._depthwise(x).permute(0, 2, 3, 1)
         y = self.fc2(F.gelu(self.fc1(self.ln(y)))) * self.gamma
         return x + y.permute(0, 3, 1, 2)
 

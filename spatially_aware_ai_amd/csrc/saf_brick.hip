@@ -375,7 +375,11 @@ struct BrickPool {
 // (hit records, scalar side, sorted groups), written to the pool as segments.  !BUILD: the persistent walk kernel (4 walker +
 // 4 mover waves): segments from the pool, then the bricks of the overflow list (or, without a build kernel, every brick),
 // which it builds itself.
-template <int CPL, bool SUM, bool BF16, bool BUILD>
+// REBUILD (walk kernel only): this instantiation carries the build code too -- it builds every brick itself (no build kernel:
+// pool.split == 0) or the bricks of the overflow list (pool.split == 3: a small second launch behind the walk of the pool's
+// segments).  The walk of the pool's segments (pool.split == 2) is compiled WITHOUT it: with the build code inlined the walk
+// kernel spilled 23-95 registers at its cap of 128.
+template <int CPL, bool SUM, bool BF16, bool BUILD, bool REBUILD = true>
 __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fuse_brick_kernel(
     KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, uint32_t img_bytes,
     unsigned long long* __restrict__ stats, unsigned int* __restrict__ ctr, const uint32_t* __restrict__ hitmask,
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((a
   const int F = wa.F;
   constexpr int kSlabCh = 64 * CPL;
 
-  if (!BUILD && stats && blockIdx.x == 0 && tid < kClsShards) {  // the classification launches' sharded counters (cls_accumulate)
+  if (!BUILD && stats && blockIdx.x == 0 && tid < kClsShards && pool.split != 3) {  // the classification launches' sharded counters (cls_accumulate)
     unsigned long long a = cls_acc[2 * tid], b = cls_acc[2 * tid + 1];
     unsigned long long c = 0, d = 0;  // ... and the build kernel's (hits, rows)
     if (pool.split) { c = pool.ctl->acc[tid][0]; d = pool.ctl->acc[tid][1]; }
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((a
     //      it) and its workgroups draw from it -- the map taps and rows of neighbouring bricks stay in one L2.  A brick is
     //      drawn while the one before it is walked, and the walkers fetch a segment's image as soon as they have walked
     //      the last slab of the segment before: it lands while the movers write that slab out.
-    if (pool.split) {
+    if (pool.split == 1 || pool.split == 2) {
       if (tid == kHitThreads) {
         L.misc[28] = blockIdx.x & 7u;
         L.misc[29] = 0u;
@@ -687,6 +691,7 @@ __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((a
 
   // ---- bricks built here: BUILD: the workgroup's own brick; the walk kernel: the bricks of the overflow list, or (no build
   //      kernel) every brick, drawn XCD by XCD
+  if constexpr (BUILD || REBUILD) {
   bool build_done = false;
   // The walk kernel behind a build kernel only rebuilds what the pool had no room for: the build kernel has already done
   // those bricks' scalar side (rgb, weights, labels, counters) -- the next window's build kernel may be running beside this
@@ -1053,6 +1058,7 @@ __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((a
     }
     BT(9);
   }
+  }  // BUILD || REBUILD
   BT(10);
   BT_FLUSH;
   if (stats) {
@@ -1108,10 +1114,10 @@ __global__ __launch_bounds__(128) void cam_table_kernel(const WinTable* __restri
 size_t cmax_words(int D) { return (size_t)D + (size_t)D / 64 + 1; }
 size_t cmax_bytes(int D) { return (cmax_words(D) * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
-template <int CPL>
+template <int CPL, bool REBUILD>
 BrickFn pick_brick(bool sum, bool bf16) {
-  if (bf16) return sum ? fuse_brick_kernel<CPL, true, true, false> : fuse_brick_kernel<CPL, false, true, false>;
-  return sum ? fuse_brick_kernel<CPL, true, false, false> : fuse_brick_kernel<CPL, false, false, false>;
+  if (bf16) return sum ? fuse_brick_kernel<CPL, true, true, false, REBUILD> : fuse_brick_kernel<CPL, false, true, false, REBUILD>;
+  return sum ? fuse_brick_kernel<CPL, true, false, false, REBUILD> : fuse_brick_kernel<CPL, false, false, false, REBUILD>;
 }
 
 uint32_t brick_count(const KVol& kv) {
@@ -1224,28 +1230,42 @@ int launch_fuse_bricks(const KVol& kv, const WinArgs& wa, const WinTable* tab, c
                        const unsigned long long* cls_acc, void* aux, size_t aux_bytes, int parity, int split, hipStream_t s) {
   uint32_t* cmax = static_cast<uint32_t*>(aux);
   const float* cams;
-  const BrickPool pool = make_pool(kv, aux, aux_bytes, parity, split, &cams);
+  BrickPool pool = make_pool(kv, aux, aux_bytes, parity, split, &cams);
   // the channels' largest magnitudes over this window's maps (the scales of the fixed-point sums)
   if (hipMemsetAsync(cmax, 0, cmax_bytes(kv.D), s) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(channel maxima)");
   hipLaunchKernelGGL(chan_max_kernel, dim3((kv.D + 255) / 256, (wa.F + 7) / 8), dim3(256), 0, s, map_imgs,
                      (int)(img_bytes / sizeof(float)), kv.D, wa.npy * wa.npx, wa.F, cmax);
   if (!split) hipLaunchKernelGGL(cam_table_kernel, dim3(1), dim3(128), 0, s, tab, wa.F, const_cast<float*>(cams));
   const bool sum = kv.accum == SAF_SUM, bf16 = kv.bf16 != 0;
-  BrickFn fn;
+  // behind a build kernel: the walk of the pool's segments (no build code in it), then the overflow list, if any, by a small
+  // launch of the instantiation that can build; without a build kernel that instantiation does everything
+  BrickFn fn, fn_re;
   size_t lds;
   if (kv.D % 256 == 0) {
-    fn = pick_brick<4>(sum, bf16); lds = sizeof(BrickLds<4>);
+    fn = pick_brick<4, false>(sum, bf16); fn_re = pick_brick<4, true>(sum, bf16); lds = sizeof(BrickLds<4>);
   } else if (kv.D % 128 == 0) {
-    fn = pick_brick<2>(sum, bf16); lds = sizeof(BrickLds<2>);
+    fn = pick_brick<2, false>(sum, bf16); fn_re = pick_brick<2, true>(sum, bf16); lds = sizeof(BrickLds<2>);
   } else {
-    fn = pick_brick<1>(sum, bf16); lds = sizeof(BrickLds<1>);
+    fn = pick_brick<1, false>(sum, bf16); fn_re = pick_brick<1, true>(sum, bf16); lds = sizeof(BrickLds<1>);
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
+  for (BrickFn f : {fn, fn_re}) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
+  }
   const int wgs_env = getenv("SAF_BRICK_WGS") ? atoi(getenv("SAF_BRICK_WGS")) : 0;
   const uint32_t grid = (uint32_t)device_cus() * (uint32_t)(wgs_env > 0 ? wgs_env : 2);
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBThreads), lds, s, kv, wa, tab, map_imgs, (uint32_t)img_bytes, stats, ctr, hitmask,
-                     mask_plane, cls_acc, cmax, cams, pool);
+  if (split) {
+    pool.split = 2;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBThreads), lds, s, kv, wa, tab, map_imgs, (uint32_t)img_bytes, stats, ctr, hitmask,
+                       mask_plane, cls_acc, cmax, cams, pool);
+    pool.split = 3;  // (a workgroup that finds the overflow list empty leaves at once)
+    hipLaunchKernelGGL(fn_re, dim3((uint32_t)device_cus()), dim3(kBThreads), lds, s, kv, wa, tab, map_imgs, (uint32_t)img_bytes, stats, ctr,
+                       hitmask, mask_plane, cls_acc, cmax, cams, pool);
+  } else {
+    fn = fn_re;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBThreads), lds, s, kv, wa, tab, map_imgs, (uint32_t)img_bytes, stats, ctr, hitmask,
+                       mask_plane, cls_acc, cmax, cams, pool);
+  }
 #ifdef SAF_BRICK_TIMING
   {
     int nb = -1;

@@ -654,9 +654,10 @@ query_wide2_kernel(Wide2Args wa) {
       }
     }
 #ifndef SAF_W2_AHEAD
-#define SAF_W2_AHEAD 8
+#define SAF_W2_AHEAD 6  // text fragments requested ahead of the MFMA that consumes them.  8 spilled 5-18 registers in the NF = 1, D = 512 instantiations (scratch traffic inside the tile loop: VERDICT round 3); 6: none
 #endif
-    constexpr int AHEAD = KS < SAF_W2_AHEAD ? KS : SAF_W2_AHEAD;
+    constexpr int kAhead = EPI == SAF_QW_QUERY_MAX && NF == 1 ? SAF_W2_AHEAD - 1 : SAF_W2_AHEAD;  // (the key registers of the per-query maximum)
+    constexpr int AHEAD = KS < kAhead ? KS : kAhead;
     uint4 t[KS];
     // (tried: fragments straight from a fragment-ordered copy of the text in L2 / L1, no LDS, no barrier: 24.0 vs 19.3 ms)
     const unsigned char* trow = curb + r * ROWB + 16 * h;  // text row (query qt*32 + r), k half h

@@ -20,7 +20,7 @@ namespace {
 //
 // A running mean is applied hit by hit, but nothing forces a row to travel to HBM between two hits.
 // Per window, on the caller's stream:
-//   classify_window_kernel  (one launch per 32 frames) every voxel against 32 frames (the full-grid sweep of
+//   classify_bricks_kernel  (one launch per 32 frames) every voxel against 32 frames (the full-grid sweep of
 //                           clipfusion.py:647-695): TSDF running mean kept in registers across the frames
 //                           and written once, one 32-bit frame mask per voxel into that launch's mask plane;
 //   fuse_window_kernel      every touched voxel's D-row is read ONCE, the voxel's hits are applied in frame
@@ -100,6 +100,9 @@ __device__ unsigned long long g_win_t[16];
 #endif
 #ifndef SAF_CLS_WPE
 #define SAF_CLS_WPE 5  // classify_bricks_kernel: waves per SIMD the register budget is set for (78 VGPRs, no spills)
+#endif
+#ifndef SAF_CLS_OCCL
+#define SAF_CLS_OCCL 1  // the occlusion cull of the classification (depth tile maxima); 0: the frame-wide largest depth only
 #endif
 #ifndef SAF_CLS_FU
 #define SAF_CLS_FU 1   // frames classified together: with the frame cull, occupancy hides the depth gathers better than batching does (1: 1.13 ms, 2: 1.17, 4: 1.29, 8: 2.08 per launch)
@@ -250,30 +253,6 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
   }
 }
 
-// Classification of one piece of 256 consecutive voxels (a lane owns 4 of them) against the launch's frames
-// (clipfusion.py:647-695): used when the grid does not tile into bricks.
-template <int KFU, bool SUM>
-__device__ __forceinline__ void classify_piece(const KVol& v, const ClsArgs& wa, const Cam* __restrict__ s_cam,
-                                               uint32_t piece_base, int lane, float rtrunc, bool tsdf_aligned,
-                                               uint32_t (&mk4)[4], unsigned long long& nt_done,
-                                               unsigned long long& tsdf_rows_done) {
-  const uint32_t nb = piece_base + (uint32_t)lane * 4u;
-  float xw[4], yw[4], zw[4];
-  bool inb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    inb[j] = nb + j < v.N;
-    int ix, iy, iz;
-    voxel_coords(v, inb[j] ? nb + j : 0u, ix, iy, iz);
-    xw[j] = v.ax[ix];
-    yw[j] = v.ay[iy];
-    zw[j] = v.az[iz];
-  }
-  const int nf = wa.n;
-  const uint32_t live = nf >= 32 ? 0xffffffffu : ((1u << nf) - 1u);
-  classify_voxels<KFU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
-}
-
 // Counters of a classification launch.  One atomic per WAVE on stats[1] / stats[6] would be 131 k atomics on
 // two addresses per launch -- they serialise in L2 and took 0.7 ms of a 1.8 ms kernel.  The four waves of a
 // workgroup are summed in LDS and added to one of 64 shards in the workspace header; the window's row kernel
@@ -298,81 +277,87 @@ __device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsig
   }
 }
 
-// classify_window_kernel: one launch per 32 frames of a window; leaves that mask word of
-// every voxel in its plane of `hitmask` and the updated TSDF.  (One launch over all 64 frames keeps the TSDF
-// in registers twice as long but puts 64 depth-image footprints in L2 at once: 4.2 ms against 2 x 1.9 ms.)
-template <bool SUM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_window_kernel(
-    KVol v, ClsArgs wa, int tile, uint32_t* __restrict__ hitmask, unsigned long long* __restrict__ stats,
-    unsigned long long* __restrict__ cls_acc, WinTable* __restrict__ tab) {
-  __shared__ Cam s_cam[kClsFrames];
-  __shared__ unsigned long long s_acc[4][2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < wa.n) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
-  file_frames(wa, tab, tid);
-  __syncthreads();
-  if (stats && wa.count && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)wa.n);
-  const uint32_t n_pieces = (v.N + kPiece - 1) / kPiece;
-  uint32_t piece = blockIdx.x * 4u + (uint32_t)wave;
-  const bool on = piece < n_pieces;  // (no early return: the workgroup meets again in cls_accumulate)
-  if (on && tile > 0) {
-    // Workgroups are dispatched in index order, so the few thousand pieces in flight at any time are
-    // consecutive indices.  In linear order those are a few whole x-planes of the grid -- seen face-on
-    // they cover the whole depth image of a frame.  Walking the (x-plane, piece-in-plane) rectangle in
-    // tiles of tile x tile keeps the pieces in flight inside a compact box, whose footprint in every
-    // frame's depth image is small enough for the frames of this launch to stay in L2 together.
-    const uint32_t ppx = (uint32_t)(((int64_t)v.ny * v.nz) / kPiece);  // pieces per x-plane (exact, checked by the host)
-    const uint32_t T = (uint32_t)tile, tj = ppx / T, per_tile = T * T;
-    const uint32_t t = piece / per_tile, r = piece - t * per_tile;
-    const uint32_t tx = t / tj, ty = t - tx * tj;
-    piece = (tx * T + r / T) * ppx + ty * T + (r - (r / T) * T);
-  }
-  const float rtrunc = 1.0f / v.trunc;
-  const bool tsdf_aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
-  unsigned long long nt_done = 0, tsdf_rows_done = 0;
-  if (on) {
-    const uint32_t nb = piece * (uint32_t)kPiece + (uint32_t)lane * 4u;
-    uint32_t mk4[4] = {0u, 0u, 0u, 0u};
-    classify_piece<4, SUM>(v, wa, s_cam, piece * (uint32_t)kPiece, lane, rtrunc, tsdf_aligned, mk4, nt_done, tsdf_rows_done);
-    if (nb + 3u < v.N) {
-      *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (nb + k < v.N) hitmask[nb + k] = mk4[k];
-    }
-  }
-  cls_accumulate(nt_done, tsdf_rows_done, lane, wave, s_acc, stats ? cls_acc : nullptr);
-}
-
-// ---- brick-shaped pieces: the classification of grids that tile into 4 x 4 x 16 bricks ----
+// ---- the classification: one launch per 32 frames of a window (one mask plane), a wave per 4 x 4 x 16 brick ----
+// ANY grid: bricks at the upper faces are partial (their lanes outside the grid are masked), the brick columns are walked
+// in 8 x 8 tiles over the brick grid padded to whole tiles (a wave whose brick lies in the padding has nothing to do).
+// (Rounds 1-3 had a second kernel over linear 256-voxel pieces for grids that do not tile into bricks -- the reference's own
+// 127 x 104 x 116, 61 x 60 x 59, ... --: no frame cull, 21 spilled registers.)
+// (One launch over all 64 frames of a window would keep the TSDF in registers twice as long but put 64 depth-image
+// footprints in L2 at once: 4.2 ms against 2 x 1.9 ms.)
 // A z-column piece is almost never outside a frame's view as a whole; a compact brick often is -- outside
 // the frustum, or farther than anything the frame has seen (z beyond the image's largest depth + trunc:
 // neither valid nor tsdf_valid).  The wave tests its brick against the launch's 32 frames lane-parallel
 // (lane k tests frame k: bounding sphere against the frustum planes and the depth bound, generous margins)
 // and classifies only the frames that survive; the arithmetic of the surviving frames is unchanged.
 constexpr int kBrickX = 4, kBrickY = 4, kBrickZ = 16;
-constexpr size_t kDmaxOff = 256;  // 32 floats in the workspace header: largest depth of each frame of a launch
+constexpr size_t kDmaxOff = 256;  // 2 x 32 floats in the workspace header: largest depth of each frame of a launch, smallest tile maximum
 
-// dmax[k] = max over the pixels of frame k of max(depth, 0) (NaN ignored, +inf kept): non-negative floats
-// order like their bit patterns, so an integer atomicMax does it.
-__global__ __launch_bounds__(256) void depth_max_kernel(ClsArgs wa, int hw, int* __restrict__ dmax_bits) {
+constexpr int kMaxDepthTiles = 4096;  // tiles per frame of the depth pyramid's one level (tile side 16 px, doubled until they fit)
+constexpr size_t kTileBytes = (size_t)kClsFrames * kMaxDepthTiles * sizeof(float);  // workspace: one launch's tile maxima
+
+// Largest depth of every frame of a launch, and of every tile of 2^ts_log2 x 2^ts_log2 pixels of it: max(depth, 0), NaN
+// ignored, +inf kept.  dmax_bits[k] (non-negative floats order like their bit patterns: an integer atomicMax) feeds the
+// coarse cull of a brick against a frame, tmax[k][tile] the fine one: a brick whose nearest voxel centre lies farther than
+// trunc behind the largest depth of the pixels it projects onto is OCCLUDED in that frame -- sdf < -1 for every voxel,
+// neither valid nor tsdf_valid (clipfusion.py:669-679) -- and is not classified at all.  One wave per tile.
+// (dmax[k] / dmax[kClsFrames + k], the largest / the SMALLEST of frame k's tile maxima, come from depth_reduce_kernel: a
+// brick nearer than the smallest tile maximum + trunc cannot be occluded anywhere in the frame and skips the tile lookups.
+// A first form added every tile's maximum to the two words of its frame with atomics: 2400 atomics per address and frame
+// serialise in L2 -- 0.3 ms per launch, more than the whole classification of a 128^3 grid.)
+__global__ __launch_bounds__(256) void depth_max_kernel(ClsArgs wa, int ts_log2, int tiles_x, int n_tiles, float* __restrict__ tmax) {
+  const int lane = threadIdx.x & 63, tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;
   const float* __restrict__ d = wa.depth[blockIdx.y];
+  const int ts = 1 << ts_log2, tx = tile % tiles_x, ty = tile / tiles_x;
   float m = 0.0f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
-    const float x = d[i];
-    m = x > m ? x : m;
+  // four loads in flight per lane (a 16 x 16 tile is exactly one round)
+  for (int i0 = lane; i0 < ts * ts; i0 += 256) {
+    float x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + 64 * k;
+      const int px = (tx << ts_log2) + (i & (ts - 1)), py = (ty << ts_log2) + (i >> ts_log2);
+      x[k] = (i < ts * ts && px < wa.W && py < wa.H) ? d[(size_t)py * wa.W + px] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = x[k] > m ? x[k] : m;
   }
   for (int o = 32; o > 0; o >>= 1) {
     const float t = __shfl_xor(m, o);
     m = t > m ? t : m;
   }
-  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(&dmax_bits[blockIdx.y], __builtin_bit_cast(int, m));
+  if (lane == 0) tmax[(size_t)blockIdx.y * kMaxDepthTiles + tile] = m;
+}
+// one workgroup per frame: the largest and the smallest of its tile maxima
+__global__ __launch_bounds__(256) void depth_reduce_kernel(const float* __restrict__ tmax, int n_tiles, float* __restrict__ dmax) {
+  __shared__ float s_hi[4], s_lo[4];
+  const float* __restrict__ t = tmax + (size_t)blockIdx.x * kMaxDepthTiles;
+  float hi = 0.0f, lo = INFINITY;
+  for (int i = threadIdx.x; i < n_tiles; i += 256) {
+    const float x = t[i];
+    hi = x > hi ? x : hi;
+    lo = x < lo ? x : lo;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float a = __shfl_xor(hi, o), b = __shfl_xor(lo, o);
+    hi = a > hi ? a : hi;
+    lo = b < lo ? b : lo;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_hi[threadIdx.x >> 6] = hi;
+    s_lo[threadIdx.x >> 6] = lo;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dmax[blockIdx.x] = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    dmax[kClsFrames + blockIdx.x] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+  }
 }
 
 template <bool SUM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE))) void classify_bricks_kernel(
-    KVol v, ClsArgs wa, int tiled, const float* __restrict__ dmax, uint32_t* __restrict__ hitmask,
+    KVol v, ClsArgs wa, const float* __restrict__ dmax, const float* __restrict__ tmax, int ts_log2, int tiles_x,
+    uint32_t* __restrict__ hitmask,
     unsigned long long* __restrict__ stats, unsigned long long* __restrict__ cls_acc, WinTable* __restrict__ tab) {
   __shared__ Cam s_cam[kClsFrames];
   __shared__ unsigned long long s_acc[4][2];
@@ -382,40 +367,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   file_frames(wa, tab, tid);
   __syncthreads();
   if (stats && wa.count && tid == 0 && blockIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n_f);
-  const uint32_t nbx = (uint32_t)v.nx / kBrickX, nby = (uint32_t)v.ny / kBrickY, nbz = (uint32_t)v.nz / kBrickZ;
-  const uint32_t q_raw = blockIdx.x * 4u + (uint32_t)wave;
-  const bool on = q_raw < nbx * nby * nbz;  // (no early return: the workgroup meets again in cls_accumulate)
-  const uint32_t q = on ? q_raw : 0u;
-  // bricks in flight form a compact box: z fastest, then 8 x 8 tiles of brick columns (32 x 32 voxels)
-  const uint32_t bz = q % nbz, t = q / nbz;
-  uint32_t bx, by;
-  if (tiled) {
-    const uint32_t tiles_y = nby / 8u, tt = t / 64u, r = t % 64u;
-    bx = (tt / tiles_y) * 8u + r / 8u;
-    by = (tt % tiles_y) * 8u + r % 8u;
-  } else {
-    bx = t / nby;
-    by = t % nby;
-  }
+  const uint32_t nbx = ((uint32_t)v.nx + kBrickX - 1) / kBrickX, nby = ((uint32_t)v.ny + kBrickY - 1) / kBrickY;
+  const uint32_t nbz = ((uint32_t)v.nz + kBrickZ - 1) / kBrickZ;
+  // bricks in flight form a compact box: z fastest, then 8 x 8 tiles of brick columns (32 x 32 voxels) over the padded brick grid
+  const uint32_t tiles_y = (nby + 7u) / 8u;
+  const uint32_t q = blockIdx.x * 4u + (uint32_t)wave;
+  const uint32_t bz = q % nbz, t = q / nbz, tt = t / 64u, r = t % 64u;
+  const uint32_t bx = (tt / tiles_y) * 8u + r / 8u, by = (tt % tiles_y) * 8u + r % 8u;
+  const bool on = bx < nbx && by < nby;  // (no early return: the workgroup meets again in cls_accumulate)
   const int ix = (int)bx * kBrickX + (lane & 3), iy = (int)by * kBrickY + ((lane >> 2) & 3);
   const int iz0 = (int)bz * kBrickZ + (lane >> 4) * 4;
-  const uint32_t nb = ((uint32_t)ix * (uint32_t)v.ny + (uint32_t)iy) * (uint32_t)v.nz + (uint32_t)iz0;
+  const bool col_in = on && ix < v.nx && iy < v.ny;
+  const int ixc = min(ix, v.nx - 1), iyc = min(iy, v.ny - 1);
+  const uint32_t nb = ((uint32_t)ixc * (uint32_t)v.ny + (uint32_t)iyc) * (uint32_t)v.nz + (uint32_t)min(iz0, v.nz - 1);
   float xw[4], yw[4], zw[4];
   bool inb[4];
-  const float x_l = v.ax[ix], y_l = v.ay[iy];
+  const float x_l = v.ax[ixc], y_l = v.ay[iyc];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     xw[j] = x_l;
     yw[j] = y_l;
-    zw[j] = v.az[iz0 + j];
-    inb[j] = true;
+    zw[j] = v.az[min(iz0 + j, v.nz - 1)];
+    inb[j] = col_in && iz0 + j < v.nz;
   }
   // ---- which frames can touch this brick at all?  lane k tests frame k
   uint32_t live;
   {
-    const float x0 = v.ax[bx * kBrickX], x1 = v.ax[bx * kBrickX + kBrickX - 1];
-    const float y0 = v.ay[by * kBrickY], y1 = v.ay[by * kBrickY + kBrickY - 1];
-    const float z0 = v.az[bz * kBrickZ], z1 = v.az[bz * kBrickZ + kBrickZ - 1];
+    // (the brick's voxel centres that lie inside the grid; a brick in the padding is clamped onto the grid: it is not classified)
+    const int bx0 = min((int)bx * kBrickX, v.nx - 1), by0 = min((int)by * kBrickY, v.ny - 1), bz0 = min((int)bz * kBrickZ, v.nz - 1);
+    const float x0 = v.ax[bx0], x1 = v.ax[min(bx0 + kBrickX - 1, v.nx - 1)];
+    const float y0 = v.ay[by0], y1 = v.ay[min(by0 + kBrickY - 1, v.ny - 1)];
+    const float z0 = v.az[bz0], z1 = v.az[min(bz0 + kBrickZ - 1, v.nz - 1)];
     const float cxw = 0.5f * (x0 + x1), cyw = 0.5f * (y0 + y1), czw = 0.5f * (z0 + z1);
     const float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
     const float rho = sqrtf(hx * hx + hy * hy + hz * hz) * 1.02f + 1e-4f;  // voxel CENTRES are what is tested
@@ -448,6 +430,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
         const float e2 = (c.k11 * yc + b2 * zc) / sqrtf(c.k11 * c.k11 + b2 * b2);
         const bool fx_pos = c.k00 > 0.0f, fy_pos = c.k11 > 0.0f;  // the usual orientation; otherwise no frustum cull
         dead = dead || (fx_pos && (d1 < -rho || d2 > rho)) || (fy_pos && (e1 < -rho || e2 > rho));
+        // ---- occlusion: the largest depth over the pixels the brick can project onto (SAF_CLS_OCCL=0 at build time: off).
+        // A voxel's pixel is round(u), u = k00 x / z + k02 (clipfusion.py:651-661 undone: grid_sample's un-normalisation gives
+        // back the pixel coordinate); over the sphere's bounding box x in [xc - rho, xc + rho], z in [zc - rho, zc + rho] (z > 0)
+        // u is monotone in x and in 1 / z: a conservative pixel rectangle, widened by a pixel, at most 16 tiles of it.
+        const float zn = zc - rho, zf = zc + rho;
+        if (SAF_CLS_OCCL && !dead && z_is_depth && fx_pos && fy_pos && zn > 1e-3f && zn > dmax[kClsFrames + lane] + v.trunc * 1.01f + 1e-4f) {
+          const float rn = 1.0f / zn, rf = 1.0f / zf;
+          const float xl = xc - rho, xh = xc + rho, yl = yc - rho, yh = yc + rho;
+          const float ul = c.k00 * (xl >= 0.0f ? xl * rf : xl * rn) + c.k02, uh = c.k00 * (xh >= 0.0f ? xh * rn : xh * rf) + c.k02;
+          const float vl = c.k11 * (yl >= 0.0f ? yl * rf : yl * rn) + c.k12, vh = c.k11 * (yh >= 0.0f ? yh * rn : yh * rf) + c.k12;
+          // (1e-3 relative for the reciprocals' rounding, a pixel for round-half-even and the reference's own arithmetic)
+          const float su = 1e-3f * (fabsf(ul) + fabsf(uh)) + 1.0f, sv = 1e-3f * (fabsf(vl) + fabsf(vh)) + 1.0f;
+          const int px0 = max((int)floorf(fmaxf(ul - su, -1.0f)), 0), px1 = min((int)ceilf(fminf(uh + su, c.fw)), wa.W - 1);
+          const int py0 = max((int)floorf(fmaxf(vl - sv, -1.0f)), 0), py1 = min((int)ceilf(fminf(vh + sv, c.fh)), wa.H - 1);
+          if (px0 <= px1 && py0 <= py1) {
+            const int tx0 = px0 >> ts_log2, tx1 = px1 >> ts_log2, ty0 = py0 >> ts_log2, ty1 = py1 >> ts_log2;
+            if (tx1 - tx0 < 4 && ty1 - ty0 < 4) {
+              // the 4 x 4 tiles from (tx0, ty0), clamped onto the rectangle (a tile may be read twice): 16 loads in flight
+              const float* __restrict__ tm = tmax + (size_t)lane * kMaxDepthTiles;
+              float t[16];
+#pragma unroll
+              for (int k = 0; k < 16; ++k) t[k] = tm[min(ty0 + (k >> 2), ty1) * tiles_x + min(tx0 + (k & 3), tx1)];
+              float m = 0.0f;
+#pragma unroll
+              for (int k = 0; k < 16; ++k) m = t[k] > m ? t[k] : m;
+              dead = zn > m + v.trunc * 1.01f + 1e-4f;  // (inf: never)
+            }
+          }
+        }
       }
     }
     live = on ? (uint32_t)__ballot(lane < n_f && !dead) : 0u;
@@ -458,7 +469,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   uint32_t mk4[4] = {0u, 0u, 0u, 0u};
   if (live)
     classify_voxels<SAF_CLS_FU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
-  if (on) *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);  // nz % 16 == 0: aligned
+  // every voxel of the grid gets its mask word (the row kernel reads them all); 16 bytes at once where the four lie in the grid
+  // and the run is aligned (always, when nz is a multiple of 4)
+  if (inb[3] && (nb & 3u) == 0u) {
+    *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (inb[j]) hitmask[nb + j] = mk4[j];
+  }
   cls_accumulate(nt_done, tsdf_rows_done, lane, wave, s_acc, stats ? cls_acc : nullptr);
 }
 
@@ -771,7 +790,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
     if (piece >= n_pieces) break;
     const bool mine = (uint32_t)(lane >> (6 - SAF_WIN_SPLIT_LOG2)) == (unit & ((1u << SAF_WIN_SPLIT_LOG2) - 1u));
     const uint32_t piece_base = piece * (uint32_t)kPiece;
-    // ---- the piece's touched voxels: (local id, frame mask) left by classify_window_kernel, compacted into LDS
+    // ---- the piece's touched voxels: (local id, frame mask) left by classify_bricks_kernel, compacted into LDS
     uint32_t mk4[4][kMaskWords];
     {
       const uint32_t nb = piece_base + (uint32_t)lane * 4u;
@@ -1240,7 +1259,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
 // window's frame bitmasks (kMaskWords words per voxel).
 // ---------------------------------------------------------------------------------------------
 struct WinLayout {
-  size_t img_bytes, maps_bytes, mask_bytes, cmax_off, total;
+  size_t img_bytes, maps_bytes, mask_bytes, tile_off, cmax_off, total;
   uint32_t mask_plane;
 };
 WinLayout win_layout(int64_t n_vox, int D, int P, bool bricks = false) {
@@ -1249,7 +1268,8 @@ WinLayout win_layout(int64_t n_vox, int D, int P, bool bricks = false) {
   w.maps_bytes = (size_t)kWin * w.img_bytes;
   w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
-  w.cmax_off = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;  // the brick form's channel maxima and camera table
+  w.tile_off = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;  // the classification's depth tile maxima (one launch's)
+  w.cmax_off = w.tile_off + kTileBytes;  // the brick form's channel maxima and camera table
   // the brick form's segment pools (6.5 GB at 256^3) only where that form can run: the row forms end at cmax_off
   w.total = w.cmax_off + (bricks ? brick_aux_bytes_est(n_vox, D) : 0);
   return w;
@@ -1384,12 +1404,14 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   }
   float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
   const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
-  const int tile_env = getenv("SAF_WIN_TILE") ? atoi(getenv("SAF_WIN_TILE")) : -1;
-  // grids that tile into 4 x 4 x 16 bricks classify brick by brick (SAF_WIN_BRICKS=0: always the linear pieces)
-  const bool bricks_on = !(getenv("SAF_WIN_BRICKS") && getenv("SAF_WIN_BRICKS")[0] == '0');
   const char* xcd_env = getenv("SAF_WIN_XCD");
-  static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kDmaxOff + 32 * sizeof(float) <= kClsAccOff,
+  static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kDmaxOff + 64 * sizeof(float) <= kClsAccOff,
                 "workspace header layout");
+  // the depth tiles of the classification's occlusion cull: 16 x 16 pixels, doubled until a frame has at most kMaxDepthTiles
+  int ts_log2 = 4;
+  while (((kf0.W + (1 << ts_log2) - 1) >> ts_log2) * ((kf0.H + (1 << ts_log2) - 1) >> ts_log2) > kMaxDepthTiles) ++ts_log2;
+  const int tiles_x = (kf0.W + (1 << ts_log2) - 1) >> ts_log2, n_tiles = tiles_x * ((kf0.H + (1 << ts_log2) - 1) >> ts_log2);
+  float* tmax = reinterpret_cast<float*>(ws + wl.tile_off);
   const int wlen = window_frames();
   const int n_win = (n_frames + wlen - 1) / wlen;
   auto win_frames = [&](int w) { return n_frames - w * wlen < wlen ? n_frames - w * wlen : wlen; };
@@ -1424,22 +1446,19 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const int n_units = (int)units.size();
 
   struct Geom {
-    uint32_t n_wgs, grid;
-    int tile, bricks, brick_tiles, xcd_order;
+    uint32_t cls_wgs, grid;  // workgroups of a classification launch (4 bricks each), of the row kernel
+    int xcd_order;
   };
   auto geom = [&](const KVol& u) {
     Geom g;
     const uint32_t n_pieces = (uint32_t)(((int64_t)u.N + kPiece - 1) / kPiece);
-    g.n_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
+    const uint32_t row_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
     g.grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : (of ? SAF_WIN_OF_WPE : 2));
-    if (g.grid > g.n_wgs) g.grid = g.n_wgs;
-    g.tile = tile_env >= 0 ? tile_env : 32;
-    const int64_t plane = (int64_t)u.ny * u.nz, ppx = plane / kPiece;
-    if (plane % kPiece != 0) g.tile = 0;
-    while (g.tile >= 8 && (ppx % g.tile != 0 || u.nx % g.tile != 0)) g.tile >>= 1;
-    if (g.tile < 8) g.tile = 0;  // linear order
-    g.bricks = bricks_on && u.nx % kBrickX == 0 && u.ny % kBrickY == 0 && u.nz % kBrickZ == 0;
-    g.brick_tiles = (u.nx / kBrickX) % 8 == 0 && (u.ny / kBrickY) % 8 == 0 ? 1 : 0;
+    if (g.grid > row_wgs) g.grid = row_wgs;
+    // the classification's bricks: the brick grid padded to whole 8 x 8 tiles of brick columns
+    const uint32_t tx = ((uint32_t)u.nx + 8 * kBrickX - 1) / (8 * kBrickX), ty = ((uint32_t)u.ny + 8 * kBrickY - 1) / (8 * kBrickY);
+    const uint32_t nbz = ((uint32_t)u.nz + kBrickZ - 1) / kBrickZ;
+    g.cls_wgs = (tx * ty * 64u * nbz + 3u) / 4u;
     // units of the row kernel in XCD-compact order (see the kernel); SAF_WIN_XCD=0: linear order
     g.xcd_order = !(xcd_env && xcd_env[0] == '0') && u.nx % 16 == 0 && u.ny % 16 == 0 && u.nz % kUnitVox == 0 && u.N % kPiece == 0 ? 1 : 0;
     return g;
@@ -1488,27 +1507,18 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
         ca.feat_map[k] = fr.feat_map;
       }
       uint32_t* plane = masks + (size_t)(fb / kClsFrames) * wl.mask_plane;
-      if (g.bricks) {  // the frames' largest depths feed the bricks' frame cull
-        if (hipMemsetAsync(dmax, 0, kClsFrames * sizeof(float), cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(dmax)");
-        hipLaunchKernelGGL(depth_max_kernel, dim3(32, ca.n), dim3(256), 0, cs, ca, kf0.H * kf0.W, reinterpret_cast<int*>(dmax));
-      }
+      // the frames' largest depths feed the bricks' frame cull
+      hipLaunchKernelGGL(depth_max_kernel, dim3((n_tiles + 3) / 4, ca.n), dim3(256), 0, cs, ca, ts_log2, tiles_x, n_tiles, tmax);
+      hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, cs, tmax, n_tiles, dmax);
       ScopedPair t(prof, 1, f0 + fb, cs);
-      if (g.bricks) {
-        if (sum)
-          hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(g.n_wgs), dim3(256), 0, cs, u.kv, ca, g.brick_tiles, dmax, plane,
-                             reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
-        else
-          hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(g.n_wgs), dim3(256), 0, cs, u.kv, ca, g.brick_tiles, dmax, plane,
-                             reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
-      } else if (sum) {
-        hipLaunchKernelGGL(classify_window_kernel<true>, dim3(g.n_wgs), dim3(256), 0, cs, u.kv, ca, g.tile, plane,
+      if (sum)
+        hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(g.cls_wgs), dim3(256), 0, cs, u.kv, ca, dmax, tmax, ts_log2, tiles_x, plane,
                            reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
-      } else {
-        hipLaunchKernelGGL(classify_window_kernel<false>, dim3(g.n_wgs), dim3(256), 0, cs, u.kv, ca, g.tile, plane,
+      else
+        hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(g.cls_wgs), dim3(256), 0, cs, u.kv, ca, dmax, tmax, ts_log2, tiles_x, plane,
                            reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
-      }
     }
-    int r = check_launch("classify_window_kernel");
+    int r = check_launch("classify_bricks_kernel");
     if (r) return r;
     if (split) {  // the brick form's build kernel: the window's hit records, sorted groups and scalar side, into the segment pool
       WinArgs wa;

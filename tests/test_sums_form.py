@@ -25,7 +25,8 @@ CASES = [
     ((31, 26, 29), 768, False, _abi.SAF_RUNNING_MEAN, 33, torch.float32, "B", None),    # three pieces per row; ragged grid
     ((31, 26, 29), 512, True, _abi.SAF_RUNNING_MEAN, 300, torch.float32, "A", (40, 100)),  # three windows: rows written, then read
     ((29, 33, 27), 512, False, _abi.SAF_SUM, 20, torch.float32, "B", None),
-    ((61, 60, 59), 512, True, _abi.SAF_RUNNING_MEAN, 48, torch.float32, "B", None),     # a grid size of the reference (voxel_grid_compare.md)
+    ((61, 60, 59), 512, True, _abi.SAF_RUNNING_MEAN, 48, torch.float32, "B", None),     # grid sizes of the reference (voxel_grid_compare.md):
+    ((57, 56, 55), 512, False, _abi.SAF_RUNNING_MEAN, 140, torch.float32, "A", None),   # partial bricks on every upper face, nz % 4 != 0
     ((33, 30, 41), 512, True, _abi.SAF_RUNNING_MEAN, 36, torch.bfloat16, "B", None),
     ((40, 24, 56), 1024, False, _abi.SAF_RUNNING_MEAN, 131, torch.bfloat16, "A", (3, 90)),
     ((16, 16, 64), 512, False, _abi.SAF_RUNNING_MEAN, 260, torch.bfloat16, "B", (0, 260)),  # a camera at rest: weights up to 260

@@ -67,6 +67,59 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
   if (acc == 12345.678f) sink[0] = acc;  // never true: keeps the loop alive without a store
 }
 
+// MIX: what the row kernel's L1 path really carries -- per batch NB pieces of L2-resident rows (the map taps) and, every
+// `every`-th batch, NR pieces of rows from a table far larger than every cache, each read once (the old feature rows: HBM
+// latency, nontemporal).  Do the slow requests hold up the fast ones?  `sink` also receives NW pieces of stores per such
+// batch when stores != 0 (the rows going back).
+template <int NB, int NR>
+__global__ __launch_bounds__(256) void mix_kernel(const float4* __restrict__ table, uint32_t n_rows, uint32_t table_bytes,
+                                                  const float4* __restrict__ big, uint32_t big_rows, float4* __restrict__ out,
+                                                  int iters, int every, int stores, uint32_t seed) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+  uint32_t s = seed ^ (wave_id * 2654435761u);
+  s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(table), 0, (int)table_bytes, 0x00020000);
+  float acc = 0.0f;
+  for (int it = 0; it < iters; ++it) {
+    float4 r[NR];
+    const bool slow = every > 0 && it % every == 0;
+    if (slow) {
+      s = s * 1664525u + 1013904223u;
+      const uint32_t row = (uint32_t)(((uint64_t)(s >> 4) * big_rows) >> 28);
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(big) + (size_t)row * (NR * 64), 0, NR * 1024, 0x00020000);
+#pragma unroll
+      for (int p = 0; p < NR; ++p) r[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16 + p * 1024, 0, 2));
+    }
+    float4 t[NB];
+#pragma unroll
+    for (int k = 0; k < NB / 2; ++k) {
+      s = s * 1664525u + 1013904223u;
+      const uint32_t row = (uint32_t)(((uint64_t)(s >> 4) * n_rows) >> 28);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        t[2 * k + p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((row * 2u + p) * 1024u + lane * 16u), 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) asm volatile("" ::"v"(t[k].x), "v"(t[k].y), "v"(t[k].z), "v"(t[k].w));
+    acc += t[0].x;
+    if (slow) {
+#pragma unroll
+      for (int p = 0; p < NR; ++p) asm volatile("" ::"v"(r[p].x), "v"(r[p].y), "v"(r[p].z), "v"(r[p].w));
+      if (stores) {
+        s = s * 1664525u + 1013904223u;
+        const uint32_t row = (uint32_t)(((uint64_t)(s >> 4) * big_rows) >> 28);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)row * (NR * 64), 0, NR * 1024, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < NR; ++p)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, r[p]), rr, lane * 16 + p * 1024, 0, 2);
+      }
+    }
+  }
+  if (acc == 12345.678f) out[0] = make_float4(acc, 0, 0, 0);
+}
+
 using Fn = void (*)(const float4*, uint32_t, uint32_t, int, uint32_t, float*);
 
 struct Variant {
@@ -86,6 +139,49 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&table, max_table));
   CK(hipMalloc(&sink, 64));
   CK(hipMemset(table, 0, max_table));
+  if (argc > 1 && argv[1][0] == 'm') {  // the mixed stream
+    // "mix" = an 8 GB table (HBM); "mix64" etc. = a table of that many MB, read over and over: after the first pass it lives in
+    // the 256 MB Infinity Cache -- what the slow rows would cost if something had brought them there ahead of time
+    const size_t big_bytes = argv[1][3] ? (size_t)atoi(argv[1] + 3) << 20 : 8ull << 30;
+    float4 *big, *out;
+    CK(hipMalloc(&big, big_bytes));
+    CK(hipMalloc(&out, big_bytes));
+    CK(hipMemset(big, 0, big_bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const uint32_t tb = 2u << 20, n_rows = tb / 2048u, big_rows = (uint32_t)(big_bytes / 2048u);
+    printf("# per batch 16 pieces of 2 KiB rows from a 2 MB table (L2) + every k-th batch one 2 KiB row of a %zu MB table (nt)\n", big_bytes >> 20);
+    for (int wpc : {8, 16}) {
+      for (int every : {0, 4, 2, 1}) {
+        for (int stores : {0, 1}) {
+          if (every == 0 && stores) continue;
+          const int grid = cus * wpc / 4;
+          const int iters = 2048;
+          hipLaunchKernelGGL((mix_kernel<16, 2>), dim3(grid), dim3(256), 0, 0, table, n_rows, tb, big, big_rows, out, iters / 4, every, stores, 1u);
+          CK(hipDeviceSynchronize());
+          float best = 1e30f;
+          for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((mix_kernel<16, 2>), dim3(grid), dim3(256), 0, 0, table, n_rows, tb, big, big_rows, out, iters, every, stores, 7u + rep);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+          }
+          const double waves = (double)grid * 4;
+          const double fast_gb = waves * iters * 16 * 1024.0 / 1e9;
+          const double slow_gb = every ? waves * (iters / every) * 2 * 1024.0 / 1e9 : 0.0;
+          printf("waves/CU %2d  slow row every %2d batches%s: %7.3f ms  L2 rows %6.2f TB/s  + HBM rows %5.2f TB/s read%s  (slow share of requests %4.1f %%)\n",
+                 wpc, every, stores ? " + stored back" : "              ", best, fast_gb / best, slow_gb / best,
+                 stores ? " and as much written" : "", 100.0 * slow_gb / (slow_gb + fast_gb + 1e-30));
+          fflush(stdout);
+        }
+      }
+    }
+    return 0;
+  }
   const Variant vars[] = {
       {"buffer_load x 8 pieces (2 KiB rows)", gather_kernel<8, 2, 0>, 8, 2},
       {"buffer_load x 16 pieces (2 KiB rows: the row kernel's 2 tap groups)", gather_kernel<16, 2, 0>, 16, 2},

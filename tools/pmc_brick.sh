@@ -1,10 +1,12 @@
 #!/bin/bash
-# PMC passes over the brick form of the window row kernel (run on a GPU box), one fresh 128-frame window, no
-# classification beside it: HBM bytes (FETCH_SIZE x 2 on gfx950, WRITE_SIZE), wave activity, LDS, L1 -> L2 requests, TA.
-# Usage: bash tools/pmc_brick.sh <outdir> [extra bench args]
+# PMC passes over the window's kernels (run on a GPU box): the row kernel in the form SAF_WIN_FORM selects (sums / rows / bricks)
+# and the classification, one after the other on one stream (SAF_WIN_OVERLAP=0): HBM bytes (FETCH_SIZE x 2 on gfx950,
+# WRITE_SIZE), wave activity, LDS, L1 -> L2 requests, TA.  Default: one fresh 128-frame window; FRAMES=512: the whole job
+# (per-launch averages over its four windows: the first is fresh, the others read most of their rows).
+# Usage: [FRAMES=512] bash tools/pmc_brick.sh <outdir> [extra bench args]
 OUT=${1:-gpurun_out/pmcbrick}; shift
 mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python3 bench.py --cpu-frames 0 --frames 128 --steps 1 --warmup 0 --no-profile-events $*"
+B="python3 bench.py --cpu-frames 0 --frames ${FRAMES:-128} --steps 1 --warmup 0 --no-profile-events --no-side --end-to-end 0 $*"
 export SAF_WIN_OVERLAP=0
 run() { name=$1; shift; timeout -k 5 100 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- $B > $OUT/$name.json 2> $OUT/$name.err || echo "FAILED $name"; }
 run a FETCH_SIZE &&
@@ -20,6 +22,8 @@ import csv, glob, json, collections, os
 def kind(name):
     if "fuse_window" in name:
         return "rows"
+    if "classify_bricks" in name or "classify_window" in name:
+        return "classify"
     if "fuse_brick" in name:  # fuse_brick_kernel<CPL, SUM, BF16, BUILD>: the last template argument tells the two kernels apart
         return "build" if name.split(">(")[0].rstrip().endswith("true") else "walk"
     return None
