@@ -470,7 +470,7 @@ def main():
         # from the committed rocprofv3 --pmc passes of this same command (tools/profile.sh, newest round first)
         traffic, traffic_source = None, None
         kname = "fuse_window_kernel" if windowed else "fuse_kernel"
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             rel = os.path.join("profiles", rnd, "window_traffic.json" if windowed else "fuse_traffic.json")
             try:
                 tj = json.load(open(os.path.join(ROOT, rel)))
@@ -512,16 +512,19 @@ def main():
                         "the window form moves %.0f %% of the bytes a frame-at-a-time fusion must move (rows travel once per "
                         "window of %d frames instead of once per frame): `frac` prices the bytes this kernel is left with, "
                         "so it FALLS when a longer window removes bytes faster than time" % (100.0 * frame_bytes / single, WIN)}
-            try:  # what the kernel is actually bound by: L2 -> L1 gathers (map taps), from the committed PMC pass
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "rowpath_pmc.json")))
+            try:  # what the kernel is bound by: the L2 -> L1 path with HBM-latency requests mixed in (committed PMC pass + probe)
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r04", "rows_pmc.json")))["rows"]
                 if a.grid == 256 and a.dim == 512 and a.depth_kind == "A" and a.feat_dtype == "f32" and not a.labels and WIN == 128:
                     gb = pj["TCP_TCC_READ_REQ_sum"] * 128.0
                     roofline["l2_gather"] = {
-                        "bytes_per_launch": int(gb), "launch_us": round(pj["us_pass_d"], 1),
-                        "achieved_TBps": round(gb / pj["us_pass_d"] / 1e6, 2), "ceiling_TBps": [16.8, 18.8],
-                        "source": "profiles/r02/rowpath_pmc.json (rocprofv3 --pmc TCP_TCC_READ_REQ_sum x 128 B over the kernel's "
-                                  "duration in that pass: one fresh 128-frame window, earlier box); ceiling = "
-                                  "MI355X_MICROARCH.md, gathers of L2-resident rows"}
+                        "bytes_per_launch": int(gb), "launch_us": round(pj["us_pass_e"], 1),
+                        "achieved_TBps": round(gb / pj["us_pass_e"] / 1e6, 2),
+                        "ceiling_TBps": {"L2-resident 2 KiB rows alone (tools/gather_probe.hip)": [32.2, 34.4],
+                                         "the same with one HBM row read and written back per two batches of 16 KiB (5.9 % of the "
+                                         "requests; this kernel has one per 1.4 batches)": [16.1, 18.6]},
+                        "source": "profiles/r04/rows_pmc.json (rocprofv3 --pmc TCP_TCC_READ_REQ_sum x 128 B over the kernel's duration in "
+                                  "that pass: the four windows of one 512-frame job, nothing beside the kernel, earlier box); ceilings: "
+                                  "profiles/r04/gather_probe.log, gather_probe_mix.log -- 8, 12 or 16 waves per CU alike"}
             except Exception:
                 pass
             form = os.environ.get("SAF_WIN_FORM", "sums")

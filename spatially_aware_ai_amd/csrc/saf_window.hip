@@ -125,6 +125,12 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_WIN_ABL
 #define SAF_WIN_ABL 0  // development: ablations of the order-free kernel (WRONG results): 1 taps "outside" (instructions issue, no
 #endif                 // request), 2 no tap instructions, 4 no row loads, 8 no row stores, 16 no multiply-adds
+#ifndef SAF_WIN_OF_LDPOL
+#define SAF_WIN_OF_LDPOL 2  // cache policy of the order-free kernel's row loads / stores (aux bits of the buffer instructions: 2 = nt)
+#endif
+#ifndef SAF_WIN_OF_STPOL
+#define SAF_WIN_OF_STPOL 2
+#endif
 #ifndef SAF_WIN_OF_WPE
 #define SAF_WIN_OF_WPE 2  // waves per SIMD the order-free kernel's register budget is set for
 #endif
@@ -1094,7 +1100,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
                   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(feat + row, 0, v.D * 4, 0x00020000);
 #pragma unroll
                   for (int c = 0; c < CPL; ++c) {
-                    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16 + c * 1024, 0, 2));
+                    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16 + c * 1024, 0, SAF_WIN_OF_LDPOL));
                     acc[r][2 * c] = (win_v2f){t.x, t.y};
                     acc[r][2 * c + 1] = (win_v2f){t.z, t.w};
                   }
@@ -1217,7 +1223,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
                   if (SAF_WIN_ABL & 8)
                     asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
                   else
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(win_v4u, o), rr, lane * 16 + c * 1024, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(win_v4u, o), rr, lane * 16 + c * 1024, 0, SAF_WIN_OF_STPOL);
                 }
               }
             } else if (BF16) {
