@@ -296,10 +296,14 @@ __device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsig
 // (lane k tests frame k: bounding sphere against the frustum planes and the depth bound, generous margins)
 // and classifies only the frames that survive; the arithmetic of the surviving frames is unchanged.
 constexpr int kBrickX = 4, kBrickY = 4, kBrickZ = 16;
-constexpr size_t kDmaxOff = 256;  // 2 x 32 floats in the workspace header: largest depth of each frame of a launch, smallest tile maximum
 
 constexpr int kMaxDepthTiles = 4096;  // tiles per frame of the depth pyramid's one level (tile side 16 px, doubled until they fit)
-constexpr size_t kTileBytes = (size_t)kClsFrames * kMaxDepthTiles * sizeof(float);  // workspace: one launch's tile maxima
+// workspace: the tile maxima of up to kTileWindows windows of a call (a window's slabs, and the same window of later slabs of a
+// slab-by-slab call, reuse them: 128 depth launches of a 512-frame job in eight slabs were 4.7 % of it), each window: 4 KB for
+// the frames' largest / smallest tile maximum, then kWin x kMaxDepthTiles floats
+constexpr int kTileWindows = 8;
+constexpr size_t kTileWinBytes = 4096 + (size_t)kWin * kMaxDepthTiles * sizeof(float);
+constexpr size_t kTileBytes = kTileWindows * kTileWinBytes;
 
 // Largest depth of every frame of a launch, and of every tile of 2^ts_log2 x 2^ts_log2 pixels of it: max(depth, 0), NaN
 // ignored, +inf kept.  dmax_bits[k] (non-negative floats order like their bit patterns: an integer atomicMax) feeds the
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256) void depth_reduce_kernel(const float* __restri
   __syncthreads();
   if (threadIdx.x == 0) {
     dmax[blockIdx.x] = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
-    dmax[kClsFrames + blockIdx.x] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    dmax[kWin + blockIdx.x] = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
   }
 }
 
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
         // back the pixel coordinate); over the sphere's bounding box x in [xc - rho, xc + rho], z in [zc - rho, zc + rho] (z > 0)
         // u is monotone in x and in 1 / z: a conservative pixel rectangle, widened by a pixel, at most 16 tiles of it.
         const float zn = zc - rho, zf = zc + rho;
-        if (SAF_CLS_OCCL && !dead && z_is_depth && fx_pos && fy_pos && zn > 1e-3f && zn > dmax[kClsFrames + lane] + v.trunc * 1.01f + 1e-4f) {
+        if (SAF_CLS_OCCL && !dead && z_is_depth && fx_pos && fy_pos && zn > 1e-3f && zn > dmax[kWin + lane] + v.trunc * 1.01f + 1e-4f) {
           const float rn = 1.0f / zn, rf = 1.0f / zf;
           const float xl = xc - rho, xh = xc + rho, yl = yc - rho, yh = yc + rho;
           const float ul = c.k00 * (xl >= 0.0f ? xl * rf : xl * rn) + c.k02, uh = c.k00 * (xh >= 0.0f ? xh * rn : xh * rf) + c.k02;
@@ -1411,13 +1415,14 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
   const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
   const char* xcd_env = getenv("SAF_WIN_XCD");
-  static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kDmaxOff + 64 * sizeof(float) <= kClsAccOff,
+  static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kClsAccOff >= 256,
                 "workspace header layout");
   // the depth tiles of the classification's occlusion cull: 16 x 16 pixels, doubled until a frame has at most kMaxDepthTiles
   int ts_log2 = 4;
   while (((kf0.W + (1 << ts_log2) - 1) >> ts_log2) * ((kf0.H + (1 << ts_log2) - 1) >> ts_log2) > kMaxDepthTiles) ++ts_log2;
   const int tiles_x = (kf0.W + (1 << ts_log2) - 1) >> ts_log2, n_tiles = tiles_x * ((kf0.H + (1 << ts_log2) - 1) >> ts_log2);
-  float* tmax = reinterpret_cast<float*>(ws + wl.tile_off);
+  int tile_window[kTileWindows];  // which window's tile maxima a slot of the tile region holds (-1: none)
+  for (int k = 0; k < kTileWindows; ++k) tile_window[k] = -1;
   const int wlen = window_frames();
   const int n_win = (n_frames + wlen - 1) / wlen;
   auto win_frames = [&](int w) { return n_frames - w * wlen < wlen ? n_frames - w * wlen : wlen; };
@@ -1495,7 +1500,12 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     const int F = u.F, f0 = u.f0, par = ui & 1;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
-    float* dmax = reinterpret_cast<float*>(hdr + kDmaxOff);
+    // the window's depth tile maxima: computed when a unit of the window first needs them
+    const int widx = f0 / wlen, tslot = widx % kTileWindows;
+    float* dmax_w = reinterpret_cast<float*>(ws + wl.tile_off + (size_t)tslot * kTileWinBytes);  // [kWin] largest, [kWin] smallest
+    float* tmax_w = dmax_w + 1024;
+    const bool tiles_cached = tile_window[tslot] == widx;
+    tile_window[tslot] = widx;
     unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
     WinTable* tab = reinterpret_cast<WinTable*>(hdr + kTableOff);
     mark("classify: begin", ui);
@@ -1514,8 +1524,12 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       }
       uint32_t* plane = masks + (size_t)(fb / kClsFrames) * wl.mask_plane;
       // the frames' largest depths feed the bricks' frame cull
-      hipLaunchKernelGGL(depth_max_kernel, dim3((n_tiles + 3) / 4, ca.n), dim3(256), 0, cs, ca, ts_log2, tiles_x, n_tiles, tmax);
-      hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, cs, tmax, n_tiles, dmax);
+      float* dmax = dmax_w + fb;
+      float* tmax = tmax_w + (size_t)fb * kMaxDepthTiles;
+      if (!tiles_cached) {
+        hipLaunchKernelGGL(depth_max_kernel, dim3((n_tiles + 3) / 4, ca.n), dim3(256), 0, cs, ca, ts_log2, tiles_x, n_tiles, tmax);
+        hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, cs, tmax, n_tiles, dmax);
+      }
       ScopedPair t(prof, 1, f0 + fb, cs);
       if (sum)
         hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(g.cls_wgs), dim3(256), 0, cs, u.kv, ca, dmax, tmax, ts_log2, tiles_x, plane,
