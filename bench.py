@@ -89,6 +89,9 @@ def parse():
                     help="ClipSeemFusion path: panoptic label histogram + bilinear rgb (BASELINE config 3)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes of one job after the timed "
+                         "regions, about a minute); the committed profiles/ figure is quoted instead")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side workloads of the default single-GPU run (configs 2, 3, 5, the coherent scene, the HBM copy rate)")
     ap.add_argument("--end-to-end", type=int, default=-1, metavar="FRAMES",
@@ -716,6 +719,14 @@ def main():
     if roofline is not None and copy_rate is not None:
         roofline["hbm_copy_GBps"] = copy_rate
         roofline["frac_of_copy_rate"] = round(roofline["achieved"] / copy_rate, 4)
+    # ---- roofline.traffic measured in THIS run (rank 0, N = 1, the default command): PMC counters cannot be read in-process, so
+    #      one job is run twice more as a child under rocprofv3 --pmc (FETCH_SIZE, then WRITE_SIZE: separate passes)
+    if roofline is not None and side is not None and not a.no_pmc and roofline.get("kernel") == "fuse_window_kernel":
+        m = measure_traffic(a)
+        if m is not None:
+            roofline["traffic"] = m["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = m["source"]
+            roofline["traffic_read_bytes"], roofline["traffic_write_bytes"] = m["read"], m["write"]
 
     # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N=1 only) ----
     cpu = None
@@ -773,6 +784,50 @@ def main():
 
 def windowed_headline(st):
     return st.get("window_rows", 0) > 0
+
+
+def measure_traffic(a, timeout_s=150):
+    """HBM bytes per window of fuse_window_kernel, measured now: this script runs ONE job (512 frames, no warm-up, no side work)
+    as a child process under `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes; output under
+    /tmp), the per-launch counter values of the row kernel are averaged.  FETCH_SIZE is doubled (on gfx950 it reports half the
+    bytes of wide coalesced reads: MI355X_MICROARCH.md, HBM section), both are KiB.  None if the profiler is not there or a
+    pass fails -- the committed figure stays in the line then."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None  # this process is itself being profiled (tools/profile.sh): no profiler inside a profiler
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="saf_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+               os.path.abspath(__file__), "--cpu-frames", "0", "--steps", "1", "--warmup", "0", "--no-profile-events", "--no-side",
+               "--end-to-end", "0", "--no-pmc", "--frames", str(a.frames), "--grid", str(a.grid), "--dim", str(a.dim),
+               "--depth-kind", a.depth_kind]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            per = []
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "fuse_window_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        per.append(float(r["Counter_Value"]))
+            if not per:
+                return None
+            vals[counter] = sum(per) / len(per)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    read, write = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
+    return {"read": int(read), "write": int(write), "hbm_bytes_per_launch": int(read + write),
+            "source": "measured in this run: one job as a child process under rocprofv3 --pmc FETCH_SIZE and again under --pmc "
+                      "WRITE_SIZE (separate passes), mean over the job's row-kernel launches; FETCH_SIZE x 2 (gfx950), KiB -> bytes"}
 
 
 def hbm_copy_rate(device, nbytes=4 << 30, reps=3):

@@ -126,12 +126,20 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
 
 /* The same for n_frames frames in order (host array of descriptors); one host call, no host
  * synchronisation between frames -- the loop of clipfusion.py:1125-1133.
- * Two device paths, identical results bit for bit:
+ * Two device paths.  Which voxels are touched, weights, tsdf, tsdf_weight, rgb and label counts are identical bit for bit
+ * on both; so are the feature rows with SAF_WIN_FORM=rows:
  *  - per-frame pipeline: one sweep + one fuse kernel per frame (any shape);
- *  - windowed, voxel-major (16 or more frames of one shape; f32 volume with feat_dim a multiple of 256, or
- *    bf16 volume with feat_dim a multiple of 512; feat_dim <= 1024): per window of SAF_WINDOW_FRAMES frames one classification launch per 32 frames (sweep,
- *    TSDF in registers, one frame-mask word per voxel) and one row kernel that reads and writes every
- *    touched feature row once per window.
+ *  - windowed, voxel-major (16 or more frames of one shape, feat_dim a multiple of 64 up to 8192): per window of
+ *    SAF_WINDOW_FRAMES frames one classification launch per 32 frames (projection, depth test, TSDF in registers, one
+ *    frame-mask word per voxel; any grid) and one row kernel that reads and writes every touched feature row ONCE per
+ *    window.  The row kernel's form (environment SAF_WIN_FORM, read per call):
+ *      sums   (default where it applies: f32 volume with feat_dim a multiple of 256, bf16 with a multiple of 512, <= 1024) a
+ *             row's samples of the window are summed in registers and the row is blended once, (w0 old + sum) / (w0 + k): the
+ *             running mean of clipfusion.py:715-721 with the window's k updates folded into one -- feature values within fp32
+ *             rounding of frame-after-frame fusion (bf16: one rounding per window instead of one per hit), reproducible
+ *             bit for bit from run to run;
+ *      rows   the same widths, hits applied one by one in frame order: feature rows bit-identical to the per-frame pipeline;
+ *      bricks every other width (and on request): brick-resident rows, map taps shared, fixed-point sums; same contract as sums.
  *    SAF_WINDOW=0 in the environment forces the per-frame pipeline. */
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
                     void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream);

@@ -1,7 +1,9 @@
-// saf_window.hip -- the windowed, voxel-major path of saf_fuse_frames: per window of
-// 64 frames two classification launches (32 frames each: sweep + TSDF in registers, one frame-mask plane) and one
-// row kernel that reads and writes every touched feature row once.  Bit-identical to the per-frame pipeline of
-// saf_fuse.hip; selected by saf_fuse_frames for calls of 16 or more frames of one shape.
+// saf_window.hip -- the windowed, voxel-major path of saf_fuse_frames: per window of 128 frames four
+// classification launches (32 frames each: projection, depth test, TSDF in registers, one frame-mask plane; any grid; a frame
+// and occlusion cull per brick) and one row kernel that reads and writes every touched feature row once -- in its order-free
+// form (a row's samples summed in registers, one blend per row: section 4.6c; the default) or its frame-ordered form
+// (SAF_WIN_FORM=rows: bit-identical to the per-frame pipeline of saf_fuse.hip).  Selected by saf_fuse_frames for calls of 16
+// or more frames of one shape.  The host side schedules a call as a list of (sub-volume, window) units.
 #include <chrono>
 #include <vector>
 
@@ -16,17 +18,17 @@ namespace {
 // is the zero row of the taps outside the map.
 
 // ------------------------------------------------------------------------------------------
-// fuse, voxel-major over a WINDOW of up to 64 frames (saf_fuse_frames with many frames).
+// fuse, voxel-major over a WINDOW of up to 128 frames (saf_fuse_frames with many frames).
 //
 // A running mean is applied hit by hit, but nothing forces a row to travel to HBM between two hits.
 // Per window, on the caller's stream:
 //   classify_bricks_kernel  (one launch per 32 frames) every voxel against 32 frames (the full-grid sweep of
 //                           clipfusion.py:647-695): TSDF running mean kept in registers across the frames
 //                           and written once, one 32-bit frame mask per voxel into that launch's mask plane;
-//   fuse_window_kernel      every touched voxel's D-row is read ONCE, the voxel's hits are applied in frame
-//                           order -- the same s*a + old*b with a = 1/(w+1), so the result is bit-identical to
-//                           fusing the frames one after the other -- and written ONCE.  Row bytes fall by the
-//                           window's hits-per-voxel ratio (1.8 for incoherent depth, 7 for a coherent scene).
+//   fuse_window_kernel      every touched voxel's D-row is read ONCE, the voxel's hits are applied -- frame-ordered form: in
+//                           frame order, the same s*a + old*b with a = 1/(w+1), bit-identical to fusing the frames one
+//                           after the other; order-free form: summed, then one blend -- and written ONCE.  Row bytes fall by
+//                           the window's hits-per-voxel ratio (2.8 for incoherent depth, 14 for a coherent scene).
 //
 // fuse_window_kernel: waves work independently (no workgroup barrier after the prologue).  A wave takes
 // pieces of 256 consecutive voxels, compacts the touched ones, and per chunk of <= 64 touched voxels
@@ -103,6 +105,9 @@ __device__ unsigned long long g_win_t[16];
 #endif
 #ifndef SAF_CLS_OCCL
 #define SAF_CLS_OCCL 1  // the occlusion cull of the classification (depth tile maxima); 0: the frame-wide largest depth only
+#endif
+#ifndef SAF_CLS_BOX
+#define SAF_CLS_BOX 1  // the brick's frame cull tests the box's extents (0: its bounding sphere, rounds 2-3)
 #endif
 #ifndef SAF_CLS_FU
 #define SAF_CLS_FU 1   // frames classified together: with the frame cull, occupancy hides the depth gathers better than batching does (1: 1.13 ms, 2: 1.17, 4: 1.29, 8: 2.08 per launch)
@@ -429,25 +434,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
       const bool rigid = fabsf(n0 - 1.0f) < 1e-3f && fabsf(n1 - 1.0f) < 1e-3f && fabsf(n2 - 1.0f) < 1e-3f &&
                          fabsf(d01) < 1e-3f && fabsf(d02) < 1e-3f && fabsf(d12) < 1e-3f;
       const bool z_is_depth = c.k20 == 0.0f && c.k21 == 0.0f && c.k22 == 1.0f;
-      dead = rigid && z_is_depth && (zc + rho <= 0.0f || zc - rho > far_z);
+      // (SAF_CLS_BOX, round 4: the brick is 4 x 4 x 16 voxels -- its bounding sphere is four times as wide as the brick is
+      //  across -- so the tests use the BOX's extent along each direction instead: for a direction n in camera space the
+      //  box reaches |n . ex| hx + |n . ey| hy + |n . ez| hz from its centre, ex / ey / ez = the world axes in camera space)
+      const float mg = 1.02f, me = 1e-4f;
+      const float ext_x = SAF_CLS_BOX ? (fabsf(c.r00) * hx + fabsf(c.r10) * hy + fabsf(c.r20) * hz) * mg + me : rho;
+      const float ext_y = SAF_CLS_BOX ? (fabsf(c.r01) * hx + fabsf(c.r11) * hy + fabsf(c.r21) * hz) * mg + me : rho;
+      const float ext_z = SAF_CLS_BOX ? (fabsf(c.r02) * hx + fabsf(c.r12) * hy + fabsf(c.r22) * hz) * mg + me : rho;
+      dead = rigid && z_is_depth && (zc + ext_z <= 0.0f || zc - ext_z > far_z);
       if (pinhole && rigid) {
         // in view <=> -0.5 <= u/z <= W - 0.5 and -0.5 <= v/z <= H - 0.5 with u = k00 x + k02 z, v = k11 y + k12 z:
-        // four planes through the camera centre; the brick is outside if its centre is farther than rho behind one
+        // four planes through the camera centre; the brick is outside if its centre is farther than its reach behind one
         const float a1 = c.k02 + 0.5f, a2 = c.k02 - c.fw + 0.5f, b1 = c.k12 + 0.5f, b2 = c.k12 - c.fh + 0.5f;
-        const float d1 = (c.k00 * xc + a1 * zc) / sqrtf(c.k00 * c.k00 + a1 * a1);
-        const float d2 = (c.k00 * xc + a2 * zc) / sqrtf(c.k00 * c.k00 + a2 * a2);
-        const float e1 = (c.k11 * yc + b1 * zc) / sqrtf(c.k11 * c.k11 + b1 * b1);
-        const float e2 = (c.k11 * yc + b2 * zc) / sqrtf(c.k11 * c.k11 + b2 * b2);
+        auto reach = [&](float nx, float ny, float nz) {  // of the box along (nx, ny, nz) (camera space, not normalised)
+          return (fabsf(nx * c.r00 + ny * c.r01 + nz * c.r02) * hx + fabsf(nx * c.r10 + ny * c.r11 + nz * c.r12) * hy +
+                  fabsf(nx * c.r20 + ny * c.r21 + nz * c.r22) * hz) * mg;
+        };
+        const float n1 = sqrtf(c.k00 * c.k00 + a1 * a1), n2 = sqrtf(c.k00 * c.k00 + a2 * a2);
+        const float m1 = sqrtf(c.k11 * c.k11 + b1 * b1), m2 = sqrtf(c.k11 * c.k11 + b2 * b2);
+        const float d1 = (c.k00 * xc + a1 * zc) / n1, d2 = (c.k00 * xc + a2 * zc) / n2;
+        const float e1 = (c.k11 * yc + b1 * zc) / m1, e2 = (c.k11 * yc + b2 * zc) / m2;
+        const float rd1 = SAF_CLS_BOX ? reach(c.k00, 0.0f, a1) / n1 + me : rho, rd2 = SAF_CLS_BOX ? reach(c.k00, 0.0f, a2) / n2 + me : rho;
+        const float re1 = SAF_CLS_BOX ? reach(0.0f, c.k11, b1) / m1 + me : rho, re2 = SAF_CLS_BOX ? reach(0.0f, c.k11, b2) / m2 + me : rho;
         const bool fx_pos = c.k00 > 0.0f, fy_pos = c.k11 > 0.0f;  // the usual orientation; otherwise no frustum cull
-        dead = dead || (fx_pos && (d1 < -rho || d2 > rho)) || (fy_pos && (e1 < -rho || e2 > rho));
+        dead = dead || (fx_pos && (d1 < -rd1 || d2 > rd2)) || (fy_pos && (e1 < -re1 || e2 > re2));
         // ---- occlusion: the largest depth over the pixels the brick can project onto (SAF_CLS_OCCL=0 at build time: off).
         // A voxel's pixel is round(u), u = k00 x / z + k02 (clipfusion.py:651-661 undone: grid_sample's un-normalisation gives
         // back the pixel coordinate); over the sphere's bounding box x in [xc - rho, xc + rho], z in [zc - rho, zc + rho] (z > 0)
         // u is monotone in x and in 1 / z: a conservative pixel rectangle, widened by a pixel, at most 16 tiles of it.
-        const float zn = zc - rho, zf = zc + rho;
+        const float zn = zc - ext_z, zf = zc + ext_z;
         if (SAF_CLS_OCCL && !dead && z_is_depth && fx_pos && fy_pos && zn > 1e-3f && zn > dmax[kWin + lane] + v.trunc * 1.01f + 1e-4f) {
           const float rn = 1.0f / zn, rf = 1.0f / zf;
-          const float xl = xc - rho, xh = xc + rho, yl = yc - rho, yh = yc + rho;
+          const float xl = xc - ext_x, xh = xc + ext_x, yl = yc - ext_y, yh = yc + ext_y;
           const float ul = c.k00 * (xl >= 0.0f ? xl * rf : xl * rn) + c.k02, uh = c.k00 * (xh >= 0.0f ? xh * rn : xh * rf) + c.k02;
           const float vl = c.k11 * (yl >= 0.0f ? yl * rf : yl * rn) + c.k12, vh = c.k11 * (yh >= 0.0f ? yh * rn : yh * rf) + c.k12;
           // (1e-3 relative for the reciprocals' rounding, a pixel for round-half-even and the reference's own arithmetic)

@@ -33,6 +33,44 @@ def test_library_builds_loads_and_exports_every_symbol():
     assert l.saf_query_workspace_bytes(7, _abi.SAF_Q_SOFTMAX) == 0
 
 
+def test_workspace_is_sized_for_the_volume(monkeypatch):
+    """the brick form's segment pools (6.5 GB at 256^3) are reserved only for volumes whose row kernel is the
+    brick form -- by width, dtype and SAF_WIN_FORM -- not for every volume (host-only: no compute)."""
+    monkeypatch.delenv("SAF_WIN_FORM", raising=False)
+    l = _lib.lib()
+    n = 256
+
+    def vol(d, dt):
+        v = _abi.SafVolume()
+        v.nx = v.ny = v.nz = n
+        v.feat_dim, v.feat_dtype, v.accum_mode, v.trunc = d, dt, _abi.SAF_RUNNING_MEAN, 0.03
+        for f in ("axis_x", "axis_y", "axis_z", "tsdf", "tsdf_weight", "weight", "rgb", "clip_feat"):
+            setattr(v, f, 4096)  # non-NULL, aligned: the descriptor is only inspected
+        return v
+
+    size = lambda d, dt: l.saf_fuse_workspace_bytes_for(ctypes.byref(vol(d, dt)), 5, 7)
+    rows_f32, rows_bf16 = size(512, _abi.SAF_F32), size(512, _abi.SAF_BF16)
+    assert 0 < rows_f32 < 1.5e9 and rows_f32 == rows_bf16, "a 512-channel volume needs no brick pools"
+    assert size(320, _abi.SAF_F32) > 4e9 and size(256, _abi.SAF_BF16) > 4e9, "widths only the brick form takes"
+    monkeypatch.setenv("SAF_WIN_FORM", "bricks")
+    assert size(512, _abi.SAF_F32) > 4e9
+    monkeypatch.setenv("SAF_WIN_FORM", "rows")
+    assert size(320, _abi.SAF_F32) < 1.5e9
+    assert l.saf_fuse_workspace_bytes_for(None, 5, 7) == 0
+    # the form-agnostic entry stays conservative: enough for whatever dtype the volume turns out to have
+    monkeypatch.delenv("SAF_WIN_FORM")
+    assert l.saf_fuse_workspace_bytes(n ** 3, 512, 5, 7) == rows_f32
+    assert l.saf_fuse_workspace_bytes(n ** 3, 256, 5, 7) >= size(256, _abi.SAF_BF16)
+
+
+def test_slab_entry_rejects_bad_lists_on_the_host():
+    l = _lib.lib()
+    vol = _abi.SafVolume()
+    fr = _abi.SafFrame()
+    rc = l.saf_fuse_frames_slabs(ctypes.byref(vol), ctypes.byref(fr), 1, None, None, 0, None, None, 0, None, None, None)
+    assert rc == _abi.SAF_E_INVALID
+
+
 def test_struct_layout_matches_header():
     # 8 x 4-byte scalars, then 9 pointers
     assert ctypes.sizeof(_abi.SafVolume) == 8 * 4 + 9 * 8

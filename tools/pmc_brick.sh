@@ -6,7 +6,7 @@
 # Usage: [FRAMES=512] bash tools/pmc_brick.sh <outdir> [extra bench args]
 OUT=${1:-gpurun_out/pmcbrick}; shift
 mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python3 bench.py --cpu-frames 0 --frames ${FRAMES:-128} --steps 1 --warmup 0 --no-profile-events --no-side --end-to-end 0 $*"
+B="python3 bench.py --cpu-frames 0 --frames ${FRAMES:-128} --steps 1 --warmup 0 --no-profile-events --no-side --end-to-end 0 --no-pmc $*"
 export SAF_WIN_OVERLAP=0
 run() { name=$1; shift; timeout -k 5 100 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- $B > $OUT/$name.json 2> $OUT/$name.err || echo "FAILED $name"; }
 run a FETCH_SIZE &&
