@@ -29,7 +29,7 @@ from . import _abi
 from ._lib import SafError, check, current_stream_ptr, lib
 
 _CHUNK_ELEMS = 1 << 28  # all_reduce / frame exchange are issued in <= 1 GiB (fp32) pieces
-_PIECE_BYTES = 4 << 30  # the striped reduce-scatter / all-gather work IN PLACE (no staging copy): pieces of <= 4 GiB
+_PIECE_BYTES = 1 << 30  # the striped reduce-scatter / all-gather work IN PLACE (no staging copy): pieces of <= 1 GiB (byte counts stay below 2^31 whatever the collective library does with them)
 
 
 def shard_frames(n_frames: int, rank: int, world: int) -> range:
@@ -55,7 +55,7 @@ def voxel_shard(n_voxels: int, rank: int, world: int):
 # "rank k owns voxel range k of the whole volume", which made every <= 1 GiB piece a strided gather of world slices into a
 # staging buffer (+ 34 GB read + 34 GB written per merge, and one staging buffer serialising copy j + 1 behind collective j).
 # Now the OWNERSHIP follows the pieces: the rows of a volume (or of one slab of it) are cut into contiguous pieces of
-# `piece_rows` rows (a multiple of world; <= 4 GiB of the widest tensor), and inside every piece rank k owns the k-th of
+# `piece_rows` rows (a multiple of world; <= 1 GiB of the widest tensor), and inside every piece rank k owns the k-th of
 # world equal parts.  A piece is then exactly what reduce_scatter_tensor / all_gather_into_tensor take in place:
 #   reduce_scatter_tensor(piece[k c : (k + 1) c], piece)        all_gather_into_tensor(piece, piece[k c : (k + 1) c])
 # No staging buffer, no copy.  Rank k ends with a list of STRIPES, one per piece; every tensor of the volume uses the same

@@ -290,7 +290,7 @@ def test_stripe_plan_tiles_and_ramp():
         seen.sort()
         assert seen[0][0] == 11 and all(seen[i][0] + seen[i][1] == seen[i + 1][0] for i in range(len(seen) - 1))
         assert seen[-1][0] + seen[-1][1] == 11 + n
-    assert sdist.piece_rows_for(2048, 8) == (4 << 30) // 2048 and sdist.piece_rows_for(1 << 40, 8) == 8
+    assert sdist.piece_rows_for(2048, 8) == sdist._PIECE_BYTES // 2048 and sdist.piece_rows_for(1 << 40, 8) == 8
     b = sdist.slab_bounds(256, 8, ramp=True)
     assert [c for _, c in b] == [16, 32, 32, 48, 48, 32, 32, 16] and b[0][0] == 0 and sum(c for _, c in b) == 256
     for nx, k in ((256, 8), (128, 8), (64, 4), (48, 3), (33, 5), (16, 8), (255, 8)):
