@@ -612,8 +612,27 @@ def gen_tiled_clip(ref_cf, out_dir):
         out[f"c{ci}_resized_sum"] = resized.double().sum(dim=(1, 2, 3)).numpy()
         out[f"c{ci}_feats"] = feats.numpy().copy()
     out["n_cases"] = np.array(3)
+    # Clip.img_inference_tiled_depthscaled (clipfusion.py:841-890; `scale_patches_by_depth`, off everywhere in the reference):
+    # one tile per stride lattice point, sized so that it covers half a metre at the point's depth, its feature vector
+    # averaged over the pixels the tiles cover.  Depths chosen so that tiles overlap, stick out of the image on every side
+    # and, for two lattice points, are missing (depth 0).
+    # (B = 1 only: for B > 1 the reference's last line divides [B, D, H, W] by [B, H, W] and raises unless B == D)
+    for ci, (b, h, w, st, dlo, dhi) in enumerate([(1, 48, 64, 16, 1.0, 3.0), (1, 40, 56, 8, 2.0, 6.0)]):
+        rgb = torch.rand(b, 3, h, w, generator=g)
+        depth = torch.rand(b, h, w, generator=g) * (dhi - dlo) + dlo
+        depth[0, st, st] = 0.0
+        depth[-1, 2 * st, st] = 0.0
+        K = torch.eye(3).repeat(b, 1, 1)
+        K[:, 0, 0] = [55.0, 47.5][ci]
+        K[:, 1, 1] = [60.0, 52.0][ci]
+        feats = clip.img_inference_tiled_depthscaled(rgb, depth, K, st)
+        out[f"d{ci}_rgb"], out[f"d{ci}_depth"], out[f"d{ci}_K"] = rgb.numpy(), depth.numpy(), K.numpy()
+        out[f"d{ci}_stride"] = np.array(st)
+        out[f"d{ci}_feats"] = feats.numpy().copy()
+    out["n_depth_cases"] = np.array(2)
     np.savez_compressed(os.path.join(out_dir, "tiled_clip.npz"), **out)
-    print("tiled clip front-end:", [tuple(out[f"c{i}_feats"].shape) for i in range(3)])
+    print("tiled clip front-end:", [tuple(out[f"c{i}_feats"].shape) for i in range(3)], "depth-scaled:",
+          [tuple(out[f"d{i}_feats"].shape) for i in range(2)])
 
 
 def main():

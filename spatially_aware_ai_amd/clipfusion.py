@@ -19,6 +19,7 @@ import ctypes as C
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import _abi
 from ._lib import SafError, check, current_stream_ptr, lib, require_cuda
@@ -812,11 +813,45 @@ class Clip(torch.nn.Module):
                 feats[base + start : base + start + len(cur)] = self.clip.encode_image(cur)
         return feats.view(bsz, npy, npx, self.feature_dim).permute(0, 3, 1, 2)
 
-    def img_inference_tiled_depthscaled(self, rgb_imgs, depth_imgs, K, patch_stride):
-        raise NotImplementedError(
-            "scale_patches_by_depth is dead code in the reference (always False: clipfusion.py:1097, "
-            "clip_seem_fusion.py:167) and is not part of the fused path"
-        )
+    def img_inference_tiled_depthscaled(self, rgb_imgs, depth_imgs, K, patch_stride, footprint_m=0.5):
+        """[B,3,H,W] in 0..1, depth [B,H,W] m, K [B,3,3] -> [B,D,H,W]: a FULL-resolution feature image (clipfusion.py:841-890;
+        ``scale_patches_by_depth``, off everywhere in the reference: :1097, clip_seem_fusion.py:167).  One tile per lattice
+        point (every ``patch_stride`` pixels, the first row / column excluded) with a valid depth, sized to cover
+        ``footprint_m`` metres at that depth (``round(f * 0.5 / depth)`` pixels, halves rounded down on both sides, clipped at
+        the image's upper-left border only -- as the reference slices), resized to 224 x 224 and encoded; every pixel gets the
+        MEAN of the embeddings of the tiles that cover it, 0 where none does.  All of an image's tiles go through the ViT in
+        batches of ``max_patch_batch_size`` (the reference encodes them one by one).  The reference itself only runs for
+        B = 1 (its last line divides [B, D, H, W] by [B, H, W]); any B works here."""
+        x = self.normalize_img(rgb_imgs)
+        bsz, _, h, w = x.shape
+        dev = x.device
+        ys = torch.arange(patch_stride, h, patch_stride, device=dev)
+        xs = torch.arange(patch_stride, w, patch_stride, device=dev)
+        out = torch.zeros(bsz, self.feature_dim, h, w, device=dev)
+        step = int(self.max_patch_batch_size)
+        for b in range(bsz):
+            d = depth_imgs[b][ys][:, xs]                      # depth at the lattice points [ny, nx]
+            keep = (d > 0).nonzero()
+            if keep.numel() == 0:
+                continue
+            dk = d[keep[:, 0], keep[:, 1]]
+            half_h = ((K[b, 1, 1] * footprint_m / dk).round().to(torch.int64) // 2).tolist()
+            half_w = ((K[b, 0, 0] * footprint_m / dk).round().to(torch.int64) // 2).tolist()
+            yc, xc = ys[keep[:, 0]].tolist(), xs[keep[:, 1]].tolist()
+            boxes = [(max(0, y - hh), min(h, y + hh), max(0, x_ - hw), min(w, x_ + hw))
+                     for y, x_, hh, hw in zip(yc, xc, half_h, half_w)]
+            if any(y1 <= y0 or x1 <= x0 for y0, y1, x0, x1 in boxes):
+                raise ValueError("a depth-scaled tile is empty (depth too large for this focal length); the reference's "
+                                 "interpolate call raises for it as well")
+            tiles = torch.cat([F.interpolate(x[b : b + 1, :, y0:y1, x0:x1], size=(224, 224), mode="bilinear", align_corners=False)
+                               for y0, y1, x0, x1 in boxes])
+            emb = torch.cat([self.clip.encode_image(tiles[s0 : s0 + step]) for s0 in range(0, len(tiles), step)]).to(out.dtype)
+            cover = torch.zeros(h, w, device=dev)
+            for (y0, y1, x0, x1), e in zip(boxes, emb):     # lattice order: the reference's order of additions
+                out[b, :, y0:y1, x0:x1] += e[:, None, None]
+                cover[y0:y1, x0:x1] += 1
+            out[b] /= cover + (cover == 0)
+        return out
 
     def text_inference(self, str_list):
         device = next(self.clip.parameters()).device
