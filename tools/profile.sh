@@ -5,13 +5,13 @@
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-frames 0 \
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-frames 0 --no-pmc \
    > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || echo "trace FAILED"
 # the headline job alone (no side workloads, no end-to-end pass: they launch the same kernel on other shapes and would
 # blur its average): the per-kernel average of THIS table is what `roofline.avg_launch_us` must agree with
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -- python3 bench.py --cpu-frames 0 \
-   --no-side --end-to-end 0 > $OUT/bench_headline_under_rocprof.json 2> $OUT/trace_headline.err || echo "headline trace FAILED"
-PM="python3 bench.py --cpu-frames 0 --steps 1 --warmup 0 --no-profile-events --no-side"  # the whole 512-frame job: a row is not read in the window that first touches it
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -- python3 bench.py --cpu-frames 0 --no-pmc \
+   --no-side --end-to-end 0 --no-pmc > $OUT/bench_headline_under_rocprof.json 2> $OUT/trace_headline.err || echo "headline trace FAILED"
+PM="python3 bench.py --cpu-frames 0 --steps 1 --warmup 0 --no-profile-events --no-side --no-pmc"  # the whole 512-frame job: a row is not read in the window that first touches it
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $PM \
    > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || echo "pmc fetch FAILED"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $PM \
