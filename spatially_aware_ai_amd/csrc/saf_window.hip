@@ -106,6 +106,9 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_CLS_OCCL
 #define SAF_CLS_OCCL 1  // the occlusion cull of the classification (depth tile maxima); 0: the frame-wide largest depth only
 #endif
+#ifndef SAF_CLS_BUFLD
+#define SAF_CLS_BUFLD 1  // depth gathers through a buffer descriptor of the frame's image (0: 64-bit addresses)
+#endif
 #ifndef SAF_CLS_BOX
 #define SAF_CLS_BOX 1  // the brick's frame cull tests the box's extents (0: its bounding sphere, rounds 2-3)
 #endif
@@ -219,9 +222,19 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
     float depth[kFU][4];
 #pragma unroll
     for (int u = 0; u < kFU; ++u) {
+      // through a buffer descriptor of the frame's depth image (the frame is wave-uniform): a 32-bit offset per lane instead of
+      // a 64-bit address, and "no pixel" (pix < 0: an offset beyond the image) reads 0 by the range check -- zeros padding
+#if SAF_CLS_BUFLD
+      const __amdgpu_buffer_rsrc_t dimg = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(wa.depth[fr[u] >= 0 ? fr[u] : 0]), 0, wa.H * wa.W * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        depth[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dimg, pix[u][j] * 4, 0, 0));
+#else
       const float* __restrict__ dimg = wa.depth[fr[u] >= 0 ? fr[u] : 0];
 #pragma unroll
       for (int j = 0; j < 4; ++j) depth[u][j] = pix[u][j] >= 0 ? dimg[pix[u][j]] : 0.0f;
+#endif
     }
 #pragma unroll
     for (int u = 0; u < kFU; ++u) {
