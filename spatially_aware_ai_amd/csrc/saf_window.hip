@@ -742,6 +742,9 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
   // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
   constexpr int P = OF ? Cfg::P : (BF16 && Cfg::P > 2 ? Cfg::P - 1 : (BF16 && CPL == 4 ? 1 : Cfg::P));  // (bf16, D = 1024: two groups of 64 tap registers in flight spilled)
   extern __shared__ __align__(16) unsigned char s_dyn[];
+#ifdef SAF_WIN_PRIO
+  __builtin_amdgcn_s_setprio(SAF_WIN_PRIO);
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4* rows = reinterpret_cast<float4*>(s_dyn + Cfg::rows_off) + (size_t)wave * SR * CPL * 64;
   uint32_t* stage = reinterpret_cast<uint32_t*>(s_dyn + Cfg::stage_off) + (size_t)wave * 6 * kHitCap;
