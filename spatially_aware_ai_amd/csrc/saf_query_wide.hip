@@ -240,6 +240,48 @@ __device__ __forceinline__ uint4 ld_stream_u4(const uint16_t* p) {  // the volum
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// One 1 KiB LDS-DMA piece (64 lanes x 16 bytes, written linearly from the wave-uniform LDS byte address `lds_addr`), issued
+// from inline assembly so that the COMPILER DOES NOT KNOW an LDS write is pending: for the builtin it orders every later
+// ds_read behind the transfer (no alias information: `s_waitcnt vmcnt(0)` right after the issue -- rounds 2-3 paid the
+// whole L2 latency of the next tile at the start of every step: the "3.3 ms of LDS-DMA" of DESIGN 4.4).  The ordering is
+// this file's own: a counted `s_waitcnt vmcnt` ahead of the barrier behind which the tile is read (w2_wait_vm).  An
+// operation the compiler's counter does not know about only makes its own waits longer, never shorter.
+#ifndef SAF_W2_ASMDMA
+#define SAF_W2_ASMDMA 1
+#endif
+// K consecutive text rows (1 KiB each: D = 512) from sbase (wave-uniform: SGPRs) + the lane's 16 bytes into K consecutive padded
+// LDS rows (ROWB bytes apart) from the wave-uniform byte address lds_addr.  One statement: M0 and the lane offset step from
+// piece to piece (a VALU instruction sits between every write of M0 and the transfer that reads it).
+#define SAF_W2_DMA_NEXT "s_add_u32 m0, m0, %5\n\tv_add_u32 %1, 0x400, %1\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+template <int K, int ROWB>
+__device__ __forceinline__ void w2_dma_rows(const uint16_t* sbase, uint32_t lane16, uint32_t lds_addr) {
+  static_assert(K == 4 || K == 8, "pieces per wave and tile");
+#if SAF_W2_ASMDMA
+  uint32_t m0_saved, voff;  // (M0 is the compiler's: handed back as found)
+  if (K == 4)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_mov_b32 %1, %2\n\tglobal_load_lds_dwordx4 %1, %3\n\t" SAF_W2_DMA_NEXT SAF_W2_DMA_NEXT
+                 SAF_W2_DMA_NEXT "s_nop 0\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved), "=&v"(voff) : "v"(lane16), "s"(sbase), "s"(lds_addr), "n"(ROWB) : "memory", "scc");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_mov_b32 %1, %2\n\tglobal_load_lds_dwordx4 %1, %3\n\t" SAF_W2_DMA_NEXT SAF_W2_DMA_NEXT
+                 SAF_W2_DMA_NEXT SAF_W2_DMA_NEXT SAF_W2_DMA_NEXT SAF_W2_DMA_NEXT SAF_W2_DMA_NEXT "s_nop 0\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved), "=&v"(voff) : "v"(lane16), "s"(sbase), "s"(lds_addr), "n"(ROWB) : "memory", "scc");
+#else
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(sbase) + lane16 + k * 1024),
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(lds_addr + k * ROWB), 16, 0, 0);
+#endif
+}
+// `s_waitcnt vmcnt(n)` for a wave-uniform n known only at run time (the instruction takes an immediate): the largest listed
+// count <= n -- waiting for more than asked is always correct.
+__device__ __forceinline__ void w2_wait_vm(int n) {
+  if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // float -> u32 that orders like the float (for integer atomic max)
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
   const uint32_t b = __builtin_bit_cast(uint32_t, f);
@@ -259,6 +301,15 @@ __device__ __forceinline__ uint2 pack4_16(float v0, float v1, float v2, float v3
   a.x = (_Float16)v0; a.y = (_Float16)v1; b.x = (_Float16)v2; b.y = (_Float16)v3;
   return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
 }
+
+// Development (-DSAF_W2_STAMP): s_memtime stamps around the segments of a step, summed per wave of workgroup 0 and read
+// back by saf_debug_w2_stamps (tools/w2_stamps.py).  Costs about a tenth of the kernel's time.
+#ifdef SAF_W2_STAMP
+__device__ unsigned long long g_w2_stamp[8 * 8];
+#define W2_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define W2_STAMP(k) do { } while (0)
+#endif
 
 struct Wide2Args {
   const uint16_t* feats;
@@ -580,19 +631,35 @@ query_wide2_kernel(Wide2Args wa) {
   cur.qt = 0;
   prev = cur;
   f32x16_t acc[2][NF];  // [step parity][fragment]: the tile being accumulated and the previous one awaiting its epilogue
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_tiles;
+#ifndef SAF_W2_STAGGER
+#define SAF_W2_STAGGER 0  // (measured: the second site splits the MFMA loop -- heat maps 24.8 vs 23.3 ms, row argmax 18.0 vs 17.6)
+#endif
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool late = SAF_W2_STAGGER && NF == 1 && kWaves == 8 && wave_u >= kWaves / 2;
+  int tail_ops = 0;  // vector-memory operations the last step issued behind its LDS-DMA (a lower bound)
 
   // One step = one (row block, query tile) pair.  In program order: barrier (tile in LDS) -> transfer of the next tile
   // issued -> the first text fragments requested -> the PREVIOUS tile's epilogue (vector work and stores that do not
   // depend on what follows) -> the MFMAs, each group consuming one fragment and requesting the one AHEAD steps ahead.
+  int qt_run = 0;
+  int64_t blk_run = blockIdx.x;
+#ifdef SAF_W2_STAMP
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
   auto step_body = [&](int64_t step, f32x16_t (&c)[NF], const f32x16_t (&pc)[NF]) {
-    const int qt = (int)(step % n_qt);
+    const int qt = qt_run;  // step % n_qt, kept incrementally (the 64-bit division cost ~250 cycles of every step: tools/w2_stamps.py)
+    qt_run = qt + 1 < n_qt ? qt + 1 : 0;
+    W2_STAMP(0);  // the tail of the step before: last epilogue pieces, loop control
     if (qt == 0) {
       // A new row block: its rows per wave, register resident for every query tile.  A 32-row fragment per wave-load
       // touches 32 rows x 32 bytes (each lane holds 16 bytes of its OWN row: the MFMA operand layout), and nothing runs
       // beside this phase: 3.7 of 19.4 ms at config 5.  Tried and measured slower: requesting the next block's rows
       // behind the last tile's MFMAs (a load into a register an MFMA is still reading stalls the in-order issue: 20.8 ms),
       // staggered workgroup phases, two independent workgroups per CU.
-      const int64_t blk = blockIdx.x + (step / n_qt) * gridDim.x;
+      const int64_t blk = blk_run;
+      blk_run += gridDim.x;
       const int64_t row0 = (blk * kWaves + wave) * kRows;
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
@@ -625,23 +692,37 @@ query_wide2_kernel(Wide2Args wa) {
       }
     }
     cur.qt = qt;
+    if (qt == 0) W2_STAMP(1);  // a new block's rows: issue, norms (the waits for the data are in the first tile's MFMAs)
     const unsigned char* curb = s_tiles + (size_t)(step & 1) * kWTile * ROWB;
     unsigned char* nxt = s_tiles + (size_t)((step + 1) & 1) * kWTile * ROWB;
-    // this tile's text is in LDS (its transfer was issued a step ago) and every wave is done reading the other buffer
+    // This tile's text is in LDS (its transfer was issued a step ago) and every wave is done reading the other buffer.
+    // The wait is COUNTED: the wave's `tail_ops` youngest vector-memory operations are the previous tile's last stores (or
+    // its atomic), issued behind the transfer -- they need not have landed (vmcnt retires in issue order).
+#if SAF_W2_ASMDMA
+    w2_wait_vm(kDma ? tail_ops : 0);
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    W2_STAMP(7);  // the wait for this wave's pieces of the tile
     __syncthreads();
+    W2_STAMP(2);  // the barrier  // the wait for the tile and the barrier
     const bool more = step + 1 < n_steps;
     const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
     uint4 stage[kDma ? 1 : PPT];
+    // the next tile by LDS-DMA, 32 / kWaves pieces per wave.  Of the two waves that share a SIMD (w and w + 4) one issues
+    // them here, the other one behind the first half of its MFMAs: an issue costs 60-185 cycles of the wave's in-order
+    // stream (MI355X_MICROARCH.md, constants), and with both at it at once the matrix pipe has nobody to run
+    auto dma_next = [&]() {
+      constexpr int K = kWTile / kWaves;
+      w2_dma_rows<K, ROWB>(wa.text16 + (int64_t)(qt_next * kWTile + wave_u * K) * D, (uint32_t)lane * 16u,
+                           lds_base + (uint32_t)((step + 1) & 1) * kWTile * ROWB + wave_u * K * ROWB);
+    };
+#ifndef SAF_W2_DMA_AT
+#define SAF_W2_DMA_AT 0  // the MFMA step behind which every wave issues the next tile's transfer (0: ahead of the first)
+#endif
     if (more) {
       if (kDma) {
-#pragma unroll
-        for (int k = 0; k < kWTile / kWaves; ++k) {
-          const int q = wave * (kWTile / kWaves) + k;
-          const uint16_t* src = wa.text16 + (int64_t)(qt_next * kWTile + q) * D + lane * 8;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(nxt + q * ROWB), 16, 0, 0);
-        }
+        if (!late && SAF_W2_DMA_AT == 0) dma_next();
       } else {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -653,6 +734,7 @@ query_wide2_kernel(Wide2Args wa) {
         }
       }
     }
+    W2_STAMP(3);  // the issue of the next tile's transfer
 #ifndef SAF_W2_AHEAD
 #define SAF_W2_AHEAD 6  // text fragments requested ahead of the MFMA that consumes them.  8 spilled 5-18 registers in the NF = 1, D = 512 instantiations (scratch traffic inside the tile loop: VERDICT round 3); 6: none
 #endif
@@ -676,6 +758,7 @@ query_wide2_kernel(Wide2Args wa) {
     fast = false;
 #endif
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int kLateAt = KS / 2;  // (behind the stores of registers 0-7, ahead of those of registers 8-15)
     if (!fast) {
       if (step > 0) w2_epilogue<OT, EPI, NF>(wa, pc, prev, st, r, h, n_qt, vec_ok);
 #pragma unroll
@@ -683,7 +766,9 @@ query_wide2_kernel(Wide2Args wa) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) c[f] = mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);  // C[query][feature row]
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
+        if (kDma && ((s == kLateAt && late) || (SAF_W2_DMA_AT > 0 && s == SAF_W2_DMA_AT && !late)) && more) dma_next();
       }
+      tail_ops = 0;
     } else {
       W2Fast<NF> fs;
 #pragma unroll
@@ -691,10 +776,14 @@ query_wide2_kernel(Wide2Args wa) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) c[f] = mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
+        if (kDma && ((s == kLateAt && late) || (SAF_W2_DMA_AT > 0 && s == SAF_W2_DMA_AT && !late)) && more) dma_next();
 #pragma unroll
         for (int i = (s * 16) / KS; i < ((s + 1) * 16) / KS; ++i) w2_fast_piece<OT, EPI, NF>(i, wa, pc, prev, st, fs, r, h, n_qt);
         __builtin_amdgcn_sched_barrier(0);  // keep the pieces where they are: between the MFMAs
       }
+      // what this step issued behind its transfer, at the very least: the stores of registers 8-15 (one per fragment for
+      // 16-bit scores, two for fp32) or the atomic below
+      tail_ops = EPI == SAF_QW_ROW_ARGMAX ? 0 : EPI == SAF_QW_QUERY_MAX ? 1 : NF * (OT == SAF_F32 ? 2 : 1);
       if (EPI == SAF_QW_QUERY_MAX) {
         const unsigned long long best = w2_query_max_reduce(fs.qk, r);
         if ((r & 1) == 0) {  // one atomic per query and half-wave, all in one instruction
@@ -703,6 +792,7 @@ query_wide2_kernel(Wide2Args wa) {
         }
       }
     }
+    if (qt == 0) W2_STAMP(4); else W2_STAMP(5);  // the tile: LDS reads, MFMAs, the previous tile's epilogue (4: first tile of a block, waits for its rows)
     if (more && !kDma) {
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
@@ -727,6 +817,12 @@ query_wide2_kernel(Wide2Args wa) {
   } else {
     w2_epilogue<OT, EPI, NF>(wa, acc[1], prev, st, r, h, n_qt, vec_ok);
   }
+#ifdef SAF_W2_STAMP
+  if (blockIdx.x == 0 && lane == 0 && wave < 8) {
+    seg[6] = (unsigned long long)n_steps;
+    for (int k = 0; k < 8; ++k) g_w2_stamp[wave * 8 + k] = seg[k];
+  }
+#endif
 }
 
 __global__ void qkeys_decode_kernel(const unsigned long long* __restrict__ keys, int Q, float* __restrict__ out_value,
@@ -802,6 +898,9 @@ int launch_wide2(const Wide2Args& wa, hipStream_t s) {
   const int rows_env = getenv("SAF_WIDE_ROWS") ? atoi(getenv("SAF_WIDE_ROWS")) : 0;
   if (rows_env == 64) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
   if (rows_env == 32) return launch_wide2_nf<FT, OT, KS, EPI, 1, 512>(wa, s);
+#ifdef SAF_W2_TWO_WGS
+  if (rows_env == 33) return launch_wide2_nf<FT, OT, KS, EPI, 1, 256>(wa, s);  // two workgroups of 4 waves per CU
+#endif
   // measured at config 5 (ms, 32 vs 64 rows per wave): heat maps 27.5 / 31.4, best query per voxel 19.3 / 20.4, raw scores
   // 25.7 / 27.8, best voxel per query 55.5 / 45.0 (its per-tile shuffle reduction is per WAVE, so fewer, larger waves win)
   if (EPI == SAF_QW_QUERY_MAX) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
@@ -981,5 +1080,11 @@ int saf_query_scan_wide_ex(const void* feats, int32_t feat_dtype, int64_t n_rows
   }
   return SAF_OK;
 }
+
+#ifdef SAF_W2_STAMP
+int saf_debug_w2_stamps(unsigned long long* host_out) {  // [8 waves][8]: cycles per segment, [6] = steps
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(saf::g_w2_stamp), sizeof(unsigned long long) * 64) == hipSuccess ? SAF_OK : SAF_E_HIP;
+}
+#endif
 
 }  // extern "C"
