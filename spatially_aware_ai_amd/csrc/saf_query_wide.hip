@@ -339,6 +339,8 @@ template <int NF>
 struct W2State {
   float best_v[NF], lse[NF];
   int best_q[NF];
+  const float* inv_lds;  // QUERY_MAX: the wave's 32 NF (scale / norm) values in LDS, by row of the wave (read four at a time: the
+                         // rows 8 g + 4 h + 0..3 behind accumulator registers 4 g .. 4 g + 3 of this lane)
 };
 
 template <int OT, int EPI, int NF>
@@ -446,32 +448,27 @@ __device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t 
       st.best_v[f] = bv;
       st.best_q[f] = bq;
     }
-  } else {  // SAF_QW_QUERY_MAX: the best of the wave's rows per query, one atomic per query and wave
-    const bool last = t.qt == n_qt - 1;
+  } else {  // SAF_QW_QUERY_MAX.  The operands are SWAPPED for this epilogue (C[feature row][query]): lane (n, h) owns query
+    // qt*32 + n and, in register i of fragment f, feature row 32 f + 8 (i >> 2) + 4 h + (i & 3) of the wave -- the maximum over
+    // rows is a per-lane chain over the registers, the two halves meet once, and one atomic instruction per tile and wave
+    // carries 32 queries (st.invc: the rows' 1/norm in this layout).
+    const int q = t.qt * kWTile + r;
+    const int64_t base = t.row[0] - r;  // the wave's first row
+    float bv = -INFINITY;
+    int bm = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int q = qbase + 8 * (i >> 2) + (i & 3);
-      float x[NF];
-      float m = -INFINITY;
+    for (int f = 0; f < NF; ++f) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        x[f] = t.row[f] < wa.n_rows ? c[f][i] * t.inv[f] : -INFINITY;
-        m = fmaxf(m, x[f]);
-      }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));  // every lane of the half: the wave's maximum
-      // the smallest row that reaches it: fragment 0 (rows row0 + r) before fragment 1 (rows row0 + 32 + r)
-      uint32_t slot = 0xffffffffu;
-#pragma unroll
-      for (int f = NF - 1; f >= 0; --f) {
-        const uint32_t hb = (uint32_t)(__ballot(x[f] == m) >> (32 * h));
-        slot = hb ? 32u * f + (uint32_t)__ffs((int)hb) - 1u : slot;
-      }
-      if (r == 0 && !(last && q >= wa.Q) && m > -INFINITY) {
-        const uint32_t row = (uint32_t)(t.row[0] + wa.row_offset) + slot;  // row[0] of lane r = 0 is the wave's first row
-        atomicMax(&wa.qkeys[q], ((unsigned long long)ordered_bits(m) << 32) | (uint32_t)~row);
+      for (int i = 0; i < 16; ++i) {
+        const int m = 32 * f + 8 * (i >> 2) + 4 * h + (i & 3);
+        const float x = base + m < wa.n_rows ? c[f][i] * st.inv_lds[m] : -INFINITY;
+        if (x > bv) { bv = x; bm = m; }  // rows ascend: the first maximum stays
       }
     }
+    unsigned long long key = bv > -INFINITY ? ((unsigned long long)ordered_bits(bv) << 32) | (uint32_t) ~(uint32_t)(base + bm + wa.row_offset) : 0ull;
+    const unsigned long long other = __shfl_xor(key, 32);
+    key = other > key ? other : key;
+    if (h == 0 && q < wa.Q && key) atomicMax(&wa.qkeys[q], key);
   }
 }
 
@@ -484,52 +481,9 @@ __device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t 
 template <int NF>
 struct W2Fast {
   float v[NF][16];                 // scaled scores / probabilities of the previous tile (SCORES, VS_BACKGROUND)
-  unsigned long long qk[16];       // QUERY_MAX: per register, the wave's best (ordered score, ~row) for lane r = 0
+  float iv[NF][4];                // QUERY_MAX: 1/norm of the rows behind the current group of four registers
+  float bv; int bm;               // QUERY_MAX: the lane's best score of the tile so far and its row (without the 4 h of the half)
 };
-
-// QUERY_MAX: per query, the largest key over the 32 lanes of a half.  A lane holds 16 keys (its row's scores of the half's 16
-// queries): a reduce-scatter BUTTERFLY -- at each of four levels a lane keeps half of its keys and trades the other half
-// with the lane whose index differs in one bit (bit 4: v_permlane16_swap; bit 3: DPP row_ror:8; bits 2, 1: ds_swizzle /
-// quad_perm), then one exchange over bit 0 -- 16 exchanges of a key in all, instead of five shuffles and a ballot per key
-// (16 x 5): the per-query maximum was 45 ms of a 19 ms scan.  Afterwards lane r of half h holds the half's best key of query
-// register i(r) = 8 b4 + 4 b3 + 2 b2 + b1 (b_k = bit k of r; lanes r and r ^ 1 hold the same).
-__device__ __forceinline__ unsigned long long w2_key_max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
-__device__ __forceinline__ unsigned long long w2_key_dpp_ror8(unsigned long long v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x128, 0xf, 0xf, false);          // row_ror:8 = lane ^ 8 of a 16-lane row
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x128, 0xf, 0xf, false);
-  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-template <int PATTERN>
-__device__ __forceinline__ unsigned long long w2_key_swizzle(unsigned long long v) {
-  const int lo = __builtin_amdgcn_ds_swizzle((int)(uint32_t)v, PATTERN);
-  const int hi = __builtin_amdgcn_ds_swizzle((int)(uint32_t)(v >> 32), PATTERN);
-  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-__device__ __forceinline__ unsigned long long w2_query_max_reduce(const unsigned long long (&qk)[16], int r) {
-  unsigned long long k8[8], k4[4], k2[2];
-  // bit 4: lanes 0-15 of a half keep keys 0-7, lanes 16-31 keys 8-15.  v_permlane16_swap(x, y) exchanges x[16:31] with
-  // y[0:15] (in both halves of the wave): afterwards x and y hold, in every lane, the two candidates of the key it keeps
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)qk[j], (uint32_t)qk[j + 8], false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(qk[j] >> 32), (uint32_t)(qk[j + 8] >> 32), false, false);
-    k8[j] = w2_key_max(((unsigned long long)hi[0] << 32) | lo[0], ((unsigned long long)hi[1] << 32) | lo[1]);
-  }
-  const bool b3 = (r & 8) != 0, b2 = (r & 4) != 0, b1 = (r & 2) != 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {  // bit 3: keep j (bit clear) or j + 4 (bit set), trade the other one
-    const unsigned long long keep = b3 ? k8[j + 4] : k8[j], give = b3 ? k8[j] : k8[j + 4];
-    k4[j] = w2_key_max(keep, w2_key_dpp_ror8(give));
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {  // bit 2 (ds_swizzle, bit mode: and 0x1f, xor 4)
-    const unsigned long long keep = b2 ? k4[j + 2] : k4[j], give = b2 ? k4[j] : k4[j + 2];
-    k2[j] = w2_key_max(keep, w2_key_swizzle<(4 << 10) | 0x1f>(give));
-  }
-  const unsigned long long keep = b1 ? k2[1] : k2[0], give = b1 ? k2[0] : k2[1];
-  const unsigned long long k1 = w2_key_max(keep, w2_key_swizzle<(2 << 10) | 0x1f>(give));
-  return w2_key_max(k1, w2_key_swizzle<(1 << 10) | 0x1f>(k1));  // bit 0: both lanes end with the half's best
-}
 
 template <int OT, int EPI, int NF>
 __device__ __forceinline__ void w2_fast_piece(int i, const Wide2Args& wa, const f32x16_t (&c)[NF], const W2Tile<NF>& t,
@@ -575,19 +529,23 @@ __device__ __forceinline__ void w2_fast_piece(int i, const Wide2Args& wa, const 
       st.best_v[f] = better ? x : st.best_v[f];
       st.best_q[f] = better ? q : st.best_q[f];
     }
-  } else {  // SAF_QW_QUERY_MAX
-    // this lane's best over its NF rows for query register i, as a key (ordered score << 32 | ~row: the larger key is the
-    // larger score, then the smaller row); the 32 lanes of a half are combined after the tile (w2_query_max_reduce)
-    float m = c[0][i] * t.inv[0];
-    uint32_t row = (uint32_t)(t.row[0] + wa.row_offset);
+  } else {  // SAF_QW_QUERY_MAX (swapped operands: see w2_epilogue): the lane's chain over its rows
 #pragma unroll
-    for (int f = 1; f < NF; ++f) {
-      const float x = c[f][i] * t.inv[f];
-      const bool better = x > m;  // rows ascend with f: the first maximum stays
-      m = better ? x : m;
-      row = better ? (uint32_t)(t.row[f] + wa.row_offset) : row;
+    for (int f = 0; f < NF; ++f) {
+      const int m = 32 * f + 8 * (i >> 2) + (i & 3);
+      if ((i & 3) == 0) {
+        const float4 v4 = *reinterpret_cast<const float4*>(st.inv_lds + m + 4 * h);
+        fs.iv[f][0] = v4.x; fs.iv[f][1] = v4.y; fs.iv[f][2] = v4.z; fs.iv[f][3] = v4.w;
+      }
+      const float x = c[f][i] * fs.iv[f][i & 3];
+      if (f == 0 && i == 0) {
+        fs.bv = x; fs.bm = m;
+      } else {
+        const bool better = x > fs.bv;  // rows ascend: the first maximum stays
+        fs.bv = better ? x : fs.bv;
+        fs.bm = better ? m : fs.bm;
+      }
     }
-    fs.qk[i] = ((unsigned long long)ordered_bits(m) << 32) | (uint32_t)~row;
   }
 }
 
@@ -628,6 +586,8 @@ query_wide2_kernel(Wide2Args wa) {
     st.best_v[f] = -INFINITY; st.best_q[f] = 0; st.lse[f] = 0.f;
     cur.inv[f] = 0.f; cur.row[f] = 0;
   }
+  float* s_inv = reinterpret_cast<float*>(s_tiles + 2 * kWTile * ROWB) + wave * kRows;  // QUERY_MAX only (W2State::inv_lds)
+  st.inv_lds = s_inv;
   cur.qt = 0;
   prev = cur;
   f32x16_t acc[2][NF];  // [step parity][fragment]: the tile being accumulated and the previous one awaiting its epilogue
@@ -738,7 +698,7 @@ query_wide2_kernel(Wide2Args wa) {
 #ifndef SAF_W2_AHEAD
 #define SAF_W2_AHEAD 6  // text fragments requested ahead of the MFMA that consumes them.  8 spilled 5-18 registers in the NF = 1, D = 512 instantiations (scratch traffic inside the tile loop: VERDICT round 3); 6: none
 #endif
-    constexpr int kAhead = EPI == SAF_QW_QUERY_MAX && NF == 1 ? SAF_W2_AHEAD - 1 : SAF_W2_AHEAD;  // (the key registers of the per-query maximum)
+    constexpr int kAhead = EPI == SAF_QW_QUERY_MAX && NF == 1 ? SAF_W2_AHEAD - 2 : SAF_W2_AHEAD;  // (the per-query maximum's chain state; -1: 3 spilled registers)
     constexpr int AHEAD = KS < kAhead ? KS : kAhead;
     uint4 t[KS];
     // (tried: fragments straight from a fragment-ordered copy of the text in L2 / L1, no LDS, no barrier: 24.0 vs 19.3 ms)
@@ -758,13 +718,14 @@ query_wide2_kernel(Wide2Args wa) {
     fast = false;
 #endif
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr bool kSwap = EPI == SAF_QW_QUERY_MAX;
     constexpr int kLateAt = KS / 2;  // (behind the stores of registers 0-7, ahead of those of registers 8-15)
     if (!fast) {
       if (step > 0) w2_epilogue<OT, EPI, NF>(wa, pc, prev, st, r, h, n_qt, vec_ok);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) c[f] = mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);  // C[query][feature row]
+        for (int f = 0; f < NF; ++f) c[f] = kSwap ? mfma16<FT>(a[f][s], t[s], s == 0 ? zero16 : c[f]) : mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);  // C[query][feature row]; kSwap: C[feature row][query]
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
         if (kDma && ((s == kLateAt && late) || (SAF_W2_DMA_AT > 0 && s == SAF_W2_DMA_AT && !late)) && more) dma_next();
       }
@@ -774,7 +735,7 @@ query_wide2_kernel(Wide2Args wa) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) c[f] = mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);
+        for (int f = 0; f < NF; ++f) c[f] = kSwap ? mfma16<FT>(a[f][s], t[s], s == 0 ? zero16 : c[f]) : mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
         if (kDma && ((s == kLateAt && late) || (SAF_W2_DMA_AT > 0 && s == SAF_W2_DMA_AT && !late)) && more) dma_next();
 #pragma unroll
@@ -784,13 +745,20 @@ query_wide2_kernel(Wide2Args wa) {
       // what this step issued behind its transfer, at the very least: the stores of registers 8-15 (one per fragment for
       // 16-bit scores, two for fp32) or the atomic below
       tail_ops = EPI == SAF_QW_ROW_ARGMAX ? 0 : EPI == SAF_QW_QUERY_MAX ? 1 : NF * (OT == SAF_F32 ? 2 : 1);
-      if (EPI == SAF_QW_QUERY_MAX) {
-        const unsigned long long best = w2_query_max_reduce(fs.qk, r);
-        if ((r & 1) == 0) {  // one atomic per query and half-wave, all in one instruction
-          const int i = ((r >> 4) & 1) * 8 + ((r >> 3) & 1) * 4 + ((r >> 2) & 1) * 2 + ((r >> 1) & 1);
-          atomicMax(&wa.qkeys[prev.qt * kWTile + 4 * h + 8 * (i >> 2) + (i & 3)], best);
-        }
+      if (EPI == SAF_QW_QUERY_MAX) {  // the two halves of a query's rows, then one atomic instruction: 32 queries
+        const uint32_t row = (uint32_t)(prev.row[0] - r + wa.row_offset) + (uint32_t)fs.bm + 4u * (uint32_t)h;
+        const uint32_t khi = ordered_bits(fs.bv), klo = ~row;
+        const unsigned long long key = ((unsigned long long)khi << 32) | klo;
+        const unsigned long long other = __shfl_xor(key, 32);
+        const unsigned long long best = other > key ? other : key;
+        if (h == 0) atomicMax(&wa.qkeys[prev.qt * kWTile + r], best);
       }
+    }
+    if (EPI == SAF_QW_QUERY_MAX && qt == 0) {
+      // The new block's 1/norms, by row -- only now: this step's epilogue pieces were the LAST tile of the block before.
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+        if (h == 0) s_inv[32 * f + r] = cur.inv[f];  // (read back by this wave only: the LDS keeps a wave's accesses in order)
     }
     if (qt == 0) W2_STAMP(4); else W2_STAMP(5);  // the tile: LDS reads, MFMAs, the previous tile's epilogue (4: first tile of a block, waits for its rows)
     if (more && !kDma) {
@@ -877,7 +845,7 @@ int launch_wide_ot(int ot, int D, const uint16_t* feats, int64_t n_rows, int64_t
 
 template <int FT, int OT, int KS, int EPI, int NF, int TH>
 int launch_wide2_nf(const Wide2Args& wa, hipStream_t s) {
-  constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16);
+  constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16) + (EPI == SAF_QW_QUERY_MAX ? (TH / 64) * 32 * NF * sizeof(float) : 0);
   auto fn = query_wide2_kernel<FT, OT, KS, EPI, NF, TH>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -902,8 +870,8 @@ int launch_wide2(const Wide2Args& wa, hipStream_t s) {
   if (rows_env == 33) return launch_wide2_nf<FT, OT, KS, EPI, 1, 256>(wa, s);  // two workgroups of 4 waves per CU
 #endif
   // measured at config 5 (ms, 32 vs 64 rows per wave): heat maps 27.5 / 31.4, best query per voxel 19.3 / 20.4, raw scores
-  // 25.7 / 27.8, best voxel per query 55.5 / 45.0 (its per-tile shuffle reduction is per WAVE, so fewer, larger waves win)
-  if (EPI == SAF_QW_QUERY_MAX) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
+  // 25.7 / 27.8 (rounds 2-3: the best voxel per query ran at 64 -- its reduction over the lanes of a wave was per tile; with the
+  // operands swapped there is none)
   return launch_wide2_nf<FT, OT, KS, EPI, 1, 512>(wa, s);
 }
 
