@@ -924,7 +924,8 @@ def side_workloads(a, device, L, frames_A, npy, npx):
               "BASELINE config 2's shape: 512 frames 640x480 (depth A) into a 128^3 x 512 fp32 grid (resident ViT-B/32-shaped features)")
     if a.dim % 512 == 0:
         fuse_case("config3_256cube_bf16_labels", 256, torch.bfloat16, True, frames_A,
-                  "BASELINE config 3's fused part: 512 frames into a 256^3 x 512 bf16 grid + the 143-class label histogram")
+                  "BASELINE config 3's fused part: 512 frames into a 256^3 x 512 bf16 grid + the 143-class label histogram "
+                  "(bf16 features: the window's map images are kept in bf16, DESIGN 4.6c)")
     nb = min(128, uniq)
     frames_B = gen_frames_gpu(nb, a.width, a.height, a.dim, npy, npx, "B", 2000, device)
     fuse_case("coherent_scene_depth_B", 256, torch.float32, False, frames_B,

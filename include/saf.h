@@ -137,7 +137,9 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
  *             row's samples of the window are summed in registers and the row is blended once, (w0 old + sum) / (w0 + k): the
  *             running mean of clipfusion.py:715-721 with the window's k updates folded into one -- feature values within fp32
  *             rounding of frame-after-frame fusion (bf16: one rounding per window instead of one per hit), reproducible
- *             bit for bit from run to run;
+ *             bit for bit from run to run.  For a bf16 volume this form also keeps the window's feature maps in bf16 (rounded
+ *             once, to nearest even, when they are re-laid for the taps): exact when the backbone emitted bf16 features
+ *             (BASELINE config 3), otherwise one more rounding at the volume's own precision per tap;
  *      rows   the same widths, hits applied one by one in frame order: feature rows bit-identical to the per-frame pipeline;
  *      bricks every other width (and on request): brick-resident rows, map taps shared, fixed-point sums; same contract as sums.
  *    SAF_WINDOW=0 in the environment forces the per-frame pipeline. */

@@ -76,13 +76,21 @@ __device__ __forceinline__ void file_frames(const ClsArgs& ca, WinTable* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restrict__ tab, float* __restrict__ imgs,
-                                                        int img_floats, int D, int P) {
+// img_elems: elements (f32, or bf16 when `as_bf16`) from one frame's image to the next.  bf16 images (bf16 volumes in the
+// order-free form): a tap is 16 bytes per 8 channels instead of 32 -- half the bytes through the L1 path that bounds the row
+// kernel, and the window's table (128 frames x 36 cells x D) at 4.7 MB instead of 9.4 sits in an XCD's L2.  The features are
+// rounded ONCE to the volume's precision (round to nearest even); exact when the backbone emitted bf16 (BASELINE config 3).
+__global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restrict__ tab, void* __restrict__ imgs,
+                                                        int img_elems, int D, int P, int as_bf16) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= (P + 1) * D) return;
   const float* __restrict__ feat_map = tab->feat_map[blockIdx.y];
   const int c = o % D, p = o / D;
-  imgs[(size_t)blockIdx.y * img_floats + o] = p < P ? feat_map[(size_t)c * P + p] : 0.0f;
+  const float x = p < P ? feat_map[(size_t)c * P + p] : 0.0f;
+  if (as_bf16)
+    static_cast<uint16_t*>(imgs)[(size_t)blockIdx.y * img_elems + o] = (uint16_t)f32_to_bf16_bits(x);
+  else
+    static_cast<float*>(imgs)[(size_t)blockIdx.y * img_elems + o] = x;
 }
 
 
@@ -97,6 +105,9 @@ __device__ unsigned long long g_win_t[16];
 #define WT_FLUSH
 #endif
 
+#ifndef SAF_WIN_MAPS16_BUILD
+#define SAF_WIN_MAPS16_BUILD 1  // bf16 volumes, order-free form: bf16 map images (0: f32 images, the A/B)
+#endif
 #ifndef SAF_WIN_P2
 #define SAF_WIN_P2 2  // tap groups in flight: 2 -> 133 VGPRs, so that two row-kernel waves leave room for classification waves on a SIMD (alone, 2 / 3 / 4 / 6 time the same)
 #endif
@@ -676,6 +687,54 @@ template <int NB, int CPL, bool SUM, bool BF16, int SR>
 __device__ __forceinline__ void win_batch_of(const WinCtx<CPL>& cx, const int (&hl)[NB + 1], int nb, const WinGroupOffs& go,
                                              const WinHit& rec, const unsigned long long (&rm)[SR],
                                              win_v2f (&acc)[SR][2 * CPL]) {
+  if constexpr (BF16 && SAF_WIN_MAPS16_BUILD) {  // bf16 map images: one 16-byte load per tap and unit of 8 channels, widened in the FMA operands
+    constexpr int UPL = CPL / 2;
+    uint4 tq[NB][4][UPL];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const bool real = u < nb;
+      const int hu = real ? hl[u] : 0;
+      const int o4[4] = {real ? __builtin_amdgcn_readlane(go.nw, hu) : (int)(kTapOutside + 0x10000u * (4 * u)),
+                         real ? __builtin_amdgcn_readlane(go.ne, hu) : (int)(kTapOutside + 0x10000u * (4 * u + 1)),
+                         real ? __builtin_amdgcn_readlane(go.sw, hu) : (int)(kTapOutside + 0x10000u * (4 * u + 2)),
+                         real ? __builtin_amdgcn_readlane(go.se, hu) : (int)(kTapOutside + 0x10000u * (4 * u + 3))};
+#pragma unroll
+      for (int k = 0; k < UPL; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          tq[u][t][k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(cx.maps, (int)((uint32_t)o4[t] + (uint32_t)cx.lane * 16u + (uint32_t)k * 1024u), 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const unsigned long long below_hi = hl[u + 1] >= 64 ? ~0ull : ((1ull << hl[u + 1]) - 1ull);
+      const unsigned long long range = below_hi & ~((1ull << hl[u]) - 1ull);
+#pragma unroll
+      for (int R = 0; R < SR; ++R) {
+        unsigned long long m = rm[R] & range;
+        while (m) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          const float wt[4] = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.nw), l)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.ne), l)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.sw), l)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec.se), l))};
+#pragma unroll
+          for (int k = 0; k < UPL; ++k) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const uint4 w = tq[u][t][k];
+              const win_v2f ww = {wt[t], wt[t]};
+              acc[R][4 * k + 0] = __builtin_elementwise_fma((win_v2f){bf16_lo(w.x), bf16_hi(w.x)}, ww, acc[R][4 * k + 0]);
+              acc[R][4 * k + 1] = __builtin_elementwise_fma((win_v2f){bf16_lo(w.y), bf16_hi(w.y)}, ww, acc[R][4 * k + 1]);
+              acc[R][4 * k + 2] = __builtin_elementwise_fma((win_v2f){bf16_lo(w.z), bf16_hi(w.z)}, ww, acc[R][4 * k + 2]);
+              acc[R][4 * k + 3] = __builtin_elementwise_fma((win_v2f){bf16_lo(w.w), bf16_hi(w.w)}, ww, acc[R][4 * k + 3]);
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   float4 tp[NB][4][CPL];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
@@ -740,7 +799,11 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
   constexpr int SR = Cfg::SR;
   // (s_setprio 1 / 3 here, ahead of the classification waves that share the SIMDs, changes nothing: 105.4 / 105.7 / 105.8 ms)
   // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
-  constexpr int P = OF ? Cfg::P : (BF16 && Cfg::P > 2 ? Cfg::P - 1 : (BF16 && CPL == 4 ? 1 : Cfg::P));  // (bf16, D = 1024: two groups of 64 tap registers in flight spilled)
+#ifndef SAF_WIN_OF_P16
+#define SAF_WIN_OF_P16 0  // tap groups in flight with bf16 map images at D = 512 (0: as for f32 images; their registers are half as many)
+#endif
+  constexpr int P = OF ? ((BF16 && SAF_WIN_MAPS16_BUILD && CPL == 2 && SAF_WIN_OF_P16 > 0) ? SAF_WIN_OF_P16 : Cfg::P)
+                       : (BF16 && Cfg::P > 2 ? Cfg::P - 1 : (BF16 && CPL == 4 ? 1 : Cfg::P));  // (bf16, D = 1024: two groups of 64 tap registers in flight spilled)
   extern __shared__ __align__(16) unsigned char s_dyn[];
 #ifdef SAF_WIN_PRIO
   __builtin_amdgcn_s_setprio(SAF_WIN_PRIO);
@@ -779,6 +842,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
   }
   __syncthreads();
   const int DV = v.D >> 2;
+  const int DVM = (BF16 && OF && SAF_WIN_MAPS16_BUILD) ? v.D >> 3 : v.D >> 2;  // 16-byte vectors of a MAP row (bf16 map images in the order-free form of a bf16 volume)
   const float half_px = (float)wa.npx / 2.0f, half_py = (float)wa.npy / 2.0f;
   const int zero_row = wa.npx * wa.npy;
   int chs[CPL];
@@ -980,7 +1044,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..kSubHits
         WinRaw<SR, UPL> raw;
         raw.nrows = nrows;
-        const WinCtx<CPL> cx{maps_rsrc, img_vecs, DV, wa.npx, wa.npy, zero_row, lane, rows};
+        const WinCtx<CPL> cx{maps_rsrc, img_vecs, DVM, wa.npx, wa.npy, zero_row, lane, rows};
         // order-free form: acc[r] = the old row (never scaled: the hits' weights are, by 1 / w0), then the window's samples
         win_v2f acc[OF ? SR : 1][2 * CPL];
         // Several rows with more than 64 hits between them (coherent scenes: ~15 hits per row): the staging entries of the
@@ -1427,7 +1491,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const int P = kf0.npy * kf0.npx;
   const WinLayout wl = win_layout(kv.N, kv.D, P);
   const bool sum = kv.accum == SAF_SUM;
-  const int img_vecs = (int)(wl.img_bytes / sizeof(float4));
+  int img_vecs = (int)(wl.img_bytes / sizeof(float4));
   const int prep_blocks = (kv.D * (P + 1) + 255) / 256;
   const size_t aux_bytes = workspace_bytes > wl.cmax_off ? workspace_bytes - wl.cmax_off : 0;
   const bool brick_form = brick_form_ok(kv) && aux_bytes > 0 && brick_aux_fits(kv, aux_bytes);
@@ -1441,6 +1505,10 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     case 3: fn = pick_win<3>(sum, kv.bf16 != 0, of, &win_lds); break;
     default: fn = pick_win<4>(sum, kv.bf16 != 0, of, &win_lds); break;
   }
+  // bf16 volume in the order-free form: the window's map images are kept in bf16 (what the kernel's BF16 && OF instantiations read)
+  const bool maps16 = !brick_form && of && kv.bf16 != 0 && SAF_WIN_MAPS16_BUILD;
+  const size_t img_bytes16 = ((size_t)kv.D * (P + 1) * 2 + 255) & ~(size_t)255;
+  if (maps16) img_vecs = (int)(img_bytes16 / sizeof(float4));
   if (!brick_form) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)win_lds);
@@ -1601,8 +1669,8 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (ov && hipStreamWaitEvent(s, ov->cls_done[par], 0) != hipSuccess) { rc = fail(SAF_E_HIP, "hipStreamWaitEvent"); break; }
     if (maps_of != u.window) {  // (the slabs of one window share its map images)
       ScopedPair t(prof, 0, f0, s);
-      hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, maps,
-                         (int)(wl.img_bytes / sizeof(float)), kv.D, P);
+      hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, static_cast<void*>(maps),
+                         maps16 ? (int)(img_bytes16 / 2) : (int)(wl.img_bytes / sizeof(float)), kv.D, P, maps16 ? 1 : 0);
       if ((rc = check_launch("prep_rows_kernel"))) break;
       maps_of = u.window;
     }

@@ -1107,6 +1107,8 @@ def test_wide_scan_v2_scores_and_epilogues(oracle, dt, dim, out_dt, n, q):
     g = torch.Generator().manual_seed(1234 + n)
     feats = torch.randn(n, dim, generator=g).to(dt)
     feats[min(77, n - 1)] = 0
+    if n > 300:
+        feats[229] = feats[100]  # tied rows (other lane half, other register): the first one must win the per-query maximum
     text = torch.randn(q, dim, generator=g)
     text = text / text.norm(dim=-1, keepdim=True)
     if q > 20:
@@ -1153,6 +1155,8 @@ def test_wide_scan_v2_scores_and_epilogues(oracle, dt, dim, out_dt, n, q):
     assert bool(((qr.cpu() >= 5000) & (qr.cpu() < 5000 + n)).all())
     assert (want[qr.cpu() - 5000, torch.arange(q)] - wv).abs().max().item() <= 3e-5
     assert (qr.cpu() == wr).float().mean().item() > 0.99
+    if n > 300:
+        assert not bool((qr.cpu() == 5000 + 229).any()), "of two tied rows the first must win"
     # empty input: no row, no maximum
     ev, er = query_scan_wide(fd[:0], td, "query_max")
     assert bool((er == -1).all()) and bool(torch.isinf(ev).all())
