@@ -96,9 +96,11 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restri
 
 #ifdef SAF_WIN_TIMING  // development aid: per-phase wave cycles of the window kernel, printed by the host
 __device__ unsigned long long g_win_t[16];
-#define WT_DECL unsigned long long wt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last_ = __builtin_readcyclecounter()
+#define WT_DECL unsigned long long wt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last_ = __builtin_readcyclecounter(), wt_c0_ = wt_last_, wt_r0_ = __builtin_amdgcn_s_memrealtime()
 #define WT(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); wt_[k] += n_ - wt_last_; wt_last_ = n_; } while (0)
-#define WT_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_win_t[k_], wt_[k_]); } while (0)
+#define WT_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_win_t[k_], wt_[k_]); \
+    if (lane == 0 && threadIdx.x < 64 && blockIdx.x == 0) { /* the shader clock over this workgroup's life: s_memtime ticks per 100 MHz tick */ \
+      atomicAdd(&g_win_t[8], __builtin_readcyclecounter() - wt_c0_); atomicAdd(&g_win_t[9], __builtin_amdgcn_s_memrealtime() - wt_r0_); } } while (0)
 #else
 #define WT_DECL
 #define WT(k)
@@ -1707,6 +1709,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       fprintf(stderr, "[win timing] masks %.1f%% expand %.1f%% project %.1f%% scalars %.1f%% records + row issue %.1f%% groups %.1f%% tap batches %.1f%% row store %.1f%% (total %.3g wave-cycles)\n",
               100.0 * t[0] / tot, 100.0 * t[1] / tot, 100.0 * t[2] / tot, 100.0 * t[3] / tot, 100.0 * t[4] / tot,
               100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, (double)tot);
+      if (t[9]) fprintf(stderr, "[win timing] shader clock during the row kernels of this call: %.3f GHz (s_memtime / s_memrealtime x 100 MHz)\n", 0.1 * (double)t[8] / (double)t[9]);
       memset(t, 0, sizeof(t));
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_win_t), t, sizeof(t));
     }
