@@ -373,9 +373,10 @@ __device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t 
           const bool rescale = (wa.flags & 1) != 0;  // query_mesh.py:39: ((r - 0.5) * 2).clamp(0, 1)
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            float p = __builtin_amdgcn_rcpf(1.0f + __expf(st.lse[f] - v[i]));
-            if (rescale) p = fminf(fmaxf((p - 0.5f) * 2.0f, 0.0f), 1.0f);
-            v[i] = p;
+            // (the same arithmetic as w2_fast_piece: interior and edge tiles of one output agree bit for bit)
+            const float p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(c[f][i], -t.inv[f] * 1.4426950408889634f,
+                                                                                                  st.lse[f] * 1.4426950408889634f)));
+            v[i] = __builtin_amdgcn_fmed3f(__builtin_fmaf(p, rescale ? 2.0f : 1.0f, rescale ? -1.0f : 0.0f), 0.0f, 1.0f);
           }
           col0 = qbase - kWTile;
         }
@@ -482,6 +483,7 @@ template <int NF>
 struct W2Fast {
   float v[NF][16];                 // scaled scores / probabilities of the previous tile (SCORES, VS_BACKGROUND)
   float iv[NF][4];                // QUERY_MAX: 1/norm of the rows behind the current group of four registers
+  float ka[NF], kb[NF];           // VS_BACKGROUND: the row's -inv log2(e) and lse log2(e)
   float bv; int bm;               // QUERY_MAX: the lane's best score of the tile so far and its row (without the 4 h of the half)
 };
 
@@ -493,11 +495,19 @@ __device__ __forceinline__ void w2_fast_piece(int i, const Wide2Args& wa, const 
     const bool rescale = (wa.flags & 1) != 0;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      float x = c[f][i] * t.inv[f];
+      float x;
       if (EPI == SAF_QW_VS_BACKGROUND) {
-        float p = __builtin_amdgcn_rcpf(1.0f + __expf(st.lse[f] - x));
-        const float pr = fminf(fmaxf((p - 0.5f) * 2.0f, 0.0f), 1.0f);
-        x = rescale ? pr : p;
+        // 1 / (1 + exp(lse - z)), z = c * inv, as 1 / (1 + 2^(c ka + kb)) with the row's ka = -inv log2(e), kb = lse log2(e);
+        // query_mesh.py:39's ((p - 0.5) * 2).clamp(0, 1) is clamp(2 p - 1): one FMA whose constants the flag picks (p itself
+        // lies in (0, 1]: the clamp is harmless without the rescale).  Six vector instructions per score instead of eleven.
+        if (i == 0) {
+          fs.ka[f] = -t.inv[f] * 1.4426950408889634f;
+          fs.kb[f] = st.lse[f] * 1.4426950408889634f;
+        }
+        const float p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(c[f][i], fs.ka[f], fs.kb[f])));
+        x = __builtin_amdgcn_fmed3f(__builtin_fmaf(p, rescale ? 2.0f : 1.0f, rescale ? -1.0f : 0.0f), 0.0f, 1.0f);
+      } else {
+        x = c[f][i] * t.inv[f];
       }
       fs.v[f][i] = x;
       if ((i & 7) == 7) {  // registers 8 gp .. 8 gp + 7 are complete: this lane's 8 columns of the pair of groups gp
