@@ -289,6 +289,8 @@ int saf_query_scan_wide(const void* feats, int32_t feat_dtype, int64_t n_rows, i
  *                         ((r - 0.5) * 2).clamp(0, 1).  out is [n_rows, n_text - n_background].
  *   SAF_QW_ROW_ARGMAX     per row the best query and its score: out_index[n] i32, out_value[n] f32
  *                         (eval_scannet_segmentation.py:553-560: the first label of the argsort); nothing N x Q is written.
+ *                         The dot products are compared before the row's scale / norm is applied (one factor per row;
+ *                         a negative scale is folded into the text): of equal products the first query wins.
  *   SAF_QW_QUERY_MAX      per query the best row and its score: out_value[q] f32, out_row[q] i64 = row_offset + local
  *                         row (equal scores: the smaller row), -1 / -inf when n_rows = 0; row_offset lets ranks that
  *                         scan voxel shards report global voxel indices.

@@ -435,7 +435,9 @@ __device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t 
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int q = qbase + 8 * (i >> 2) + (i & 3);
-        float x = c[f][i] * t.inv[f];
+        // the RAW dot products are compared: a row's scale / norm is one non-negative factor for all of its queries (a negative
+        // `scale` arrives as negated text, see the host side), multiplied in once, into the row's best
+        float x = c[f][i];
         if (last && q >= wa.Q) x = -INFINITY;  // zero-padded text rows are no candidates
         if (x > bv) { bv = x; bq = q; }        // queries ascend: the first maximum stays
       }
@@ -444,7 +446,7 @@ __device__ __forceinline__ void w2_epilogue(const Wide2Args& wa, const f32x16_t 
         const float ov = __shfl_xor(bv, 32);
         const int oq = __shfl_xor(bq, 32);
         if (ov > bv || (ov == bv && oq < bq)) { bv = ov; bq = oq; }
-        if (h == 0 && t.row[f] < wa.n_rows) { wa.out_index[t.row[f]] = bq; wa.out_value[t.row[f]] = bv; }
+        if (h == 0 && t.row[f] < wa.n_rows) { wa.out_index[t.row[f]] = bq; wa.out_value[t.row[f]] = bv * t.inv[f]; }
       }
       st.best_v[f] = bv;
       st.best_q[f] = bq;
@@ -534,7 +536,7 @@ __device__ __forceinline__ void w2_fast_piece(int i, const Wide2Args& wa, const 
     const int q = qbase + 8 * (i >> 2) + (i & 3);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const float x = c[f][i] * t.inv[f];
+      const float x = c[f][i];               // raw dot products: see w2_epilogue
       const bool better = x > st.best_v[f];  // queries ascend: the first maximum stays
       st.best_v[f] = better ? x : st.best_v[f];
       st.best_q[f] = better ? q : st.best_q[f];
@@ -912,14 +914,15 @@ int launch_wide2_epi(int epi, int ot, const Wide2Args& wa, hipStream_t s) {
 // first n_bg rows (the shared background prompts) fill tile 0, zero padded to 32 rows; target t is row 32 + t.
 template <int FT>
 __global__ void text_tiles_kernel(const float* __restrict__ text, int Q, int64_t tstride, int D, int Qpad, int n_bg,
-                                  uint16_t* __restrict__ out, unsigned long long* __restrict__ qkeys) {
+                                  uint16_t* __restrict__ out, unsigned long long* __restrict__ qkeys, int negate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (qkeys && i < Qpad) qkeys[i] = 0ull;
   if (i >= Qpad * D) return;
   const int q = i / D, k = i - q * D;
   int src = q;
   if (n_bg > 0) src = q < kWTile ? (q < n_bg ? q : -1) : q - kWTile + n_bg;
-  const float v = (src >= 0 && src < Q) ? text[(int64_t)src * tstride + k] : 0.0f;
+  float v = (src >= 0 && src < Q) ? text[(int64_t)src * tstride + k] : 0.0f;
+  if (negate) v = -v;  // ROW_ARGMAX with a negative scale: -text and |scale| give the same scores, and the rows' factor stays >= 0
   const int o = i;
   if (FT == SAF_BF16) {
     out[o] = (uint16_t)f32_to_bf16_bits(v);
@@ -1031,12 +1034,15 @@ int saf_query_scan_wide_ex(const void* feats, int32_t feat_dtype, int64_t n_rows
   unsigned long long* qkeys = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(workspace) +
                                                                    (((size_t)Qpad * feat_dim * 2 + 255) & ~(size_t)255));
   const int items = Qpad * feat_dim;
+  // ROW_ARGMAX compares raw dot products (a row's scale / norm must not flip their order): a negative scale goes into the text
+  const int negate = epilogue == SAF_QW_ROW_ARGMAX && scale < 0.0f ? 1 : 0;
+  if (negate) scale = -scale;
   if (feat_dtype == SAF_BF16)
     hipLaunchKernelGGL(text_tiles_kernel<SAF_BF16>, dim3((items + 255) / 256), dim3(256), 0, s, text, n_text, text_stride,
-                       feat_dim, Qpad, n_bg, text16, epilogue == SAF_QW_QUERY_MAX ? qkeys : nullptr);
+                       feat_dim, Qpad, n_bg, text16, epilogue == SAF_QW_QUERY_MAX ? qkeys : nullptr, negate);
   else
     hipLaunchKernelGGL(text_tiles_kernel<SAF_F16>, dim3((items + 255) / 256), dim3(256), 0, s, text, n_text, text_stride,
-                       feat_dim, Qpad, n_bg, text16, epilogue == SAF_QW_QUERY_MAX ? qkeys : nullptr);
+                       feat_dim, Qpad, n_bg, text16, epilogue == SAF_QW_QUERY_MAX ? qkeys : nullptr, negate);
   int rc = check_launch("text_tiles_kernel");
   if (rc) return rc;
   if (n_rows > 0) {

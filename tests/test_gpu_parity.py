@@ -1147,6 +1147,12 @@ def test_wide_scan_v2_scores_and_epilogues(oracle, dt, dim, out_dt, n, q):
     assert agree > 0.999, f"row_argmax agrees with the oracle on only {agree:.4f} of the rows"
     if q > 20:
         assert not bool((idx.cpu() == 17).any()), "of two tied queries the first must win"
+    # a negative scale: the largest of scale * score is the smallest score (the kernel compares raw dot products of negated text)
+    idx_n, val_n = query_scan_wide(fd, td, "row_argmax", scale=-2.0)
+    live = torch.ones(n, dtype=torch.bool)
+    live[min(77, n - 1)] = False  # the all-zero row: every query ties at 0
+    assert (val_n.cpu() - (-2.0) * want.min(dim=1).values)[live].abs().max().item() <= 6e-5
+    assert (want[torch.arange(n), idx_n.cpu().long()] - want.min(dim=1).values)[live].abs().max().item() <= 3e-5
     # per-query maximum over the rows, with a row offset (voxel shards report global indices)
     qv, qr = query_scan_wide(fd, td, "query_max", row_offset=5000)
     wv, wr = oracle.wide_scan(feats, text, "query_max", row_offset=5000, round_to=dt)
