@@ -48,6 +48,19 @@ __device__ __forceinline__ float elem16_to_f32(uint16_t b) {
   return (float)__builtin_bit_cast(_Float16, b);
 }
 
+// acc + lo^2 + hi^2 of a pair of 16-bit elements
+template <int FT>
+__device__ __forceinline__ float dot2_self(uint32_t w, float acc) {
+  if (FT == SAF_BF16) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    const bf2_t v = __builtin_bit_cast(bf2_t, w);
+    return __builtin_amdgcn_fdot2_f32_bf16(v, v, acc, false);
+  }
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const h2_t v = __builtin_bit_cast(h2_t, w);
+  return __builtin_amdgcn_fdot2(v, v, acc, false);
+}
+
 template <int OT>
 __device__ __forceinline__ void store_score(void* __restrict__ out, int64_t idx, float v) {
   if (OT == SAF_F32) {
@@ -645,17 +658,19 @@ query_wide2_kernel(Wide2Args wa) {
       for (int f = 0; f < NF; ++f) {
         cur.inv[f] = wa.scale;
         if (wa.normalize) {
-          float ss = 0.f;
+          // the row's squared norm: one v_dot2_f32_{f16,bf16} per pair of elements (exact products, fp32 sums) -- a quarter of the
+          // instructions of widening and two FMAs per pair; two chains, added at the end
+          float ss = 0.f, ss2 = 0.f;
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
             const uint32_t w[4] = {a[f][s].x, a[f][s].y, a[f][s].z, a[f][s].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float lo = elem16_to_f32<FT>((uint16_t)(w[j] & 0xffffu)), hi = elem16_to_f32<FT>((uint16_t)(w[j] >> 16));
-              ss = __builtin_fmaf(lo, lo, ss);
-              ss = __builtin_fmaf(hi, hi, ss);
+            for (int j = 0; j < 4; j += 2) {
+              ss = dot2_self<FT>(w[j], ss);
+              ss2 = dot2_self<FT>(w[j + 1], ss2);
             }
           }
+          ss += ss2;
           ss += __shfl_xor(ss, 32);
           // SAF_NORM_L2_CLAMP: norm.clamp_min(0.1); SAF_NORM_L2 with nan_to_num: an all-zero row scores 0
           cur.inv[f] = wa.normalize == SAF_NORM_L2_CLAMP ? wa.scale / fmaxf(sqrtf(ss), 0.1f)
@@ -744,15 +759,62 @@ query_wide2_kernel(Wide2Args wa) {
       tail_ops = 0;
     } else {
       W2Fast<NF> fs;
+      // ROW_ARGMAX: the tile's best per lane is a chain over the 16 accumulator registers of the previous tile -- compare
+      // (v_cmp) behind one MFMA, the two selects behind the NEXT one: the MFMA and the LDS read between them are the wait
+      // states a v_cndmask needs behind the v_cmp that wrote its mask (the compiler filled them with s_nop), and the winner's
+      // query is selected from constants (its index inside the tile), the tile's base added once per tile.  3 instructions per
+      // register instead of 5 in a kernel the power limit binds.
+      float ra_v[NF], ra_x[NF];
+      int ra_i[NF];
+      bool ra_b[NF];
+      int ra_pending = -1;
+      auto ra_idc = [](int i) { return 8 * (i >> 2) + (i & 3); };
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) c[f] = kSwap ? mfma16<FT>(a[f][s], t[s], s == 0 ? zero16 : c[f]) : mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
         if (kDma && ((s == kLateAt && late) || (SAF_W2_DMA_AT > 0 && s == SAF_W2_DMA_AT && !late)) && more) dma_next();
+        if (EPI == SAF_QW_ROW_ARGMAX) {
+          if (ra_pending >= 0) {
 #pragma unroll
-        for (int i = (s * 16) / KS; i < ((s + 1) * 16) / KS; ++i) w2_fast_piece<OT, EPI, NF>(i, wa, pc, prev, st, fs, r, h, n_qt);
+            for (int f = 0; f < NF; ++f) {
+              ra_v[f] = ra_b[f] ? ra_x[f] : ra_v[f];
+              ra_i[f] = ra_b[f] ? ra_idc(ra_pending) : ra_i[f];
+            }
+            ra_pending = -1;
+          }
+#pragma unroll
+          for (int i = (s * 16) / KS; i < ((s + 1) * 16) / KS; ++i) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              ra_x[f] = pc[f][i];  // raw dot products: see w2_epilogue
+              if (i == 0) {
+                ra_v[f] = ra_x[f];
+                ra_i[f] = 0;
+              } else {
+                ra_b[f] = ra_x[f] > ra_v[f];  // queries ascend: the first maximum stays
+              }
+            }
+            if (i > 0) ra_pending = i;
+          }
+        } else {
+#pragma unroll
+          for (int i = (s * 16) / KS; i < ((s + 1) * 16) / KS; ++i) w2_fast_piece<OT, EPI, NF>(i, wa, pc, prev, st, fs, r, h, n_qt);
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep the pieces where they are: between the MFMAs
+      }
+      if (EPI == SAF_QW_ROW_ARGMAX) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          if (ra_pending >= 0) {
+            ra_v[f] = ra_b[f] ? ra_x[f] : ra_v[f];
+            ra_i[f] = ra_b[f] ? ra_idc(ra_pending) : ra_i[f];
+          }
+          const bool better = ra_v[f] > st.best_v[f];  // tiles ascend: the first maximum stays
+          st.best_v[f] = better ? ra_v[f] : st.best_v[f];
+          st.best_q[f] = better ? prev.qt * kWTile + 4 * h + ra_i[f] : st.best_q[f];
+        }
       }
       // what this step issued behind its transfer, at the very least: the stores of registers 8-15 (one per fragment for
       // 16-bit scores, two for fp32) or the atomic below
