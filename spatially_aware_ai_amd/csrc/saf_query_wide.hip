@@ -775,7 +775,7 @@ query_wide2_kernel(Wide2Args wa) {
         for (int f = 0; f < NF; ++f) c[f] = kSwap ? mfma16<FT>(a[f][s], t[s], s == 0 ? zero16 : c[f]) : mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
         if (kDma && ((s == kLateAt && late) || (SAF_W2_DMA_AT > 0 && s == SAF_W2_DMA_AT && !late)) && more) dma_next();
-        if (EPI == SAF_QW_ROW_ARGMAX) {
+        if (EPI == SAF_QW_ROW_ARGMAX || EPI == SAF_QW_QUERY_MAX) {
           if (ra_pending >= 0) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
@@ -788,7 +788,15 @@ query_wide2_kernel(Wide2Args wa) {
           for (int i = (s * 16) / KS; i < ((s + 1) * 16) / KS; ++i) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-              ra_x[f] = pc[f][i];  // raw dot products: see w2_epilogue
+              if (EPI == SAF_QW_QUERY_MAX) {  // (swapped operands: the chain runs over the lane's ROWS, each with its own 1 / norm)
+                if ((i & 3) == 0) {
+                  const float4 v4 = *reinterpret_cast<const float4*>(st.inv_lds + 32 * f + 8 * (i >> 2) + 4 * h);
+                  fs.iv[f][0] = v4.x; fs.iv[f][1] = v4.y; fs.iv[f][2] = v4.z; fs.iv[f][3] = v4.w;
+                }
+                ra_x[f] = pc[f][i] * fs.iv[f][i & 3];
+              } else {
+                ra_x[f] = pc[f][i];  // raw dot products: see w2_epilogue
+              }
               if (i == 0) {
                 ra_v[f] = ra_x[f];
                 ra_i[f] = 0;
@@ -804,16 +812,24 @@ query_wide2_kernel(Wide2Args wa) {
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the pieces where they are: between the MFMAs
       }
-      if (EPI == SAF_QW_ROW_ARGMAX) {
+      if (EPI == SAF_QW_ROW_ARGMAX || EPI == SAF_QW_QUERY_MAX) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           if (ra_pending >= 0) {
             ra_v[f] = ra_b[f] ? ra_x[f] : ra_v[f];
             ra_i[f] = ra_b[f] ? ra_idc(ra_pending) : ra_i[f];
           }
-          const bool better = ra_v[f] > st.best_v[f];  // tiles ascend: the first maximum stays
-          st.best_v[f] = better ? ra_v[f] : st.best_v[f];
-          st.best_q[f] = better ? prev.qt * kWTile + 4 * h + ra_i[f] : st.best_q[f];
+          if (EPI == SAF_QW_ROW_ARGMAX) {
+            const bool better = ra_v[f] > st.best_v[f];  // tiles ascend: the first maximum stays
+            st.best_v[f] = better ? ra_v[f] : st.best_v[f];
+            st.best_q[f] = better ? prev.qt * kWTile + 4 * h + ra_i[f] : st.best_q[f];
+          } else if (f == 0) {
+            fs.bv = ra_v[0]; fs.bm = ra_i[0];
+          } else {
+            const bool better = ra_v[f] > fs.bv;  // rows ascend with the fragment: the first maximum stays
+            fs.bv = better ? ra_v[f] : fs.bv;
+            fs.bm = better ? 32 * f + ra_i[f] : fs.bm;
+          }
         }
       }
       // what this step issued behind its transfer, at the very least: the stores of registers 8-15 (one per fragment for
