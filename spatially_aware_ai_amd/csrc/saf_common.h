@@ -142,7 +142,20 @@ __device__ __forceinline__ float div_by_uniform(float a, float b, float y) {
   return __builtin_fmaf(r1, y, q1);
 }
 
-// clipfusion.py:654-659: uv = uvz[:2] / z ; grid = ((uv + 0.5) / [W, H]) * 2 - 1
+// clipfusion.py:654-659: uv = uvz[:2] / z ; grid = ((uv + 0.5) / [W, H]) * 2 - 1.  finish_from_uv: everything behind the
+// two IEEE divisions (qu = u / z, qv = v / z).
+__device__ __forceinline__ Proj finish_from_uv(const Cam& c, float qu, float qv, float z) {
+  Proj p;
+  float gx = qu + 0.5f, gy = qv + 0.5f;
+  gx = div_by_uniform(gx, c.fw, c.rfw);
+  gy = div_by_uniform(gy, c.fh, c.rfh);
+  gx = gx * 2.0f;
+  gy = gy * 2.0f;
+  p.gx = gx - 1.0f;
+  p.gy = gy - 1.0f;
+  p.z = z;
+  return p;
+}
 __device__ __forceinline__ Proj finish_projection(const Cam& c, const Uvz& h) {
   Proj p;
   float gx = h.u / h.z, gy = h.v / h.z;

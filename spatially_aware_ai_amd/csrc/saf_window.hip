@@ -57,6 +57,9 @@ struct ClsArgs {
   int n, H, W;  // frames of this launch (<= kClsFrames), image size
   int slot;     // index of the launch's first frame within the window (0, 32, 64, 96)
   int count;    // 1: this launch counts its frames in stats[2] (a window classified slab by slab counts them once)
+  float guard_x, guard_y;  // SAF_CLS_GUARD: W * 2^-20, H * 2^-20 (2: always the reference's chain -- images wider than 8192)
+  float mid_x, mid_y;      // (W - 1) / 2, (H - 1) / 2
+  unsigned long long* verify;  // SAF_CLS_GUARD = 2 (development): disagreements of the two paths are counted here
   const float* depth[kClsFrames];
   const float* rgb[kClsFrames];
   const float* pose[kClsFrames];
@@ -121,6 +124,12 @@ __device__ unsigned long long g_win_t[16];
 #endif
 #ifndef SAF_CLS_BUFLD
 #define SAF_CLS_BUFLD 1  // depth gathers through a buffer descriptor of the frame's image (0: 64-bit addresses)
+#endif
+#ifndef SAF_CLS_GUARD
+#define SAF_CLS_GUARD 1  // the voxel's pixel from the quotients themselves wherever no lane is near a rounding boundary (0: always the reference's chain; 2: both, disagreements counted)
+#endif
+#ifndef SAF_CLS_GUARD_EPS
+#define SAF_CLS_GUARD_EPS 0x1p-20f  // the guard band per pixel of image width / height (the chain's error bound is 11.1 * 2^-24 = 0.69 of it)
 #endif
 #ifndef SAF_CLS_BOX
 #define SAF_CLS_BOX 1  // the brick's frame cull tests the box's extents (0: its bounding sphere, rounds 2-3)
@@ -225,6 +234,41 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
       const Cam cam = s_cam[on ? fr[u] : 0];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+#if SAF_CLS_GUARD
+        // The voxel's pixel without the normalise / un-normalise round trip (clipfusion.py:654-661 and grid_sample's own
+        // arithmetic: +0.5, /W, *2, -1, +1, *W/2, -0.5, round): that chain returns the quotient qu = u / z to within
+        // W * 11.1 * 2^-24 (every rounding of it at its largest, |qu| <= 2 W; beyond that the voxel is out of view by a margin no
+        // rounding reaches), so wherever qu and qv are farther than W * 2^-20 / H * 2^-20 from every half-integer, the pixel is
+        // (rint(qu), rint(qv)), "in view" is -0.5 < qu < W - 0.5 (both ends are half-integers) and an in-view pixel is inside
+        // the image.  If ANY lane of the wave is closer than that (14 % of the voxel slots at 640 x 480) the whole wave takes
+        // the reference's chain for this voxel.  The two IEEE divisions are the same on both paths.
+        const Uvz hq = project_uvz(cam, xw[j], yw[j], zw[j]);
+        const float qu = hq.u / hq.z, qv = hq.v / hq.z;
+        const float ru = __builtin_rintf(qu), rv = __builtin_rintf(qv);
+        const bool near = fabsf(qu - ru) > 0.5f - wa.guard_x || fabsf(qv - rv) > 0.5f - wa.guard_y;  // (NaN: not near, and not in view below)
+        int pixel;
+        if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+          const Proj p = finish_from_uv(cam, qu, qv, hq.z);
+          const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
+          const int px = nearest_index(p.gx, p.gy, cam, wa.W);
+          pixel = in_view ? (px >= 0 ? px : -1) : -2;
+        } else {
+          const bool in_view = on && inb[j] && fabsf(qu - wa.mid_x) < cam.sfx && fabsf(qv - wa.mid_y) < cam.sfy && (hq.z > 0.0f);
+          pixel = in_view ? (int)rv * wa.W + (int)ru : -2;
+        }
+#if SAF_CLS_GUARD > 1  // development: both paths, disagreements counted in stats[7]
+        {
+          const Proj p = finish_from_uv(cam, qu, qv, hq.z);
+          const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
+          const int px = nearest_index(p.gx, p.gy, cam, wa.W);
+          const int want = in_view ? (px >= 0 ? px : -1) : -2;
+          if (want != pixel && wa.verify) atomicAdd(wa.verify, 1ull);
+        }
+#endif
+        pix[u][j] = pixel;
+        pz[u][j] = hq.z;
+        continue;
+#endif
         const Proj p = project(cam, xw[j], yw[j], zw[j]);
         const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
         const int px = nearest_index(p.gx, p.gy, cam, wa.W);
@@ -1621,6 +1665,10 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       ClsArgs ca;
       ca.n = fb + kClsFrames < F ? kClsFrames : F - fb;
       ca.H = kf0.H; ca.W = kf0.W; ca.slot = fb; ca.count = u.count;
+      ca.guard_x = kf0.W <= 8192 ? (float)kf0.W * SAF_CLS_GUARD_EPS : 2.0f;
+      ca.guard_y = kf0.H <= 8192 ? (float)kf0.H * SAF_CLS_GUARD_EPS : 2.0f;
+      ca.mid_x = (float)(kf0.W - 1) * 0.5f; ca.mid_y = (float)(kf0.H - 1) * 0.5f;
+      ca.verify = stats ? reinterpret_cast<unsigned long long*>(stats) + 7 : nullptr;
       for (int k = 0; k < kClsFrames; ++k) {
         const saf_frame& fr = frames[f0 + fb + (k < ca.n ? k : 0)];
         ca.depth[k] = fr.depth; ca.rgb[k] = fr.rgb; ca.pose[k] = fr.pose; ca.K[k] = fr.K; ca.label_map[k] = fr.label_map;
