@@ -241,24 +241,30 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
         // rounding reaches), so wherever qu and qv are farther than W * 2^-20 / H * 2^-20 from every half-integer, the pixel is
         // (rint(qu), rint(qv)), "in view" is -0.5 < qu < W - 0.5 (both ends are half-integers) and an in-view pixel is inside
         // the image.  If ANY lane of the wave is closer than that (14 % of the voxel slots at 640 x 480) the whole wave takes
-        // the reference's chain for this voxel.  The two IEEE divisions are the same on both paths.
+        // the reference's chain for this voxel ...
         const Uvz hq = project_uvz(cam, xw[j], yw[j], zw[j]);
-        const float qu = hq.u / hq.z, qv = hq.v / hq.z;
-        const float ru = __builtin_rintf(qu), rv = __builtin_rintf(qv);
-        const bool near = fabsf(qu - ru) > 0.5f - wa.guard_x || fabsf(qv - rv) > 0.5f - wa.guard_y;  // (NaN: not near, and not in view below)
+        // ... and, on the guarded path, without the two IEEE divisions either: au = u * rcp(z) is within |qu| * 0.75 * 2^-22 of
+        // the quotient (v_rcp_f32: 1 ulp; one rounding of the product), so the band is widened by |au| * 2^-21.  (z below
+        // 2^-100 -- the camera inside the voxel -- takes the reference's path: rcp overflows there.)
+        const float rz = __builtin_amdgcn_rcpf(hq.z);
+        const float au = hq.u * rz, av = hq.v * rz;
+        const float ru = __builtin_rintf(au), rv = __builtin_rintf(av);
+        const bool near = fabsf(au - ru) > 0.5f - __builtin_fmaf(fabsf(au), 0x1p-21f, wa.guard_x) ||
+                          fabsf(av - rv) > 0.5f - __builtin_fmaf(fabsf(av), 0x1p-21f, wa.guard_y) ||
+                          fabsf(hq.z) < 0x1p-100f;  // (NaN: not near, and not in view below)
         int pixel;
         if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
-          const Proj p = finish_from_uv(cam, qu, qv, hq.z);
+          const Proj p = finish_from_uv(cam, hq.u / hq.z, hq.v / hq.z, hq.z);
           const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
           const int px = nearest_index(p.gx, p.gy, cam, wa.W);
           pixel = in_view ? (px >= 0 ? px : -1) : -2;
         } else {
-          const bool in_view = on && inb[j] && fabsf(qu - wa.mid_x) < cam.sfx && fabsf(qv - wa.mid_y) < cam.sfy && (hq.z > 0.0f);
+          const bool in_view = on && inb[j] && fabsf(au - wa.mid_x) < cam.sfx && fabsf(av - wa.mid_y) < cam.sfy && (hq.z > 0.0f);
           pixel = in_view ? (int)rv * wa.W + (int)ru : -2;
         }
 #if SAF_CLS_GUARD > 1  // development: both paths, disagreements counted in stats[7]
         {
-          const Proj p = finish_from_uv(cam, qu, qv, hq.z);
+          const Proj p = finish_from_uv(cam, hq.u / hq.z, hq.v / hq.z, hq.z);
           const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
           const int px = nearest_index(p.gx, p.gy, cam, wa.W);
           const int want = in_view ? (px >= 0 ? px : -1) : -2;
