@@ -97,3 +97,39 @@ def test_sums_form_nan_inf_in_the_maps_reach_exactly_the_rows_they_reach_frame_a
     assert torch.equal(torch.isnan(a), torch.isnan(b)), "NaN reaches other elements"
     assert torch.equal(torch.isinf(a), torch.isinf(b)) and torch.equal(a[torch.isinf(a)], b[torch.isinf(b)])
     assert int(torch.isnan(a).sum()) > 0 and int(torch.isinf(a).sum()) > 0
+
+
+def test_classification_guard_on_pixel_boundaries(rows_form):
+    """The classification takes a voxel's pixel from the quotients u / z, v / z themselves wherever no lane of its wave is
+    within W * 2^-20 (+ |q| * 2^-21) of a rounding boundary, and the reference's normalise / un-normalise chain otherwise
+    (DESIGN 4.6d).  Cameras built so that a whole plane of voxel centres projects ONTO the boundaries -- axis-aligned, the plane at
+    z = 1, fx = 1 / voxel size: u = i + cx exactly -- with cx = 0.5 +- 0 .. 6 guard bands (and the image's edges -0.5 and
+    W - 0.5 among the half-integers hit): the windowed path must agree bit for bit with the per-frame pipeline, whose sweep
+    kernel runs the reference's chain for every voxel."""
+    from spatially_aware_ai_amd.synthetic import GridSpec
+
+    w, h, dim = 96, 80, 256
+    s = 2.0 ** -6
+    grid = GridSpec(origin=torch.tensor([-16 * s, -24 * s, 1.0]), voxel_size=s, nvox=torch.tensor([64, 64, 16], dtype=torch.int32),
+                    trunc=3 * s)
+    base = _frames(31337, 34, dim, "B", w=w, h=h)
+    frames = []
+    band = w * 2.0 ** -20
+    for k, f in enumerate(base):
+        pose = torch.eye(4).unsqueeze(0)       # camera at the world origin looking along +z: camera coordinates = world
+        # around the boundary, both signs: a few guard bands (odd k) and a few PER CENT of one (even k: inside what the
+        # reference's own chain of roundings can move across the boundary)
+        m = (k - 17) * (0.375 if k % 2 else 0.02)
+        K = torch.tensor([[[64.0, 0.0, 0.5 + m * band + 16.0], [0.0, 64.0, 0.5 - m * band + 24.0], [0.0, 0.0, 1.0]]])
+        depth = torch.full((1, h, w), 1.0 + (k % 5) * s)
+        depth[:, ::7, ::5] = 0.0
+        frames.append(dict(f, pose=pose, K=K, depth=depth))
+    one = _fuse(_build(grid, dim, False, _abi.SAF_RUNNING_MEAN, torch.float32, defer=False), frames, False, per_call=7)
+    win = _fuse(_build(grid, dim, False, _abi.SAF_RUNNING_MEAN, torch.float32), frames, False)
+    s1, s2 = one.stats(), win.stats()
+    assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0, "the windowed path did not run"
+    s1.pop("window_tsdf_voxels"), s2.pop("window_tsdf_voxels")
+    assert s1 == s2 and s1["valid"] > 10000, (s1, s2)
+    for name in EXACT:
+        assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs from the per-frame pipeline"
+    assert torch.equal(one.clip_feat, win.clip_feat)
