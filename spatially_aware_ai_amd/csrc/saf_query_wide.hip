@@ -617,11 +617,7 @@ query_wide2_kernel(Wide2Args wa) {
   prev = cur;
   f32x16_t acc[2][NF];  // [step parity][fragment]: the tile being accumulated and the previous one awaiting its epilogue
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_tiles;
-#ifndef SAF_W2_STAGGER
-#define SAF_W2_STAGGER 0  // (measured: the second site splits the MFMA loop -- heat maps 24.8 vs 23.3 ms, row argmax 18.0 vs 17.6)
-#endif
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const bool late = SAF_W2_STAGGER && NF == 1 && kWaves == 8 && wave_u >= kWaves / 2;
   int tail_ops = 0;  // vector-memory operations the last step issued behind its LDS-DMA (a lower bound)
 
   // One step = one (row block, query tile) pair.  In program order: barrier (tile in LDS) -> transfer of the next tile
@@ -696,20 +692,18 @@ query_wide2_kernel(Wide2Args wa) {
     const bool more = step + 1 < n_steps;
     const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
     uint4 stage[kDma ? 1 : PPT];
-    // the next tile by LDS-DMA, 32 / kWaves pieces per wave.  Of the two waves that share a SIMD (w and w + 4) one issues
-    // them here, the other one behind the first half of its MFMAs: an issue costs 60-185 cycles of the wave's in-order
-    // stream (MI355X_MICROARCH.md, constants), and with both at it at once the matrix pipe has nobody to run
+    // the next tile by LDS-DMA, 32 / kWaves pieces per wave, ahead of the tile's first MFMA.  (Tried: of the two waves that
+    // share a SIMD one issuing here and the other one behind the first half of its MFMAs -- the second site splits the MFMA
+    // loop: heat maps 24.8 vs 23.3 ms --; every wave issuing behind its 8th / 16th MFMA: 17.4 / 17.8 vs 17.7 ms for the row
+    // argmax, 23.2 / 24.3 vs 23.1 for the heat maps.)
     auto dma_next = [&]() {
       constexpr int K = kWTile / kWaves;
       w2_dma_rows<K, ROWB>(wa.text16 + (int64_t)(qt_next * kWTile + wave_u * K) * D, (uint32_t)lane * 16u,
                            lds_base + (uint32_t)((step + 1) & 1) * kWTile * ROWB + wave_u * K * ROWB);
     };
-#ifndef SAF_W2_DMA_AT
-#define SAF_W2_DMA_AT 0  // the MFMA step behind which every wave issues the next tile's transfer (0: ahead of the first)
-#endif
     if (more) {
       if (kDma) {
-        if (!late && SAF_W2_DMA_AT == 0) dma_next();
+        dma_next();
       } else {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -746,7 +740,6 @@ query_wide2_kernel(Wide2Args wa) {
 #endif
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr bool kSwap = EPI == SAF_QW_QUERY_MAX;
-    constexpr int kLateAt = KS / 2;  // (behind the stores of registers 0-7, ahead of those of registers 8-15)
     if (!fast) {
       if (step > 0) w2_epilogue<OT, EPI, NF>(wa, pc, prev, st, r, h, n_qt, vec_ok);
 #pragma unroll
@@ -754,7 +747,6 @@ query_wide2_kernel(Wide2Args wa) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) c[f] = kSwap ? mfma16<FT>(a[f][s], t[s], s == 0 ? zero16 : c[f]) : mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);  // C[query][feature row]; kSwap: C[feature row][query]
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
-        if (kDma && ((s == kLateAt && late) || (SAF_W2_DMA_AT > 0 && s == SAF_W2_DMA_AT && !late)) && more) dma_next();
       }
       tail_ops = 0;
     } else {
@@ -774,7 +766,6 @@ query_wide2_kernel(Wide2Args wa) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) c[f] = kSwap ? mfma16<FT>(a[f][s], t[s], s == 0 ? zero16 : c[f]) : mfma16<FT>(t[s], a[f][s], s == 0 ? zero16 : c[f]);
         if (s + AHEAD < KS) t[s + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W2_TOFF(s + AHEAD));
-        if (kDma && ((s == kLateAt && late) || (SAF_W2_DMA_AT > 0 && s == SAF_W2_DMA_AT && !late)) && more) dma_next();
         if (EPI == SAF_QW_ROW_ARGMAX || EPI == SAF_QW_QUERY_MAX) {
           if (ra_pending >= 0) {
 #pragma unroll
