@@ -147,7 +147,9 @@ __device__ unsigned long long g_win_t[16];
 #define SAF_WIN_WPE 2
 #endif
 #ifndef SAF_WIN_OF_SR2
-#define SAF_WIN_OF_SR2 5  // order-free form, D = 512: rows of a sub-chunk = accumulator sets in registers (8 VGPRs each)
+#define SAF_WIN_OF_SR2 6  // order-free form, D = 512: rows of a sub-chunk = accumulator sets in registers (8 VGPRs each).  6: 167 VGPRs (f32) / 176 (bf16):
+                          // two row waves still leave a SIMD room for two classification waves (2 x 176 + 2 x 80 = 512); job 76.1 / 75.4 / 75.1 ms for 5 / 6 / 7
+                          // (7: 176 / 189 VGPRs -- the bf16 kernel would push the classification down to one wave)
 #endif
 #ifndef SAF_WIN_OF_P2
 #define SAF_WIN_OF_P2 2
