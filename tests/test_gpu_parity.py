@@ -1392,3 +1392,24 @@ def test_slab_by_slab_fusion_equals_the_whole_volume(seem):
         s1, s2 = whole.stats(), fz.stats()
         for k in ("valid", "tsdf_valid", "labels_dropped"):
             assert s1[k] == s2[k], (mode, k, s1, s2)
+
+
+@pytest.mark.parametrize("n,q,dt", [(5000, 7, torch.float16), (70001, 32, torch.bfloat16), (300, 1, torch.float16)])
+def test_wide_scan_single_query_tile(n, q, dt):
+    """n_text <= 32: one query tile, so EVERY step of the scan's persistent loop is a row-block change (rows reloaded, the same tile
+    transferred again into the other LDS buffer) -- scores, row argmax and per-query maximum against fp32 torch."""
+    from spatially_aware_ai_amd.clipfusion import query_scan_wide
+
+    g = torch.Generator().manual_seed(5 + n)
+    f = torch.randn(n, 512, generator=g).to(dt).cuda()
+    t = torch.randn(q, 512, generator=g)
+    t = (t / t.norm(dim=-1, keepdim=True)).cuda()
+    ref = torch.nn.functional.normalize(f.float(), dim=-1) @ t.to(dt).float().T
+    s = query_scan_wide(f, t, "scores", out_dtype=torch.float32)
+    idx, val = query_scan_wide(f, t, "row_argmax")
+    qv, qr = query_scan_wide(f, t, "query_max")
+    assert (s - ref).abs().max().item() < 3e-5
+    assert (val - ref.max(dim=1).values).abs().max().item() < 3e-5
+    assert (ref[torch.arange(n, device="cuda"), idx.long()] - ref.max(dim=1).values).abs().max().item() < 3e-5
+    assert (qv - ref.max(dim=0).values).abs().max().item() < 3e-5
+    assert (ref[qr, torch.arange(q, device="cuda")] - ref.max(dim=0).values).abs().max().item() < 3e-5
