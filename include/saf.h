@@ -97,7 +97,8 @@ typedef struct saf_frame {
  *  [4] fuse workgroups that gave up waiting for their frame's sweep (must stay 0)
  *  [5] feature rows read-modify-written by window kernels (= sum over windows of |union of valid sets|;
  *      0 when the per-frame pipeline ran)  [6] voxels whose TSDF a window's classification updated
- *      (sum over windows of |union of tsdf-valid sets|)  [7] reserved */
+ *      (sum over windows of |union of tsdf-valid sets|)  [7] disagreements between the classification's guarded pixel path and
+ *      the reference's chain, counted only with SAF_CLS_VERIFY=1 in the environment (a self-check; must stay 0) */
 #define SAF_STATS_WORDS 8
 /* frames per window of the windowed path of saf_fuse_frames (stats[5] and [6] count per window); SAF_WIN_FRAMES=64 in the
  * environment selects 64-frame windows */

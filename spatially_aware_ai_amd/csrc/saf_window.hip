@@ -196,7 +196,7 @@ struct WinCfg {
 // the frame bitmask of voxel j.  KFU frames at a time: their depth gathers are in flight together.
 // The classification of a lane's 4 consecutive voxels (flat indices nb .. nb+3, world coordinates xw/yw/zw,
 // inb = inside the grid) against the frames of `live` (bit k = frame k of the launch), ascending.
-template <int KFU, bool SUM>
+template <int KFU, bool SUM, bool VERIFY = false>
 __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa, const Cam* __restrict__ s_cam, uint32_t nb,
                                                 const float (&xw)[4], const float (&yw)[4], const float (&zw)[4],
                                                 const bool (&inb)[4], float rtrunc, bool tsdf_aligned,
@@ -264,15 +264,13 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
           const bool in_view = on && inb[j] && fabsf(au - wa.mid_x) < cam.sfx && fabsf(av - wa.mid_y) < cam.sfy && (hq.z > 0.0f);
           pixel = in_view ? (int)rv * wa.W + (int)ru : -2;
         }
-#if SAF_CLS_GUARD > 1  // development: both paths, disagreements counted in stats[7]
-        {
+        if constexpr (VERIFY || SAF_CLS_GUARD > 1) {  // the self-check (SAF_CLS_VERIFY=1 at run time): both paths, disagreements counted in stats[7]
           const Proj p = finish_from_uv(cam, hq.u / hq.z, hq.v / hq.z, hq.z);
           const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
           const int px = nearest_index(p.gx, p.gy, cam, wa.W);
           const int want = in_view ? (px >= 0 ? px : -1) : -2;
           if (want != pixel && wa.verify) atomicAdd(wa.verify, 1ull);
         }
-#endif
         pix[u][j] = pixel;
         pz[u][j] = hq.z;
         continue;
@@ -447,7 +445,7 @@ __global__ __launch_bounds__(256) void depth_reduce_kernel(const float* __restri
   }
 }
 
-template <bool SUM>
+template <bool SUM, bool VERIFY = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE))) void classify_bricks_kernel(
     KVol v, ClsArgs wa, const float* __restrict__ dmax, const float* __restrict__ tmax, int ts_log2, int tiles_x,
     uint32_t* __restrict__ hitmask,
@@ -574,7 +572,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   unsigned long long nt_done = 0, tsdf_rows_done = 0;
   uint32_t mk4[4] = {0u, 0u, 0u, 0u};
   if (live)
-    classify_voxels<SAF_CLS_FU, SUM>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
+    classify_voxels<SAF_CLS_FU, SUM, VERIFY>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
   // every voxel of the grid gets its mask word (the row kernel reads them all); 16 bytes at once where the four lie in the grid
   // and the run is aligned (always, when nz is a multiple of 4)
   if (inb[3] && (nb & 3u) == 0u) {
@@ -1691,12 +1689,13 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, cs, tmax, n_tiles, dmax);
       }
       ScopedPair t(prof, 1, f0 + fb, cs);
-      if (sum)
-        hipLaunchKernelGGL(classify_bricks_kernel<true>, dim3(g.cls_wgs), dim3(256), 0, cs, u.kv, ca, dmax, tmax, ts_log2, tiles_x, plane,
-                           reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
-      else
-        hipLaunchKernelGGL(classify_bricks_kernel<false>, dim3(g.cls_wgs), dim3(256), 0, cs, u.kv, ca, dmax, tmax, ts_log2, tiles_x, plane,
-                           reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
+      // SAF_CLS_VERIFY=1 (read per call): the self-checking classification -- every voxel slot computes the reference's pixel chain
+      // as well and counts disagreements with the guarded path in stats[7] (tests; tools/cls_guard_verify.py)
+      const bool verify = getenv("SAF_CLS_VERIFY") && getenv("SAF_CLS_VERIFY")[0] == '1' && stats;
+      auto kfn = verify ? (sum ? classify_bricks_kernel<true, true> : classify_bricks_kernel<false, true>)
+                        : (sum ? classify_bricks_kernel<true, false> : classify_bricks_kernel<false, false>);
+      hipLaunchKernelGGL(kfn, dim3(g.cls_wgs), dim3(256), 0, cs, u.kv, ca, dmax, tmax, ts_log2, tiles_x, plane,
+                         reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
     }
     int r = check_launch("classify_bricks_kernel");
     if (r) return r;

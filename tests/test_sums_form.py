@@ -133,3 +133,20 @@ def test_classification_guard_on_pixel_boundaries(rows_form):
     for name in EXACT:
         assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs from the per-frame pipeline"
     assert torch.equal(one.clip_feat, win.clip_feat)
+
+
+@pytest.mark.parametrize("nvox,w,h,n,kind", [((64, 64, 64), 640, 480, 48, "A"), ((48, 64, 40), 333, 517, 40, "B"),
+                                             ((61, 60, 59), 1280, 960, 24, "A")])
+def test_classification_guarded_pixel_path_self_check(monkeypatch, nvox, w, h, n, kind):
+    """SAF_CLS_VERIFY=1: the classification computes, for every voxel slot, the reference's normalise / un-normalise chain as well
+    as the guarded path (the pixel from u * rcp(z), v * rcp(z) wherever no lane is near a rounding boundary) and counts
+    disagreements in stats[7].  Millions of voxel tests per case; the count must be 0 (with the guard band set to zero the
+    same check finds thousands: profiles/r04/classification_guard.txt)."""
+    monkeypatch.setenv("SAF_CLS_VERIFY", "1")
+    grid = syn.make_grid(nvox, side=2.56)
+    frames = _frames(4000 + n, n, 256, kind, w=w, h=h)
+    fz = _fuse(_build(grid, 256, False, _abi.SAF_RUNNING_MEAN, torch.float32), frames, False)
+    s = fz.fuse_stats.cpu().tolist()
+    assert s[5] > 0, "the windowed path did not run"
+    assert s[1] > 1_000_000, s  # TSDF-valid voxel tests (a fraction of all the slots checked)
+    assert s[7] == 0, f"{s[7]} voxel slots disagree with the reference's chain"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Development: the classification's guarded pixel path against the reference's chain, voxel slot by voxel slot (library built
-with -DSAF_CLS_GUARD=2: both are computed, disagreements counted in stats[7]).  Runs bench-like jobs at several image sizes,
+"""Development: the classification's guarded pixel path against the reference's chain, voxel slot by voxel slot (SAF_CLS_VERIFY=1 in the
+environment: both are computed, disagreements counted in stats[7]).  Runs bench-like jobs at several image sizes,
 both depth distributions; prints tests and disagreements.  tools/cls_guard_verify.sh builds, runs, rebuilds."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
