@@ -3,6 +3,8 @@
   * ``ClipSeemFusion``        -- reference clip_seem_fusion.py:611-888: the ClipFusion volume plus a
                                  per-voxel panoptic class histogram, rgb sampled bilinearly.
   * ``argmax_with_check``     -- the manager's label decode (clip_seem_fusion.py:315-325).
+  * ``discover_objects`` / ``extract_mesh_by_object`` -- the manager's object bookkeeping around the volume
+                                 (handy_utils.py:295-480, :585-611).
   * ``TextQueryEngine``       -- the query half of ``InSituManager`` (``clip_text_query``,
                                  clip_seem_fusion.py:482-561) over fused vertex / voxel features.
 
@@ -236,6 +238,33 @@ def discover_objects(labels_grid, class_names, class_colors=None, null_class=133
     scene_knowledge = {"unique_objects": unique_objects, "object_counts": object_counts,
                        "unchanged_objects": unchanged_objects, "new_objects": new_objects, "missing_objects": missing_objects}
     return scene_knowledge, voxel_obj_idx
+
+
+def extract_mesh_by_object(vertices, faces, colors, vertex_indices, obj_idx):
+    """The sub-mesh of one object (handy_utils.py:585-611): the vertices whose sampled object index equals ``obj_idx``,
+    the faces all of whose corners are such vertices, re-indexed.  Returns ``(object_vertices, object_faces,
+    object_colors, mesh)``; ``mesh`` is an ``open3d.geometry.TriangleMesh`` where open3d is installed (the reference
+    builds one and its caller ignores it, clip_seem_fusion.py:396-402), else None.  The re-indexing is a lookup table
+    instead of the reference's Python loop over faces."""
+    vertices, faces, colors = np.asarray(vertices), np.asarray(faces), np.asarray(colors)
+    vi = np.asarray(vertex_indices)
+    object_indices = np.where(vi.reshape(len(vi), -1)[:, 0] == obj_idx)[0]
+    object_vertices, object_colors = vertices[object_indices], colors[object_indices]
+    lut = np.full(len(vertices), -1, dtype=np.int64)
+    lut[object_indices] = np.arange(len(object_indices))
+    mapped = lut[faces] if len(faces) else np.zeros((0, 3), np.int64)
+    object_faces = mapped[(mapped >= 0).all(axis=1)].astype(faces.dtype if len(faces) else np.int64)
+    mesh = None
+    try:
+        import open3d as o3d
+
+        mesh = o3d.geometry.TriangleMesh()
+        mesh.vertices = o3d.utility.Vector3dVector(object_vertices)
+        mesh.triangles = o3d.utility.Vector3iVector(object_faces)
+        mesh.vertex_colors = o3d.utility.Vector3dVector(object_colors)
+    except ImportError:
+        pass
+    return object_vertices, object_faces, object_colors, mesh
 
 
 class TextQueryEngine:

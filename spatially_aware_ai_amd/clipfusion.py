@@ -465,6 +465,7 @@ class _FusionVolumeMixin:
                 t.zero_()
         super().__setattr__("accum_mode", accum_mode)
         self._shard_stripes = None
+        self.__dict__["_shard_plans"] = None
         self.__dict__["_feat_stale"] = lazy
 
 
@@ -1032,25 +1033,44 @@ def backproject_pcd(dataset, batch_size=1, num_workers=0, device="cpu", max_dept
     vv, uu = torch.meshgrid(v.long(), u.long(), indexing="ij")
     vv, uu = vv.reshape(-1), uu.reshape(-1)
     npts = uv_size * uv_size
-    xyz_all, rgb_all = [], []
+    xyz_dev, valid_dev, rgb_all = [], [], []
+    # frames travel through two reusable pinned buffers (a copy from the loader's freshly allocated pageable batch costs
+    # milliseconds on ROCm: the pages are pinned for the one transfer), results stay on the device until the end: one sync
+    pinned, events, k = {}, [None, None], 0
+    stream = torch.cuda.current_stream(dev)
     for rgb_imgs, depth_imgs, poses, K, _ in loader:
         bsz = len(rgb_imgs)
-        depth_d = depth_imgs.to(dev, torch.float32).contiguous()
-        poses_d = poses.to(dev, torch.float32).contiguous()
-        kinv_d = K.to(torch.float32).inverse().to(dev).contiguous()
+        if events[k] is not None:
+            events[k].synchronize()
+        staged = []
+        for i, t in enumerate((depth_imgs.to(torch.float32), poses.to(torch.float32), K.to(torch.float32).inverse())):
+            buf = pinned.get((k, i))
+            if buf is None or buf.shape != t.shape:
+                buf = pinned[(k, i)] = torch.empty(t.shape, dtype=torch.float32).pin_memory()
+            buf.copy_(t)
+            staged.append(buf.to(dev, non_blocking=True))
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        events[k], k = ev, 1 - k
+        depth_d, poses_d, kinv_d = staged
         xyz = torch.empty((bsz, npts, 3), dtype=torch.float32, device=dev)
         valid = torch.empty((bsz, npts), dtype=torch.uint8, device=dev)
         for i in range(bsz):
             rc = lib().saf_backproject_lattice(
                 depth_d[i].data_ptr(), dataset.imheight, dataset.imwidth, poses_d[i].data_ptr(), kinv_d[i].data_ptr(),
                 u_dev.data_ptr(), uv_size, v_dev.data_ptr(), uv_size, float(max_depth), xyz[i].data_ptr(),
-                valid[i].data_ptr(), current_stream_ptr(),
+                valid[i].data_ptr(), stream.cuda_stream,
             )
             check(rc, "saf_backproject_lattice")
-        valid = valid.bool().cpu()
-        xyz_all.append(xyz.cpu()[valid])
-        rgb_all.append(rgb_imgs[:, vv, uu][valid])
-    return torch.cat(xyz_all, dim=0), torch.cat(rgb_all, dim=0)
+        for t in staged:
+            t.record_stream(stream)
+        xyz_dev.append(xyz)
+        valid_dev.append(valid)
+        rgb_all.append(rgb_imgs[:, vv, uu])
+    if not xyz_dev:
+        return torch.zeros((0, 3)), torch.zeros((0, 3))
+    valid = torch.cat(valid_dev).bool().cpu()
+    return torch.cat(xyz_dev).cpu()[valid], torch.cat(rgb_all)[valid]
 
 
 def scene_bounds(xyz, voxel_size, trunc_m):

@@ -137,6 +137,15 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_CLS_FU
 #define SAF_CLS_FU 1   // frames classified together: with the frame cull, occupancy hides the depth gathers better than batching does (1: 1.13 ms, 2: 1.17, 4: 1.29, 8: 2.08 per launch)
 #endif
+#ifndef SAF_CLS_CUBE
+#define SAF_CLS_CUBE 0  // 1: voxel j of a lane lies in the brick's j-th 4 x 4 x 4 cube (z = 4 j + lane / 16), so that the 64 depth gathers of one
+                        // instruction land in a cube's pixel footprint instead of the whole 16-voxel column's.  Measured (round 5,
+                        // profiles/r05/classification_variants.txt): no difference, 76.4 vs 76.6 ms per job -- a lane keeps 4 consecutive z
+#endif
+#ifndef SAF_CLS_ABL
+#define SAF_CLS_ABL 0  // development (same results): 1 = every depth gather issued twice (the second one's pixel mirrored in its row):
+#endif                 // doubles the classification's load on the texture-address unit and nothing else; 2 = the projection's vector
+                       // arithmetic twice, no memory request (profiles/r05/classification_variants.txt)
 #ifndef SAF_WIN_SPLIT_LOG2
 #define SAF_WIN_SPLIT_LOG2 2  // a piece is handed out in 2^k parts (quarters measured best: halves 6967, quarters 7165, eighths 6049 frames/s on the coherent scene)
 #endif
@@ -204,7 +213,8 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
                                                 unsigned long long& tsdf_rows_done) {
   float told[4];
   int tw[4];
-  const bool vec = tsdf_aligned && inb[3] && (nb & 3u) == 0u;
+  constexpr uint32_t kZS = SAF_CLS_CUBE ? 4u : 1u;  // flat-index distance of a lane's voxels j and j + 1
+  const bool vec = kZS == 1u && tsdf_aligned && inb[3] && (nb & 3u) == 0u;
   if (vec) {
     const float4 t4 = *reinterpret_cast<const float4*>(v.tsdf + nb);
     const int4 w4 = *reinterpret_cast<const int4*>(v.tsdf_w + nb);
@@ -213,8 +223,8 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      told[j] = inb[j] ? v.tsdf[nb + j] : 0.0f;
-      tw[j] = inb[j] ? v.tsdf_w[nb + j] : 0;
+      told[j] = inb[j] ? v.tsdf[nb + kZS * j] : 0.0f;
+      tw[j] = inb[j] ? v.tsdf_w[nb + kZS * j] : 0;
     }
   }
   uint32_t touched = 0;  // bit j: voxel j's TSDF changed
@@ -245,6 +255,19 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
         // the image.  If ANY lane of the wave is closer than that (14 % of the voxel slots at 640 x 480) the whole wave takes
         // the reference's chain for this voxel ...
         const Uvz hq = project_uvz(cam, xw[j], yw[j], zw[j]);
+#if SAF_CLS_ABL & 2  // the guarded path's arithmetic a second time on a shifted point, result kept alive: twice the vector work, no memory request
+        {
+          const Uvz h2 = project_uvz(cam, xw[j] + 0.25f, yw[j] - 0.25f, zw[j] + 0.125f);
+          const float r2 = __builtin_amdgcn_rcpf(h2.z);
+          const float a2 = h2.u * r2, b2 = h2.v * r2;
+          const float c2 = __builtin_rintf(a2), d2 = __builtin_rintf(b2);
+          const bool n2 = fabsf(a2 - c2) > 0.5f - __builtin_fmaf(fabsf(a2), 0x1p-21f, wa.guard_x) ||
+                          fabsf(b2 - d2) > 0.5f - __builtin_fmaf(fabsf(b2), 0x1p-21f, wa.guard_y);
+          const bool v2 = fabsf(a2 - wa.mid_x) < cam.sfx && fabsf(b2 - wa.mid_y) < cam.sfy && (h2.z > 0.0f);
+          const int p2 = (v2 && !n2) ? (int)d2 * wa.W + (int)c2 : -2;
+          asm volatile("" ::"v"(p2));
+        }
+#endif
         // ... and, on the guarded path, without the two IEEE divisions either: au = u * rcp(z) is within |qu| * 0.75 * 2^-22 of
         // the quotient (v_rcp_f32: 1 ulp; one rounding of the product), so the band is widened by |au| * 2^-21.  (z below
         // 2^-100 -- the camera inside the voxel -- takes the reference's path: rcp overflows there.)
@@ -293,6 +316,15 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         depth[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dimg, pix[u][j] * 4, 0, 0));
+#if SAF_CLS_ABL & 1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = pix[u][j] / wa.W, col = pix[u][j] - row * wa.W;
+        const int twin = pix[u][j] >= 0 ? row * wa.W + (wa.W - 1 - col) : pix[u][j];
+        const float d2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dimg, twin * 4, 0, 0));
+        asm volatile("" ::"v"(d2));
+      }
+#endif
 #else
       const float* __restrict__ dimg = wa.depth[fr[u] >= 0 ? fr[u] : 0];
 #pragma unroll
@@ -332,8 +364,8 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (touched & (1u << j)) {
-          v.tsdf[nb + j] = told[j];
-          v.tsdf_w[nb + j] = tw[j];
+          v.tsdf[nb + kZS * j] = told[j];
+          v.tsdf_w[nb + kZS * j] = tw[j];
         }
       }
     }
@@ -467,7 +499,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   const uint32_t bx = (tt / tiles_y) * 8u + r / 8u, by = (tt % tiles_y) * 8u + r % 8u;
   const bool on = bx < nbx && by < nby;  // (no early return: the workgroup meets again in cls_accumulate)
   const int ix = (int)bx * kBrickX + (lane & 3), iy = (int)by * kBrickY + ((lane >> 2) & 3);
-  const int iz0 = (int)bz * kBrickZ + (lane >> 4) * 4;
+  // a lane's four voxels: z = iz0 + kZS j (SAF_CLS_CUBE: one per 4 x 4 x 4 cube of the brick; else four consecutive ones)
+  constexpr int kZS = SAF_CLS_CUBE ? 4 : 1;
+  const int iz0 = (int)bz * kBrickZ + (SAF_CLS_CUBE ? (lane >> 4) : (lane >> 4) * 4);
   const bool col_in = on && ix < v.nx && iy < v.ny;
   const int ixc = min(ix, v.nx - 1), iyc = min(iy, v.ny - 1);
   const uint32_t nb = ((uint32_t)ixc * (uint32_t)v.ny + (uint32_t)iyc) * (uint32_t)v.nz + (uint32_t)min(iz0, v.nz - 1);
@@ -478,8 +512,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   for (int j = 0; j < 4; ++j) {
     xw[j] = x_l;
     yw[j] = y_l;
-    zw[j] = v.az[min(iz0 + j, v.nz - 1)];
-    inb[j] = col_in && iz0 + j < v.nz;
+    zw[j] = v.az[min(iz0 + kZS * j, v.nz - 1)];
+    inb[j] = col_in && iz0 + kZS * j < v.nz;
   }
   // ---- which frames can touch this brick at all?  lane k tests frame k
   uint32_t live;
@@ -575,12 +609,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
     classify_voxels<SAF_CLS_FU, SUM, VERIFY>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
   // every voxel of the grid gets its mask word (the row kernel reads them all); 16 bytes at once where the four lie in the grid
   // and the run is aligned (always, when nz is a multiple of 4)
-  if (inb[3] && (nb & 3u) == 0u) {
+  if (kZS == 1 && inb[3] && (nb & 3u) == 0u) {
     *reinterpret_cast<uint4*>(hitmask + nb) = make_uint4(mk4[0], mk4[1], mk4[2], mk4[3]);
-  } else {
+  } else {  // (cube order: the four lanes of a column write 16 consecutive bytes per instruction)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (inb[j]) hitmask[nb + j] = mk4[j];
+      if (inb[j]) hitmask[nb + kZS * j] = mk4[j];
   }
   cls_accumulate(nt_done, tsdf_rows_done, lane, wave, s_acc, stats ? cls_acc : nullptr);
 }

@@ -143,6 +143,124 @@ def _all_gather_striped(t, plan, group, rank, world):
             dist.broadcast(t[first + world * c : first + rows], src=_global_rank(group, world - 1), group=group)
 
 
+# ---- the SPARSE merge: rows no rank touched do not travel ---------------------------------------------------------------
+#
+# A feature row is non-zero only if its weight is (rows are written together with a weight increment, clipfusion.py:715-721),
+# and a real scan touches a thin shell of the grid (the coherent scene: 17 % of the rows per window, a fifth of the volume
+# over a whole job) -- while the merge of config 4 is collective-bound.  So `weight` -- 4 bytes per voxel,
+# 0.2 % of the volume -- is all-reduced FIRST: every rank then knows the job's total weight, i.e. the union of the rows any
+# rank touched, without exchanging a bitmap.  Per piece of the stripe plan the wide tensors (features, colours, label
+# counts) then take one of two routes, decided identically on every rank from that mask:
+#   * most rows touched (incoherent depth; > `sparse` of the piece): the in-place striped reduce-scatter, as before;
+#   * few rows touched: the touched rows of part k are packed and sent to rank k (all_to_all_single with uneven splits -- on
+#     the fully connected xGMI mesh every pair has its own link), rank k adds the world contributions in rank order and
+#     writes the sums back to its rows.  Same ownership, same stripes, same result up to the order of the fp32 additions.
+# tsdf / tsdf_weight are touched almost everywhere (every voxel in front of a surface) and are 8 bytes per voxel: always dense.
+_SPARSE_TENSORS = ("clip_feat", "rgb", "labels_one_hot")
+_SPARSE_DEFAULT = 0.5
+last_merge = {"pieces": 0, "packed": 0, "rows": 0, "touched_rows": 0}  # of this process's latest _merge_rows (bench / tests)
+
+
+def sparse_threshold(sparse=None):
+    """The touched fraction of a piece up to which it travels packed: ``sparse`` if given, else SAF_MERGE_SPARSE (0 = the
+    dense route always), else 0.5."""
+    import os
+
+    if sparse is None:
+        e = os.environ.get("SAF_MERGE_SPARSE")
+        sparse = float(e) if e not in (None, "") else _SPARSE_DEFAULT
+    return max(0.0, float(sparse))
+
+
+def _touched_rows(weight_total, plan, world):
+    """From the all-reduced weight of the rows the plan covers: (idx, offs) -- idx = the touched rows (global indices,
+    ascending, on the device), offs[j][k] = position in idx of the first touched row of part k of piece j (k = world: the
+    piece's end, the tail rows included in the last part's count are NOT -- they are reduced on their own).  One host sync."""
+    first0 = plan[0][0]
+    n_rows = plan[-1][0] + plan[-1][1] - first0
+    touched = weight_total[first0 : first0 + n_rows] > 0
+    bounds = []
+    for first, rows, c in plan:
+        bounds += [first - first0 + k * c for k in range(world + 1)]
+    cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=touched.device), torch.cumsum(touched, 0, dtype=torch.int64)])
+    pre = cs[torch.tensor(bounds, dtype=torch.int64, device=touched.device)].cpu().tolist()
+    idx = torch.nonzero(touched).squeeze(1) + first0
+    offs = [pre[j * (world + 1) : (j + 1) * (world + 1)] for j in range(len(plan))]
+    return idx, offs
+
+
+def _reduce_scatter_packed(t, idx, offs_j, group, rank, world):
+    """One piece, packed: the touched rows of part k (idx[offs_j[k] : offs_j[k + 1]]) go to rank k, which adds the world
+    contributions (rank order: deterministic) and writes them back in place."""
+    counts = [offs_j[k + 1] - offs_j[k] for k in range(world)]
+    if sum(counts) == 0:
+        return
+    send = t.index_select(0, idx[offs_j[0] : offs_j[world]])
+    mine = counts[rank]
+    recv = torch.empty((world * mine,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_to_all_single(recv, send, [mine] * world, counts, group=group)
+    if mine:
+        red = recv.view((world, mine) + tuple(t.shape[1:])).sum(dim=0, dtype=t.dtype)
+        t.index_copy_(0, idx[offs_j[rank] : offs_j[rank + 1]], red)
+
+
+def _merge_rows(tensors, plan, group, rank, world, sparse=None):
+    """SUM the rows the plan covers across the ranks; rank k ends with the reduced rows of its stripes.  Returns the number of
+    pieces that travelled packed (0: the dense route throughout)."""
+    thr = sparse_threshold(sparse)
+    w = tensors.get("weight")
+    wide = [k for k in _SPARSE_TENSORS if tensors.get(k) is not None]
+    packed = 0
+    last_merge.update(pieces=len(plan), packed=0, rows=sum(r for _, r, _ in plan), touched_rows=-1)
+    if thr > 0 and w is not None and wide and plan:
+        first0 = plan[0][0]
+        n_rows = plan[-1][0] + plan[-1][1] - first0
+        _all_reduce(w[first0 : first0 + n_rows], group)  # the job's weight on EVERY rank: also the union of the touched rows
+        idx, offs = _touched_rows(w, plan, world)
+        for j, (first, rows, c) in enumerate(plan):
+            frac = (offs[j][world] - offs[j][0]) / max(1, world * c)
+            go_packed = c > 0 and frac <= thr
+            packed += 1 if go_packed else 0
+            for name, t in tensors.items():
+                if name == "weight":
+                    continue
+                if go_packed and name in wide:
+                    _reduce_scatter_packed(t, idx, offs[j], group, rank, world)
+                    if rows > world * c:
+                        dist.reduce(t[first + world * c : first + rows], dst=_global_rank(group, world - 1), op=dist.ReduceOp.SUM, group=group)
+                else:
+                    _reduce_scatter_striped(t, [(first, rows, c)], group, rank, world)
+        last_merge.update(packed=packed, touched_rows=int(idx.numel()))
+        return packed
+    for t in tensors.values():
+        _reduce_scatter_striped(t, plan, group, rank, world)
+    return 0
+
+
+def probe_all_to_all(device, group=None):
+    """The packed route's collective on a small tensor with uneven splits, checked: None, or what went wrong (the ranks agree
+    on the outcome).  A merge whose probe fails runs dense (``sparse=0``)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [1 + (k % 3) for k in range(world)]
+    why = None
+    try:
+        send = torch.cat([torch.full((counts[k], 4), float(rank * 100 + k), device=device) for k in range(world)])
+        mine = counts[rank]
+        recv = torch.empty((world * mine, 4), device=device)
+        dist.all_to_all_single(recv, send, [mine] * world, counts, group=group)
+        want = torch.cat([torch.full((mine, 4), float(r * 100 + rank), device=device) for r in range(world)])
+        if not torch.equal(recv, want):
+            why = "all_to_all probe: wrong rows"
+    except Exception as e:  # noqa: BLE001
+        why = f"{type(e).__name__}: {e}"[:200]
+    try:
+        if not _agree(why is None, device, group):
+            return why or "all_to_all probe failed on another rank"
+    except Exception as e:  # noqa: BLE001
+        return why or f"{type(e).__name__}: {e}"[:200]
+    return None
+
+
 def _plan_for(tensors: dict, n_rows: int, world: int, row0: int = 0, piece_bytes: int | None = None):
     widest = max(max(1, t[0].numel()) * t.element_size() if t.shape[0] else 1 for t in tensors.values())
     return stripe_plan(n_rows, world, piece_rows_for(widest, world, piece_bytes), row0)
@@ -323,10 +441,12 @@ def slab_rows(fusion, x0: int, count: int):
     return x0 * ny * nz, count * ny * nz
 
 
-def merge_slab_sums(tensors: dict, first_row: int, n_rows: int, group=None, mode: str = "reduce_scatter", piece_bytes=None):
+def merge_slab_sums(tensors: dict, first_row: int, n_rows: int, group=None, mode: str = "reduce_scatter", piece_bytes=None,
+                    sparse=None, plans_out=None):
     """SUM rows [first_row, first_row + n_rows) of every tensor across the ranks; with ``reduce_scatter`` rank k ends with
     its stripes of the slab (returned as a list of (first, count) in volume rows: the k-th part of every piece of the slab),
-    the other rows keep partial sums."""
+    the other rows keep partial sums (``weight``: the job's total, when the sparse route ran -- ``_merge_rows``).
+    ``plans_out``: a list the slab's stripe plan is appended to (``gather_shards`` all-gathers along it)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [(first_row, n_rows)]
     world = dist.get_world_size(group)
@@ -336,8 +456,9 @@ def merge_slab_sums(tensors: dict, first_row: int, n_rows: int, group=None, mode
             _all_reduce(t[first_row : first_row + n_rows], group)
         return [(first_row, n_rows)]
     plan = _plan_for(tensors, n_rows, world, first_row, piece_bytes)
-    for t in tensors.values():
-        _reduce_scatter_striped(t, plan, group, rank, world)
+    _merge_rows(tensors, plan, group, rank, world, sparse)
+    if plans_out is not None:
+        plans_out.append(plan)
     return stripes_of_rank(plan, rank, world)
 
 
@@ -350,7 +471,7 @@ def _require_f32_sums(fusion, what):
 
 
 def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, group=None, comm_stream=None, mode="reduce_scatter",
-                         stats_ptr=None, profiler=None, ramp=True):
+                         stats_ptr=None, profiler=None, ramp=True, sparse=None):
     """One frame-sharded job with the merge hidden behind the fusion: the rank's frames are fused slab by slab (SUM mode)
     and each finished slab is reduce-scattered (in place, striped: ``merge_slab_sums``) + finalised on ``comm_stream`` while
     the next one is fused.  Returns the list of (first_row, count) stripes that hold final means on this rank, and leaves the
@@ -368,40 +489,48 @@ def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, grou
     comm = comm_stream if comm_stream is not None else main
     tensors = {k: fusion._buffers[k] for k in VOLUME_TENSORS if fusion._buffers.get(k) is not None}
     stats_ptr = fusion._buffers["fuse_stats"].data_ptr() if stats_ptr is None else stats_ptr
-    stripes = []
+    stripes, plans = [], []
     nx = int(fusion.nvox[0])
     n = fusion._buffers["tsdf"].numel()
     slabs = slab_bounds(nx, n_slabs, ramp=ramp)
     k = len(slabs)
     # ONE C call fuses every frame into slab 0, slab 1, ... (the first window of a slab is classified beside the last row
     # kernel of the slab before it) and records an event behind each slab; the collectives wait for those on `comm`
-    with torch.cuda.device(dev):
-        events = [torch.cuda.Event() for _ in slabs]
-        for ev in events:
-            ev.record(main)  # (torch creates the HIP event at its first record; the C call records it again, for real)
-        x0s = (C.c_int32 * k)(*[s_[0] for s_ in slabs])
-        nxs = (C.c_int32 * k)(*[s_[1] for s_ in slabs])
-        handles = (C.c_void_p * k)(*[int(ev.cuda_event) for ev in events])
-        vol = fusion._c_volume(for_fuse=True)
-        check(L.saf_fuse_frames_slabs(C.byref(vol), frame_arr, n_frames, x0s, nxs, k, handles, workspace.data_ptr(), workspace.numel(),
-                                      stats_ptr, profiler, main.cuda_stream), "saf_fuse_frames_slabs")
-        with torch.cuda.stream(comm):
-            for (x0, cnt), ev in zip(slabs, events):
-                comm.wait_event(ev)
-                r0, nr = slab_rows(fusion, x0, cnt)
-                for first, count in merge_slab_sums(tensors, r0, nr, group, mode):
-                    check(L.saf_merge_finalize(C.byref(vol), first, count, comm.cuda_stream), "saf_merge_finalize")
-                    stripes.append((first, count))
+    try:
+        with torch.cuda.device(dev):
+            events = [torch.cuda.Event() for _ in slabs]
+            for ev in events:
+                ev.record(main)  # (torch creates the HIP event at its first record; the C call records it again, for real)
+            x0s = (C.c_int32 * k)(*[s_[0] for s_ in slabs])
+            nxs = (C.c_int32 * k)(*[s_[1] for s_ in slabs])
+            handles = (C.c_void_p * k)(*[int(ev.cuda_event) for ev in events])
+            vol = fusion._c_volume(for_fuse=True)
+            check(L.saf_fuse_frames_slabs(C.byref(vol), frame_arr, n_frames, x0s, nxs, k, handles, workspace.data_ptr(), workspace.numel(),
+                                          stats_ptr, profiler, main.cuda_stream), "saf_fuse_frames_slabs")
+            with torch.cuda.stream(comm):
+                for (x0, cnt), ev in zip(slabs, events):
+                    comm.wait_event(ev)
+                    r0, nr = slab_rows(fusion, x0, cnt)
+                    for first, count in merge_slab_sums(tensors, r0, nr, group, mode, sparse=sparse, plans_out=plans):
+                        check(L.saf_merge_finalize(C.byref(vol), first, count, comm.cuda_stream), "saf_merge_finalize")
+                        stripes.append((first, count))
+    except BaseException:
+        # some slabs are reduced / finalised, others not: the volume is neither sums nor means.  Poisoned until reset(),
+        # like a failed flush (clipfusion._flush_pending): a later integrate or merge must not count anything twice.
+        fusion.__dict__["_poisoned"] = "fuse_merge_pipelined failed part-way: the volume is half sums, half means"
+        raise
     if comm is not main:
         main.wait_event(comm.record_event())
     # the volume now holds means on this rank's stripes (partial sums elsewhere): no longer a SUM volume
     torch.nn.Module.__setattr__(fusion, "accum_mode", _abi.SAF_RUNNING_MEAN)
     whole = sum(c for _, c in stripes) == n  # one rank, or all_reduce: every slab is complete here
     fusion._shard_stripes = None if whole else list(stripes)
+    fusion.__dict__["_shard_plans"] = None if whole else plans
     return stripes
 
 
-def merge_sums(tensors: dict, group=None, mode: str = "reduce_scatter", gather: bool = False, piece_bytes=None):
+def merge_sums(tensors: dict, group=None, mode: str = "reduce_scatter", gather: bool = False, piece_bytes=None, sparse=None,
+               plans_out=None):
     """Element-wise SUM of per-rank volume tensors (dict name -> tensor with voxels on dim 0).
     Device-agnostic (RCCL on GPUs, gloo in the CPU tests).  Returns the list of (first, count) voxel ranges that are fully
     reduced on this rank: its stripes (``stripe_plan``), or [(0, n)]."""
@@ -417,12 +546,13 @@ def merge_sums(tensors: dict, group=None, mode: str = "reduce_scatter", gather: 
     if mode != "reduce_scatter":
         raise ValueError(mode)
     plan = _plan_for(tensors, n, world, 0, piece_bytes)
-    for t in tensors.values():
-        _reduce_scatter_striped(t, plan, group, rank, world)
+    _merge_rows(tensors, plan, group, rank, world, sparse)
     if gather:
         for t in tensors.values():
             _all_gather_striped(t, plan, group, rank, world)
         return [(0, n)]
+    if plans_out is not None:
+        plans_out.append(plan)
     return stripes_of_rank(plan, rank, world)
 
 
@@ -450,7 +580,7 @@ def means_to_sums(fusion):
     fusion.accum_mode = _abi.SAF_SUM
 
 
-def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool = False, piece_bytes=None):
+def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool = False, piece_bytes=None, sparse=None):
     """The single merge step of the frame-sharded job: RCCL SUM of the per-rank sum volumes, then
     the local divide.  ``fusion`` must have been fused with ``accum_mode = SAF_SUM`` (call
     ``means_to_sums`` first otherwise).  Returns the list of (first, count) voxel ranges that hold final
@@ -465,7 +595,8 @@ def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool
         means_to_sums(fusion)
     tensors = _volume_tensors(fusion)
     n = fusion.tsdf.numel()
-    stripes = merge_sums(tensors, group=group, mode=mode, gather=False, piece_bytes=piece_bytes)
+    plans = []
+    stripes = merge_sums(tensors, group=group, mode=mode, gather=False, piece_bytes=piece_bytes, sparse=sparse, plans_out=plans)
     for first, count in stripes:
         finalize_sums(fusion, first, count)
     if stripes == [(0, n)]:
@@ -474,6 +605,7 @@ def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool
     # integrate() refuses to fuse into it (clipfusion._fuse_now) until gather_shards() has made it whole.
     fusion.accum_mode = _abi.SAF_RUNNING_MEAN
     fusion._shard_stripes = list(stripes)
+    fusion.__dict__["_shard_plans"] = plans
     if gather:
         gather_shards(fusion, group)
         return [(0, n)]
@@ -482,22 +614,32 @@ def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool
 
 def gather_shards(fusion, group=None):
     """All-gather a voxel-sharded merged volume (``merge_volumes(..., gather=False)`` or ``fuse_merge_pipelined``) so that every
-    rank holds the whole merged volume and may fuse further frames.  Every rank's stripes travel as they lie: the ranks
-    exchange their stripe lists (a few integers) and each stripe is broadcast in place by its owner."""
+    rank holds the whole merged volume and may fuse further frames.  Along the stripe plans the merge recorded
+    (``_shard_plans``: one per merge, or one per slab of the pipelined merge) this is the in-place striped all-gather -- one
+    ``all_gather_into_tensor`` per piece and tensor, every link busy.  A volume whose stripes were set by hand (no plan) falls
+    back to exchanging the stripe lists (a few integers) and one rooted broadcast per stripe, tensor and 1 GiB chunk."""
     n = fusion.tsdf.numel()
     mine = getattr(fusion, "_shard_stripes", None)
     if mine is None:
         return [(0, n)]
     world = dist.get_world_size(group)
-    every = [None] * world
-    dist.all_gather_object(every, [tuple(int(v) for v in st) for st in mine], group=group)
     tensors = _volume_tensors(fusion)
-    for k, stripes in enumerate(every):
-        for first, count in stripes:
+    plans = getattr(fusion, "_shard_plans", None)
+    if plans:
+        rank = dist.get_rank(group)
+        for plan in plans:
             for t in tensors.values():
-                for c in _chunks(t[first : first + count]):
-                    dist.broadcast(c, src=_global_rank(group, k), group=group)
+                _all_gather_striped(t, plan, group, rank, world)
+    else:
+        every = [None] * world
+        dist.all_gather_object(every, [tuple(int(v) for v in st) for st in mine], group=group)
+        for k, stripes in enumerate(every):
+            for first, count in stripes:
+                for t in tensors.values():
+                    for c in _chunks(t[first : first + count]):
+                        dist.broadcast(c, src=_global_rank(group, k), group=group)
     fusion._shard_stripes = None
+    fusion.__dict__["_shard_plans"] = None
     return [(0, n)]
 
 

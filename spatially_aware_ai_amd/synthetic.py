@@ -14,6 +14,7 @@ worst case -- or (B) an analytic sphere-in-a-box scene (coherent shell).
 from __future__ import annotations
 
 import math
+import zlib
 from dataclasses import dataclass
 
 import torch
@@ -76,6 +77,18 @@ def intrinsics(width: int, height: int) -> torch.Tensor:
 def _analytic_depth(pose: torch.Tensor, k: torch.Tensor, width: int, height: int) -> torch.Tensor:
     """Depth (camera z) of a sphere r=0.9 m inside an axis-aligned box of half-size 1.2 m.  Works on
     whatever device ``pose`` lives on (the benchmark generates its frames on the GPU)."""
+    return _analytic_scene(pose, k, width, height)[0]
+
+
+# Panoptic class ids the analytic scene's surfaces carry (COCO panoptic order, kmax.constants: 56 = chair's thing id is not
+# needed here -- any ids in [0, 133) work; the names come from whatever class list the caller hands to discover_objects):
+# the sphere, then the box's faces -x +x -y +y -z +z.  Two opposite walls share a class: two objects of one label.
+SCENE_SURFACE_CLASSES = (56, 131, 131, 119, 119, 122, 100)
+
+
+def _analytic_scene(pose: torch.Tensor, k: torch.Tensor, width: int, height: int, half=1.2):
+    """(depth [H,W] f32, surface [H,W] int64): depth as ``_analytic_depth``; surface 0 = the sphere, 1..6 = the box
+    face the ray leaves through (-x +x -y +y -z +z).  ``half``: the box's half-size, a number or one per axis."""
     dev = pose.device
     u = torch.arange(width, dtype=torch.float64, device=dev)
     v = torch.arange(height, dtype=torch.float64, device=dev)
@@ -96,13 +109,29 @@ def _analytic_depth(pose: torch.Tensor, k: torch.Tensor, width: int, height: int
     s_sphere = torch.where(disc > 0, (-b - disc.clamp_min(0).sqrt()) / (2 * a), inf)
     s_sphere = torch.where(s_sphere > 0, s_sphere, inf)
     # box exit (camera is outside the box: take the far faces, i.e. the inside of the room)
-    half = 1.2
+    half = torch.as_tensor(half, dtype=torch.float64, device=dev)
     inv = 1.0 / d
     t1 = (-half - o) * inv
     t2 = (half - o) * inv
-    s_box = torch.maximum(t1, t2).min(dim=-1).values
+    far = torch.maximum(t1, t2)
+    s_box, axis = far.min(dim=-1)
     s = torch.minimum(s_sphere, s_box)
-    return s.float()
+    exits_high = torch.gather(t2 >= t1, -1, axis[..., None])[..., 0]
+    surface = torch.where(s_sphere <= s_box, torch.zeros_like(axis), 1 + 2 * axis + exits_high.long())
+    return s.float(), surface
+
+
+def blob_label_map(gen, width: int, height: int, n_blobs: int = 40, n_label_classes: int = 134, device=None):
+    """A piecewise-constant class map [H,W] int64 like a panoptic segmentation's: the Voronoi cells of ``n_blobs``
+    seeded points, each with a random class (SURVEY 8d draws the label map iid per pixel -- the worst case for the
+    label histogram and nothing a segmentation network emits)."""
+    dev = device if device is not None else (gen.device if hasattr(gen, "device") else "cpu")
+    pts = torch.rand((n_blobs, 2), generator=gen, device=dev) * torch.tensor([height, width], dtype=torch.float32, device=dev)
+    cls = torch.randint(0, n_label_classes, (n_blobs,), generator=gen, device=dev)
+    vv, uu = torch.meshgrid(torch.arange(height, dtype=torch.float32, device=dev),
+                            torch.arange(width, dtype=torch.float32, device=dev), indexing="ij")
+    d2 = (vv[..., None] - pts[:, 0]) ** 2 + (uu[..., None] - pts[:, 1]) ** 2
+    return cls[d2.argmin(dim=-1)]
 
 
 def make_frame(
@@ -116,6 +145,8 @@ def make_frame(
     radius: float = 2.5,
     n_label_classes: int = 134,
     missing_depth_frac: float = 0.0,
+    label_kind: str = "iid",
+    box_half=1.2,
 ):
     """One frame: dict of CPU f32 tensors shaped like a B=1 batch of the reference's loaders
     (clipfusion.py:190) plus the per-frame feature map and label map that stand in for the
@@ -124,10 +155,11 @@ def make_frame(
     c = c / c.norm() * radius
     pose = look_at_pose(c)
     k = intrinsics(width, height)
+    surface = None
     if depth_kind == "A":
         depth = torch.rand(height, width, generator=gen, dtype=torch.float32) * 2.0 + 1.5
     elif depth_kind == "B":
-        depth = _analytic_depth(pose, k, width, height)
+        depth, surface = _analytic_scene(pose, k, width, height, box_half)
     else:
         raise ValueError(depth_kind)
     if missing_depth_frac > 0:
@@ -135,7 +167,19 @@ def make_frame(
         depth = depth.masked_fill(hole, 0.0)
     rgb = torch.rand(height, width, 3, generator=gen, dtype=torch.float32)
     feat = torch.randn(feat_dim, npy, npx, generator=gen, dtype=torch.float32)
-    labels = torch.randint(0, n_label_classes, (height, width), generator=gen, dtype=torch.int64)
+    if label_kind == "iid":
+        labels = torch.randint(0, n_label_classes, (height, width), generator=gen, dtype=torch.int64)
+    elif label_kind == "blobs":  # piecewise constant in the image
+        labels = blob_label_map(gen, width, height, n_label_classes=n_label_classes)
+    elif label_kind == "scene":  # the class of the surface the pixel sees: coherent in 3-D (depth B only)
+        if surface is None:
+            raise ValueError("label_kind='scene' needs depth_kind='B'")
+        labels = torch.tensor(SCENE_SURFACE_CLASSES, dtype=torch.int64)[surface]
+    else:
+        raise ValueError(label_kind)
+    if surface is not None and label_kind == "scene":
+        return {"depth": depth[None], "rgb": rgb[None], "pose": pose[None], "K": k[None], "feat": feat[None], "labels": labels,
+                "surface": surface}
     return {
         "depth": depth[None],
         "rgb": rgb[None],
@@ -155,3 +199,93 @@ def feature_map_shape(width: int, height: int):
     """Patch size H/3, stride H/6 (clipfusion.py:1199-1201 uses 160/80 at 640x480)."""
     p, s = height // 3, height // 6
     return (height - p) // s + 1, (width - p) // s + 1
+
+
+# ---- a whole synthetic scan for the scene-level flow (spatially_aware_ai_amd/scene.py, bench.py --scene, tests/test_scene_pipeline.py)
+SCENE_CLASS_NAMES = {56: "chair", 131: "wall", 119: "floor", 122: "ceiling", 100: "window"}
+REFERENCE_GRID_BOX_HALF = (1.21, 0.98, 1.10)  # with 2 cm voxels and trunc = 3 voxels the scene's bounds come out as the
+                                              # reference's largest recorded grid, 127 x 104 x 116 (voxel_grid_compare.md:1-23)
+
+
+def class_embeddings(dim: int, n_classes: int = 134, seed: int = 1234) -> torch.Tensor:
+    """One seeded unit vector per panoptic class: what stands in for a CLIP embedding of the class in the scene flow."""
+    e = torch.randn(n_classes, dim, generator=torch.Generator().manual_seed(seed))
+    return e / e.norm(dim=-1, keepdim=True)
+
+
+class SyntheticScan(torch.utils.data.Dataset):
+    """A scan of the analytic sphere-in-a-box scene in the shape of the reference's loaders: ``imwidth`` / ``imheight`` and
+    ``__getitem__ -> (rgb[H,W,3], depth[H,W], pose[4,4], K[3,3], idx)`` (clipfusion.py:190).  Per frame it also holds what the
+    backbones would say: a panoptic map (the class of the surface every pixel sees) and a CLIP-shaped feature map whose
+    cell (i, j) is the embedding of the class at the cell's centre plus noise -- so that objects, segment colours and a text
+    query over the reconstruction mean something."""
+
+    def __init__(self, seed, n_frames, width, height, feat_dim, box_half=1.2, noise=0.3):
+        self.imwidth, self.imheight = width, height
+        self.npy, self.npx = feature_map_shape(width, height)
+        self.patch, self.stride = height // 3, height // 6
+        self.emb = class_embeddings(feat_dim)
+        gen = torch.Generator().manual_seed(seed)
+        self.frames = []
+        cls_of = torch.tensor(SCENE_SURFACE_CLASSES, dtype=torch.int64)
+        cy = torch.arange(self.npy) * self.stride + self.patch // 2
+        cx = torch.arange(self.npx) * self.stride + self.patch // 2
+        for _ in range(n_frames):
+            f = make_frame(gen, width, height, feat_dim, self.npy, self.npx, depth_kind="B", label_kind="scene", box_half=box_half)
+            centre_cls = cls_of[f["surface"][cy][:, cx]]  # [npy, npx]
+            f["feat"] = (self.emb[centre_cls].permute(2, 0, 1) + noise * f["feat"][0])[None].contiguous()
+            self.frames.append(f)
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __getitem__(self, i):
+        f = self.frames[i]
+        return f["rgb"][0], f["depth"][0], f["pose"][0], f["K"][0], i
+
+
+class ReplayClip:
+    """Backbone stand-in for a ``SyntheticScan``: ``img_inference_tiled`` hands back the scan's feature maps in call order
+    (one ``integrate`` per frame, as the reference drives it); the text side maps a class name to its embedding."""
+
+    def __init__(self, scan, device="cuda", class_names=None):
+        self.feature_dim = scan.emb.shape[1]
+        self.maps = [f["feat"].to(device) for f in scan.frames]
+        self.emb = scan.emb
+        self.names = class_names
+        self.calls = 0
+
+    def img_inference_tiled(self, rgb, patch_size, patch_stride):
+        m = self.maps[self.calls % len(self.maps)]
+        self.calls += 1
+        return m
+
+    def encode_text_with_prompt_ensemble(self, texts, device, prompt_templates=None):
+        rows = []
+        for t in texts:
+            if self.names is not None and t in self.names:
+                rows.append(self.emb[self.names.index(t)])
+            else:  # not a class of the scene: a seeded direction of its own
+                v = torch.randn(self.feature_dim, generator=torch.Generator().manual_seed(zlib.crc32(t.encode())))
+                rows.append(v / v.norm())
+        return torch.stack(rows).to(device)
+
+
+class ReplaySeg:
+    def __init__(self, scan, device="cuda"):
+        self.maps = [f["labels"].to(device) for f in scan.frames]
+        self.calls = 0
+
+    def run_on_image(self, rgb_chw):
+        m = self.maps[self.calls % len(self.maps)]
+        self.calls += 1
+        return m
+
+
+def scene_class_names(n_classes: int = 134):
+    return [SCENE_CLASS_NAMES.get(i, f"class{i}") for i in range(n_classes)]
+
+
+def scene_class_colors(n_classes: int = 134):
+    g = torch.Generator().manual_seed(77)
+    return torch.randint(0, 256, (n_classes, 3), generator=g).tolist()

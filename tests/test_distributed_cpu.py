@@ -23,9 +23,9 @@ DIM, W, H = 8, 40, 30
 N_FRAMES = 7
 
 
-def _frames():
+def _frames(depth_kind="A"):
     npy, npx = syn.feature_map_shape(W, H)
-    return syn.make_frames(321, N_FRAMES, width=W, height=H, feat_dim=DIM, npy=npy, npx=npx, depth_kind="A"), (npy, npx)
+    return syn.make_frames(321, N_FRAMES, width=W, height=H, feat_dim=DIM, npy=npy, npx=npx, depth_kind=depth_kind), (npy, npx)
 
 
 def _fuse(vol, frames, seem):
@@ -42,19 +42,24 @@ def _tensors(vol):
     return t
 
 
-def _worker(rank, world, port, mode, gather, out_dir, piece_bytes=None):
+def _worker(rank, world, port, mode, gather, out_dir, piece_bytes=None, sparse=None, nvox=NVOX, side=1.2, depth_kind="A",
+            trunc_vox=3.0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import oracle as O
 
-        grid = syn.make_grid(NVOX, side=1.2)
-        frames, _ = _frames()
+        grid = syn.make_grid(nvox, side=side, trunc_vox=trunc_vox)
+        frames, _ = _frames(depth_kind)
         mine = sdist.shard_frames(len(frames), rank, world)
         vol = O.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM, 143, _abi.SAF_SUM)
         _fuse(vol, [frames[i] for i in mine], seem=True)
-        stripes = sdist.merge_sums(_tensors(vol), mode=mode, gather=gather, piece_bytes=piece_bytes)
+        if sparse is not None:
+            assert sdist.probe_all_to_all(torch.device("cpu")) is None
+        stripes = sdist.merge_sums(_tensors(vol), mode=mode, gather=gather, piece_bytes=piece_bytes, sparse=sparse)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "last_merge.npy"), np.array([sdist.last_merge[k] for k in ("pieces", "packed", "rows", "touched_rows")]))
         # local divide over the stripes this rank owns (the HIP path calls saf_merge_finalize here)
         c = vol.c_volume()
         import ctypes as C
@@ -120,6 +125,47 @@ def test_merge_equals_single_process(tmp_path, oracle, mode, world, piece_bytes)
     expect = world if mode == "all_reduce" else 1
     assert (covered == expect).all(), "every voxel must be finalised by exactly the ranks that own it"
     assert int(ref.weight.sum()) > 0
+
+
+@pytest.mark.parametrize("world,sparse,want_packed", [(2, 1.0, "all"), (4, 1.0, "all"), (8, 1.0, "all"), (4, 0.3, "some"), (2, 0.0, "none")])
+def test_sparse_merge_equals_single_process(tmp_path, oracle, world, sparse, want_packed):
+    """The merge that skips what no rank touched ("exploit sparsity"): the coherent scene in a grid wider
+    than the scene -- whole pieces of the stripe plan are empty, others thin shells -- merged with the touched rows packed
+    (all_to_all with uneven splits) where the touched share of a piece is at most `sparse`, dense elsewhere: the same
+    stripes, the same volume as one process fusing every frame."""
+    nvox, side, piece_bytes = (16, 12, 10), 4.2, 143 * 4 * 48
+    mp.spawn(_worker, args=(world, _free_port(), "reduce_scatter", False, str(tmp_path), piece_bytes, sparse, nvox, side, "B", 1.0),
+             nprocs=world, join=True)
+    grid = syn.make_grid(nvox, side=side, trunc_vox=1.0)
+    frames, _ = _frames("B")
+    ref = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, DIM, 143)
+    _fuse(ref, frames, seem=True)
+    n = ref.n
+    pieces, packed, rows, touched = np.load(os.path.join(tmp_path, "last_merge.npy")).tolist()
+    plan = sdist.stripe_plan(n, world, sdist.piece_rows_for(143 * 4, world, piece_bytes))
+    assert pieces == len(plan) >= 3 and rows == n
+    w_ref = ref.weight.numpy()
+    if want_packed == "none":
+        assert packed == 0 and touched == -1
+    else:
+        assert touched == int((w_ref > 0).sum()) and 0 < touched < 0.5 * n
+        empty = sum(1 for first, r, c in plan if not (w_ref[first:first + world * c] > 0).any())
+        assert empty >= 1, "the workload has whole pieces no rank touched"
+        assert packed == pieces if want_packed == "all" else 0 < packed < pieces
+    covered = np.zeros(n, dtype=np.int32)
+    for r in range(world):
+        g = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        stripes = [tuple(int(v) for v in st) for st in g["stripes"]]
+        assert stripes == sdist.stripes_of_rank(plan, r, world)
+        for first, count in stripes:
+            sl = slice(first, first + count)
+            covered[sl] += 1
+            assert np.array_equal(g["weight"][sl], w_ref[sl]) and np.array_equal(g["tsdf_weight"][sl], ref.tsdf_weight.numpy()[sl])
+            assert np.array_equal(g["labels_one_hot"][sl], ref.labels_one_hot.numpy()[sl])
+            np.testing.assert_allclose(g["clip_feat"][sl], ref.clip_feat.numpy()[sl], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(g["rgb"][sl], ref.rgb.numpy()[sl], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(g["tsdf"][sl], ref.tsdf.numpy()[sl], rtol=1e-4, atol=2e-6)
+    assert (covered == 1).all()
 
 
 # ---- BASELINE config 5: the voxel-sharded query scan (sharding + reductions; the scan itself is injected) ----
@@ -299,7 +345,7 @@ def test_stripe_plan_tiles_and_ramp():
         assert all(c > 0 for _, c in b) and b[0][1] <= max(c for _, c in b) and b[-1][1] <= max(c for _, c in b)
 
 
-def _gather_shards_worker(rank, world, port, out):
+def _gather_shards_worker(rank, world, port, out, with_plan=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -319,15 +365,35 @@ def _gather_shards_worker(rank, world, port, out):
                 x[f:f + c] = t[f:f + c]
             setattr(v, k, x)
         v._shard_stripes = mine
+        calls = {"all_gather_into_tensor": 0, "broadcast": 0}
+        real = {k: getattr(dist, k) for k in calls}
+        for k in calls:
+            def counted(*a, _k=k, **kw):
+                calls[_k] += 1
+                return real[_k](*a, **kw)
+            setattr(dist, k, counted)
+        if with_plan:  # what merge_volumes / fuse_merge_pipelined record: one plan per merge (two here: as after two slabs)
+            half = (len(plan) // 2)
+            v._shard_plans = [plan[:half], plan[half:]]
         assert sdist.gather_shards(v) == [(0, n)] and v._shard_stripes is None
-        out[rank] = all(torch.equal(getattr(v, k), t) for k, t in full.items())
+        for k in calls:
+            setattr(dist, k, real[k])
+        ok = all(torch.equal(getattr(v, k), t) for k, t in full.items())
+        if with_plan:  # the striped in-place all-gather: one call per whole piece and tensor, a broadcast only for the tail
+            whole_pieces = sum(1 for _, rows, c in plan if c > 0)
+            ok = ok and calls["all_gather_into_tensor"] == 3 * whole_pieces and calls["broadcast"] <= 3 and v._shard_plans is None
+        else:
+            ok = ok and calls["all_gather_into_tensor"] == 0 and calls["broadcast"] > 0
+        out[rank] = ok
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_gather_shards_makes_a_striped_volume_whole(world):
+@pytest.mark.parametrize("world,with_plan", [(2, False), (4, False), (2, True), (4, True), (8, True)])
+def test_gather_shards_makes_a_striped_volume_whole(world, with_plan):
+    """With the stripe plans the merge recorded: the in-place striped all-gather (every link busy); without (stripes set by
+    hand): stripe lists exchanged, one rooted broadcast per stripe."""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_gather_shards_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert all(out.get(r) for r in range(world))
+    mp.spawn(_gather_shards_worker, args=(world, _free_port(), out, with_plan), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
