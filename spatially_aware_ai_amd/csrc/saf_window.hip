@@ -42,8 +42,9 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int kWinMinFrames = 16;  // shorter calls run the per-frame pipeline
 #ifndef SAF_WIN_HITCAP
-#define SAF_WIN_HITCAP 128
-#endif
+#define SAF_WIN_HITCAP 512  // hits of a chunk (the staging area in LDS: 6 words per hit and wave -- 48 KB per workgroup).  128 until round 5: a coherent
+#endif                      // scene's chunk was then 9 rows (14 hits each) -- 1.5 sub-chunks, the lane-parallel phases a quarter full; 512: 48.3 -> 46.4 ms
+                            // on scene B, 76.1 -> 75.0 on depth A (profiles/r05/row_knobs.txt)
 constexpr int kHitCap = SAF_WIN_HITCAP;
 static_assert(kHitCap >= kWin, "a voxel's hits of one window must fit a chunk");
 constexpr int kWinThreads = 256;
@@ -874,6 +875,7 @@ __device__ __forceinline__ void win_batch_of(const WinCtx<CPL>& cx, const int (&
   }
 }
 
+
 template <int CPL, bool SUM, bool BF16, bool OF>
 __global__ __launch_bounds__(kWinThreads)
 __attribute__((amdgpu_waves_per_eu(OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE, OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE))) void
@@ -1125,6 +1127,8 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         // up to SR rows and kSubHits hits (a voxel has at most kWin <= kSubHits): more than 64 hits are applied in passes
         constexpr int kSubHits = 128;
         static_assert(kSubHits >= kWin && kSubHits <= kHitCap && kSubHits <= 128, "two blocks of 64 hits at most");
+        // (round 5, profiles/r05/row_knobs.txt: sub-chunks cut at 64 hits -- one pass, never a presort -- are SLOWER on the coherent
+        //  scene, 7.9 -> 9.0 ms per window: what a sub-chunk costs is mostly per sub-chunk, not per pass)
         const unsigned long long okm = __ballot(lane >= i0 && lane < m && lane < i0 + SR && (incl - pbase) <= kSubHits);
         const int nrows = __popcll(okm);  // >= 1
         const int nh = __builtin_amdgcn_readlane(incl, i0 + nrows - 1) - pbase;  // 1..kSubHits
@@ -1362,6 +1366,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
             }
             first = false;
           }
+          WT(6);  // (inside the pass loop: a second pass's records must not be charged with the first pass's tap batches)
         }
         // nothing is outstanding here (every tap load has been consumed); the explicit wait only tells the
         // compiler's wait-count pass so, or it would drain vmcnt -- i.e. the previous row's store -- before
