@@ -87,6 +87,8 @@ def parse():
                     help="feature-volume dtype: f32 = the reference layout (headline); bf16 = BASELINE config 3")
     ap.add_argument("--labels", action="store_true",
                     help="ClipSeemFusion path: panoptic label histogram + bilinear rgb (BASELINE config 3)")
+    ap.add_argument("--label-kind", default="iid", choices=["iid", "world"],
+                    help="--labels: panoptic maps iid per pixel (SURVEY 8d) or consistent in 3-D (world_label_maps)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile-events", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
@@ -146,6 +148,27 @@ def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device):
     rgb = torch.rand((n, height, width, 3), generator=g, device=device)
     feat = torch.randn((n, dim, npy, npx), generator=g, device=device)
     return depth, rgb, poses, ks, feat
+
+
+def world_label_maps(depth, poses, ks, n_seeds=40, n_classes=134, seed=78):
+    """Panoptic maps that are consistent in 3-D, as a segmentation of a static scene is: the class of a pixel is the class of the
+    Voronoi cell (of `n_seeds` seeded points in the scene cube) that the surface point it sees -- un-projected with its depth --
+    lies in.  Whatever frame observes a voxel's surroundings then reports the same class, which SURVEY 8d's iid map (the worst
+    case for the label histogram) never does.  [F,H,W] float32 on the frames' device."""
+    dev = depth.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    seeds = (torch.rand((n_seeds, 3), generator=g, device=dev) - 0.5) * 2.56
+    cls = torch.randint(0, n_classes, (n_seeds,), generator=g, device=dev).float()
+    f, h, w = depth.shape
+    vv, uu = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+    out = torch.empty((f, h, w), dtype=torch.float32, device=dev)
+    for i in range(f):
+        k, p = ks[i], poses[i]
+        x = (uu - k[0, 2]) / k[0, 0] * depth[i]
+        y = (vv - k[1, 2]) / k[1, 1] * depth[i]
+        pts = torch.stack((x, y, depth[i]), dim=-1).reshape(-1, 3) @ p[:3, :3].T + p[:3, 3]
+        out[i] = cls[torch.cdist(pts, seeds).argmin(dim=1)].view(h, w)
+    return out
 
 
 def launch_ranks(a):
@@ -253,8 +276,11 @@ def main():
                                                  1000 + rank, device)
     label_maps = None
     if a.labels:
-        gl = torch.Generator(device=device).manual_seed(77 + rank)
-        label_maps = torch.randint(0, 134, (uniq, a.height, a.width), generator=gl, device=device).float()
+        if a.label_kind == "world":
+            label_maps = world_label_maps(depth, poses, ks)
+        else:
+            gl = torch.Generator(device=device).manual_seed(77 + rank)
+            label_maps = torch.randint(0, 134, (uniq, a.height, a.width), generator=gl, device=device).float()
     arr_u, keep, _, _ = fusion._make_frames(depth, rgb, poses, ks, feat, label_maps, a.labels)
     frames = (_abi.SafFrame * a.frames)()
     for i in range(a.frames):
@@ -887,14 +913,17 @@ def side_workloads(a, device, L, frames_A, npy, npx):
     class Resident:
         feature_dim = a.dim
 
-    def fuse_case(name, nvox, fdt, labels, fr, note):
+    def fuse_case(name, nvox, fdt, labels, fr, note, label_kind="iid"):
         grid = syn.make_grid(nvox)
         d_, r_, p_, k_, f_ = fr
         if labels:
             fz = ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, a.height // 3, a.height // 6,
                                 Resident(), None, keep_xyz_world=False, feat_dtype=fdt).to(device)
-            gl = torch.Generator(device=device).manual_seed(77)
-            lm = torch.randint(0, 134, (d_.shape[0], a.height, a.width), generator=gl, device=device).float()
+            if label_kind == "world":
+                lm = world_label_maps(d_, p_, k_)
+            else:
+                gl = torch.Generator(device=device).manual_seed(77)
+                lm = torch.randint(0, 134, (d_.shape[0], a.height, a.width), generator=gl, device=device).float()
         else:
             fz = ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, Resident(), None, a.height // 3,
                             a.height // 6, keep_xyz_world=False, feat_dtype=fdt).to(device)
@@ -950,7 +979,12 @@ def side_workloads(a, device, L, frames_A, npy, npx):
     if a.dim % 512 == 0:
         fuse_case("config3_256cube_bf16_labels", 256, torch.bfloat16, True, frames_A,
                   "BASELINE config 3's fused part: 512 frames into a 256^3 x 512 bf16 grid + the 143-class label histogram "
-                  "(bf16 features: the window's map images are kept in bf16, DESIGN 4.6c)")
+                  "(bf16 features: the window's map images are kept in bf16, DESIGN 4.6c); panoptic maps iid per pixel (SURVEY 8d: "
+                  "no two frames agree on a voxel's class -- the worst case for the histogram)")
+        fuse_case("config3_256cube_bf16_labels_consistent", 256, torch.bfloat16, True, frames_A,
+                  "config 3's fused part with panoptic maps that are consistent in 3-D (the class of the Voronoi cell, of 40 seeded "
+                  "points, that the observed surface point lies in): what a segmentation of a static scene looks like -- a voxel's "
+                  "equal classes of consecutive frames are counted with one add", label_kind="world")
     nb = min(128, uniq)
     frames_B = gen_frames_gpu(nb, a.width, a.height, a.dim, npy, npx, "B", 2000, device)
     fuse_case("coherent_scene_depth_B", 256, torch.float32, False, frames_B,

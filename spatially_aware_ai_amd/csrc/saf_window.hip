@@ -164,6 +164,9 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_WIN_OF_P2
 #define SAF_WIN_OF_P2 2
 #endif
+#ifndef SAF_WIN_LABEL_RUNS
+#define SAF_WIN_LABEL_RUNS 1  // label histogram: one add per run of equal classes of a voxel's hits (0: one atomic per hit, rounds 1-4)
+#endif
 #ifndef SAF_WIN_ABL
 #define SAF_WIN_ABL 0  // development: ablations of the order-free kernel (WRONG results): 1 taps "outside" (instructions issue, no
 #endif                 // request), 2 no tap instructions, 4 no row loads, 8 no row stores, 16 no multiply-adds
@@ -1075,6 +1078,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         const int j = j0 + lane;
         const uint32_t hf = j < htot ? s_hf[j] : 0u;
         const uint32_t n = (uint32_t)__shfl((int)n_l, (int)(hf & 63u));
+        int lbl = -1;  // the hit's panoptic class, -1: none
         if (j < htot) {
           const int fb = (int)(hf >> 22);
           int ix, iy, iz;
@@ -1094,7 +1098,30 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
           s_ha[j] = s0;
           s_hb[j] = s1;
           s_hs2[j] = s2;
+#if !SAF_WIN_LABEL_RUNS
           count_label_lane<true>(v, kf, n, pix, stats);
+#endif
+          // the hit's class (clip_seem_fusion.py:786-791: nearest sample of the panoptic map, .long())
+          if (SAF_WIN_LABEL_RUNS && v.labels && kf.label_map) {
+            const float lraw = kf.label_map[pix >= 0 ? pix : 0];
+            const long long l = (long long)(pix >= 0 ? lraw : 0.f);
+            const bool ok = l >= 0 && l < v.n_classes;
+            lbl = ok ? (int)l : -1;
+            if (!ok && stats) atomicAdd(&stats[3], 1ull);
+          }
+        }
+        if (SAF_WIN_LABEL_RUNS && v.labels && s_lab[0]) {
+          // Label histogram (clip_seem_fusion.py:820-822), one add per RUN: a voxel's hits lie in consecutive lanes in frame
+          // order, and what a panoptic model says about a static scene is the same frame after frame -- the first lane of a
+          // run of equal classes of one voxel adds the run's length (integer adds: bit for bit the per-hit histogram; a run
+          // that straddles two rounds of 64 hits is two adds).  Maps that are iid per pixel have runs of one: as before.
+          const int prev_l = __shfl_up(lbl, 1);
+          const uint32_t prev_v = (uint32_t)__shfl_up((int)(hf & 63u), 1);
+          const bool head = lbl >= 0 && (lane == 0 || prev_l != lbl || prev_v != (hf & 63u));
+          const unsigned long long stops = __ballot(head || lbl < 0);  // where a run cannot continue
+          const unsigned long long above = lane == 63 ? 0ull : (stops >> (lane + 1));
+          const int len = above ? __ffsll((long long)above) : 64 - lane;
+          if (head) atomicAdd(v.labels + (int64_t)n * v.n_classes + lbl, len);
         }
       }
       wave_lds_sync();
