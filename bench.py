@@ -107,6 +107,8 @@ def parse():
                          "clipfusion.py:1125-1133) with the deferred window queue behind it; reported as api_b1")
     ap.add_argument("--queries", type=int, default=1000, help="--query: number of target text queries")
     ap.add_argument("--query-wide-only", action="store_true", help="--query: skip the fp32 L=5 / L=63 cases")
+    ap.add_argument("--side-traffic", metavar="JSON", default=None,
+                    help="measure the side workloads' HBM counter traffic (two profiler passes per workload) into this file and exit")
     ap.add_argument("--scene", action="store_true",
                     help="the scene-level flow of the reference's manager (clip_seem_fusion.py:247-437, then :482-561) on one "
                          "synthetic scan: seconds per stage and in total, one JSON line")
@@ -218,6 +220,9 @@ def main():
     if a.query:
         return bench_query(a, world, rank, local_rank)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    if a.side_traffic:
+        side_traffic(a, a.side_traffic)
+        return
     if a.scene:
         torch.cuda.set_device(local_rank)
         r = bench_scene(a, torch.device("cuda", local_rank), a.scene_frames)
@@ -583,8 +588,8 @@ def main():
                                 ("frames (order-free form: a row's samples of the window are summed in registers and blended once -- "
                                  "feature values within fp32 rounding of frame-by-frame fusion, everything else bit-identical)"
                                  if form[0] == "s" else "frames (hits applied in frame order: bit-identical to frame-by-frame fusion)") +
-                                "; `avg_launch_us` = the row kernel's time per WINDOW (the first window of a call runs as four slab "
-                                "launches, so that its classification hides behind its own rows: `launches` / `windows`); the NEXT "
+                                "; `avg_launch_us` = the row kernel's time per WINDOW (one launch per window unless SAF_WIN_SLABS / "
+                                "SAF_WIN_W0_SLABS cut windows into slabs: `launches` / `windows`); the NEXT "
                                 "unit's classification + TSDF (classify kernels, kernel_breakdown.sweep_us per launch of 32 frames) "
                                 "run beside it on a second stream, so this duration is that of a kernel sharing the chip: `isolated` "
                                 "is the same kernel alone")
@@ -837,7 +842,7 @@ def windowed_headline(st):
     return st.get("window_rows", 0) > 0
 
 
-def measure_traffic(a, timeout_s=150):
+def measure_traffic(a, timeout_s=150, overrides=None):
     """HBM bytes per window of fuse_window_kernel, measured now: this script runs ONE job (512 frames, no warm-up, no side work)
     as a child process under `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes; output under
     /tmp), the per-launch counter values of the row kernel are averaged.  FETCH_SIZE is doubled (on gfx950 it reports half the
@@ -856,10 +861,13 @@ def measure_traffic(a, timeout_s=150):
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="saf_pmc_", dir="/tmp")
+        o = dict(grid=str(a.grid), depth_kind=a.depth_kind, feat_dtype=a.feat_dtype, labels=a.labels, label_kind=a.label_kind)
+        o.update(overrides or {})
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
                os.path.abspath(__file__), "--cpu-frames", "0", "--steps", "1", "--warmup", "0", "--no-profile-events", "--no-side",
-               "--end-to-end", "0", "--no-pmc", "--frames", str(a.frames), "--grid", str(a.grid), "--dim", str(a.dim),
-               "--depth-kind", a.depth_kind]
+               "--end-to-end", "0", "--no-pmc", "--frames", str(a.frames), "--grid", o["grid"], "--dim", str(a.dim),
+               "--depth-kind", o["depth_kind"], "--feat-dtype", o["feat_dtype"], "--label-kind", o["label_kind"]] + (
+                   ["--labels"] if o["labels"] else [])
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s, check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -870,7 +878,8 @@ def measure_traffic(a, timeout_s=150):
                         per.append(float(r["Counter_Value"]))
             if not per:
                 return None
-            vals[counter] = sum(per) / len(per)
+            # per WINDOW (a window cut into slab launches -- SAF_WIN_SLABS -- is still one unit of `avg_launch_us`)
+            vals[counter] = sum(per) / max(1, (a.frames + WIN - 1) // WIN)
         except Exception:
             return None
         finally:
@@ -878,7 +887,30 @@ def measure_traffic(a, timeout_s=150):
     read, write = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
     return {"read": int(read), "write": int(write), "hbm_bytes_per_launch": int(read + write),
             "source": "measured in this run: one job as a child process under rocprofv3 --pmc FETCH_SIZE and again under --pmc "
-                      "WRITE_SIZE (separate passes), mean over the job's row-kernel launches; FETCH_SIZE x 2 (gfx950), KiB -> bytes"}
+                      "WRITE_SIZE (separate passes), the job's row-kernel launches summed per window; FETCH_SIZE x 2 (gfx950), KiB -> bytes"}
+
+
+SIDE_TRAFFIC_CASES = {  # side workload -> the main-path flags of the same job (bench.py --side-traffic)
+    "config2_128cube_f32": dict(grid="128"),
+    "config3_256cube_bf16_labels": dict(feat_dtype="bf16", labels=True, label_kind="iid"),
+    "config3_256cube_bf16_labels_consistent": dict(feat_dtype="bf16", labels=True, label_kind="world"),
+    "coherent_scene_depth_B": dict(depth_kind="B"),
+}
+
+
+def side_traffic(a, path):
+    """`bench.py --side-traffic`: the counter traffic (HBM bytes per window of the row kernel) of every side workload's job, two
+    profiler passes each, written to `path` (committed as profiles/r05/side_traffic.json: the default run, which must stay
+    within minutes, quotes it instead of running eight more child processes)."""
+    out = {}
+    for name, ov in SIDE_TRAFFIC_CASES.items():
+        m = measure_traffic(a, overrides=ov)
+        out[name] = None if m is None else {"read": m["read"], "write": m["write"], "hbm_bytes_per_window": m["hbm_bytes_per_launch"]}
+        print(name, out[name], flush=True)
+    out["method"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over one 512-frame job of the same seeds and shapes as the "
+                     "side workload, row-kernel launches summed per window; FETCH_SIZE x 2 (gfx950), KiB -> bytes")
+    json.dump(out, open(path, "w"), indent=1)
+    return out
 
 
 def hbm_copy_rate(device, nbytes=4 << 30, reps=3):
@@ -971,6 +1003,13 @@ def side_workloads(a, device, L, frames_A, npy, npx):
                          "frac": round(fuse_bytes / kern / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "avg_launch_us": round(kern * 1e6, 1), "launches": int(n.value), "windows": int(n_win),
                          "algorithmic_bytes_per_launch": int(fuse_bytes)}}
+        try:  # counter traffic of the same job: measured this round with `bench.py --side-traffic` (two profiler passes per workload)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r05", "side_traffic.json")))
+            if tj.get(name) and a.dim == 512 and a.width == 640 and a.height == 480:
+                out[name]["roofline"]["traffic"] = tj[name]["hbm_bytes_per_window"]
+                out[name]["roofline"]["traffic_source"] = "profiles/r05/side_traffic.json (this round, another box): " + tj["method"]
+        except Exception:  # noqa: BLE001
+            pass
         del fz, ws, keep
         torch.cuda.empty_cache()
 

@@ -124,7 +124,7 @@ def dwconv7x7(x, weight, bias=None, _cache=None):
 
     n, c, h, w = x.shape
     dt = {torch.float32: _abi.SAF_F32, torch.bfloat16: _abi.SAF_BF16, torch.float16: _abi.SAF_F16}[x.dtype]
-    key = (weight.data_ptr(), weight._version, x.device)
+    key = (weight.data_ptr(), weight._version, x.device) + ((None, None) if bias is None else (bias.data_ptr(), bias._version))
     if _cache is not None and _cache.get("key") == key:
         w_kkc, b32 = _cache["w"], _cache["b"]
     else:

@@ -16,6 +16,7 @@ fallback: tensors that are not on the HIP device raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -479,8 +480,14 @@ class _FusionVolumeMixin:
         s = self.fuse_stats.cpu().tolist()
         if s[4]:
             raise SafError(f"{s[4]} fuse workgroups timed out waiting for their frame's sweep; the volume is incomplete")
+        # the form the windowed path takes for this volume NOW (environment, read per call by the library): results of two
+        # runs are comparable bit for bit only under the same form
+        form = os.environ.get("SAF_WIN_FORM", "sums")
+        form = {"s": "sums", "r": "rows", "b": "bricks"}.get(form[:1], "sums")
+        if form == "sums" and self._buffers["clip_feat"].dtype == torch.bfloat16:
+            form = "rows (SAF_WIN_MAPS16=0)" if os.environ.get("SAF_WIN_MAPS16", "1")[:1] == "0" else "sums, bf16 map images"
         return {"valid": s[0], "tsdf_valid": s[1], "frames": s[2], "labels_dropped": s[3], "window_rows": s[5],
-                "window_tsdf_voxels": s[6]}
+                "window_tsdf_voxels": s[6], "window_form": form}
 
     def sample_mesh_vertices(self, verts_index, voxel_obj_idx=None, objects_segmentation_color=None):
         """The sampling half of ``extract_mesh`` (reference clipfusion.py:741-760, clip_seem_fusion.py:843-878)

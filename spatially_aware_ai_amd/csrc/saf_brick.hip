@@ -380,7 +380,10 @@ struct BrickPool {
 // segments).  The walk of the pool's segments (pool.split == 2) is compiled WITHOUT it: with the build code inlined the walk
 // kernel spilled 23-95 registers at its cap of 128.
 template <int CPL, bool SUM, bool BF16, bool BUILD, bool REBUILD = true>
-__global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void fuse_brick_kernel(
+// (round 5: the walk instantiations that carry the build code -- the small launch over the overflow list, and SAF_BRICK_SPLIT=0 --
+//  may use the registers of two waves per SIMD instead of four: they spilled 6-96 VGPRs at the cap of 128.  Their workgroups are
+//  independent -- work is handed out by counters -- so fewer of them resident at once only lengthens those rare launches.)
+__global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((amdgpu_waves_per_eu((!BUILD && REBUILD) ? 2 : 4, 4))) void fuse_brick_kernel(
     KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, uint32_t img_bytes,
     unsigned long long* __restrict__ stats, unsigned int* __restrict__ ctr, const uint32_t* __restrict__ hitmask,
     uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc, const uint32_t* __restrict__ cmax,

@@ -337,6 +337,7 @@ struct Wide2Args {
   float* out_value;        // ROW_ARGMAX [n_rows]
   unsigned long long* qkeys;  // QUERY_MAX [Qpad]: ordered(score) << 32 | low 32 bits of ~row (smaller row wins ties)
   int64_t row_offset;
+  int safe_wait;  // SAF_W2_SAFE_WAIT=1 (read per call): vmcnt(0) in front of every tile's barrier instead of the counted wait
 };
 
 // What the epilogue of a tile needs to know about the tile (it runs one step later, beside the next tile's MFMAs,
@@ -682,7 +683,9 @@ query_wide2_kernel(Wide2Args wa) {
     // The wait is COUNTED: the wave's `tail_ops` youngest vector-memory operations are the previous tile's last stores (or
     // its atomic), issued behind the transfer -- they need not have landed (vmcnt retires in issue order).
 #if SAF_W2_ASMDMA
-    w2_wait_vm(kDma ? tail_ops : 0);
+    // (the count is this file's claim about what the compiler emits behind the transfer: SAF_W2_SAFE_WAIT=1 drains instead,
+    //  and tests/test_gpu_parity.py::test_wide_scan_counted_wait_equals_the_draining_wait compares the two bit for bit)
+    w2_wait_vm(kDma && !wa.safe_wait ? tail_ops : 0);
 #else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1120,6 +1123,7 @@ int saf_query_scan_wide_ex(const void* feats, int32_t feat_dtype, int64_t n_rows
     wa.n_rows = n_rows; wa.fstride = feat_stride; wa.text16 = text16; wa.Q = cols; wa.Qpad = Qpad; wa.scale = scale;
     wa.normalize = normalize; wa.n_bg = n_bg; wa.flags = flags; wa.out = out; wa.ostride = out_stride;
     wa.out_index = out_index; wa.out_value = out_value; wa.qkeys = qkeys; wa.row_offset = row_offset;
+    wa.safe_wait = getenv("SAF_W2_SAFE_WAIT") && getenv("SAF_W2_SAFE_WAIT")[0] == '1' ? 1 : 0;
     if (feat_dtype == SAF_BF16)
       rc = feat_dim == 512 ? launch_wide2_epi<SAF_BF16, 32>(epilogue, out_dtype, wa, s) : launch_wide2_epi<SAF_BF16, 16>(epilogue, out_dtype, wa, s);
     else

@@ -1616,7 +1616,11 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const int split = brick_form && brick_split() ? 1 : 0;
   WinFn fn = nullptr;
   size_t win_lds = 0;
-  const bool of = window_form_sums();
+  // SAF_WIN_MAPS16=0 (read per call): a bf16 volume keeps fp32 map images -- it takes the frame-ordered kernel, bit-identical
+  // to the per-frame bf16 pipeline -- instead of the order-free form's bf16 images (one rounding of every tap to the volume's
+  // precision, exact when the backbone emitted bf16: BASELINE config 3).  fp32 volumes are not affected.
+  const char* m16 = getenv("SAF_WIN_MAPS16");
+  const bool of = window_form_sums() && !(kv.bf16 != 0 && m16 && m16[0] == '0');
   if (!brick_form) switch (kv.D / 256) {
     case 1: fn = pick_win<1>(sum, kv.bf16 != 0, of, &win_lds); break;
     case 2: fn = pick_win<2>(sum, kv.bf16 != 0, of, &win_lds); break;

@@ -1413,3 +1413,30 @@ def test_wide_scan_single_query_tile(n, q, dt):
     assert (ref[torch.arange(n, device="cuda"), idx.long()] - ref.max(dim=1).values).abs().max().item() < 3e-5
     assert (qv - ref.max(dim=0).values).abs().max().item() < 3e-5
     assert (ref[qr, torch.arange(q, device="cuda")] - ref.max(dim=0).values).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("dt,d", [(torch.float16, 512), (torch.bfloat16, 256)])
+def test_wide_scan_counted_wait_equals_the_draining_wait(dt, d, monkeypatch):
+    """The wide scan's next text tile travels by LDS-DMA issued from inline assembly and is waited for with a COUNTED
+    `s_waitcnt vmcnt(n)`, n = the vector-memory operations the code claims to issue behind the transfer (saf_query_wide.hip).
+    If the compiler ever emitted fewer, the wait would release before the tile has landed.  SAF_W2_SAFE_WAIT=1 drains
+    (`vmcnt(0)`) instead: every epilogue must give bit for bit the same answer both ways, over enough tiles (thousands of
+    transfers per wave) that a tile read early would show."""
+    from spatially_aware_ai_amd.clipfusion import query_scan_wide
+
+    n, q, n_bg = 400_000, 1000, 4
+    g = torch.Generator(device="cuda").manual_seed(31)
+    f = torch.randn((n, d), generator=g, device="cuda").to(dt)
+    t = torch.randn((n_bg + q, d), generator=g, device="cuda")
+    t = t / t.norm(dim=-1, keepdim=True)
+
+    def run():
+        heat = query_scan_wide(f, t, "vs_background", scale=100.0, n_background=n_bg, rescale=True)
+        return (query_scan_wide(f, t[n_bg:], "scores"), heat) + tuple(query_scan_wide(f, t[n_bg:], "row_argmax")) + tuple(
+            query_scan_wide(f, t[n_bg:], "query_max"))
+
+    counted = run()
+    monkeypatch.setenv("SAF_W2_SAFE_WAIT", "1")
+    drained = run()
+    for a, b in zip(counted, drained):
+        assert torch.equal(a, b)

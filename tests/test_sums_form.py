@@ -150,3 +150,25 @@ def test_classification_guarded_pixel_path_self_check(monkeypatch, nvox, w, h, n
     assert s[5] > 0, "the windowed path did not run"
     assert s[1] > 1_000_000, s  # TSDF-valid voxel tests (a fraction of all the slots checked)
     assert s[7] == 0, f"{s[7]} voxel slots disagree with the reference's chain"
+
+
+def test_bf16_volume_with_fp32_map_images_takes_the_frame_ordered_kernel(monkeypatch):
+    """SAF_WIN_MAPS16=0 (read per call): the run-time escape from the bf16 map images of a bf16 volume's order-free form -- the
+    window is fused by the frame-ordered kernel from fp32 images, bit for bit the per-frame bf16 pipeline; fp32 volumes keep
+    the order-free form.  `stats()["window_form"]` says which form a volume takes."""
+    nvox, dim, n_frames = (33, 30, 41), 512, 36
+    grid = syn.make_grid(nvox, side=2.56 * nvox[0] / max(nvox))
+    frames = _frames(515, n_frames, dim, "B")
+    one = _fuse(_build(grid, dim, True, _abi.SAF_RUNNING_MEAN, torch.bfloat16, defer=False), frames, True, per_call=7)
+    monkeypatch.setenv("SAF_WIN_FORM", "sums")
+    sums16 = _fuse(_build(grid, dim, True, _abi.SAF_RUNNING_MEAN, torch.bfloat16), frames, True)
+    assert sums16.stats()["window_form"] == "sums, bf16 map images" and sums16.stats()["window_rows"] > 0
+    monkeypatch.setenv("SAF_WIN_MAPS16", "0")
+    rows32 = _fuse(_build(grid, dim, True, _abi.SAF_RUNNING_MEAN, torch.bfloat16), frames, True)
+    st = rows32.stats()
+    assert st["window_form"] == "rows (SAF_WIN_MAPS16=0)" and st["window_rows"] > 0
+    for name in EXACT + ("labels_one_hot", "clip_feat"):
+        assert torch.equal(getattr(one, name), getattr(rows32, name)), f"{name} differs from the sequential path"
+    assert not torch.equal(sums16.clip_feat, rows32.clip_feat)  # (the two forms round differently: that is what the switch is for)
+    f32 = _fuse(_build(grid, dim, True, _abi.SAF_RUNNING_MEAN, torch.float32), frames, True)
+    assert f32.stats()["window_form"] == "sums"

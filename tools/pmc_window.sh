@@ -20,7 +20,7 @@ for d in "abc":
     acc = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(fs[-1])):
         kn = r["Kernel_Name"]
-        k = "classify_window_kernel" if ("classify_window" in kn or "classify_bricks" in kn) else "fuse_window_kernel" if "fuse_window" in kn else None
+        k = "classify_bricks_kernel" if ("classify_window" in kn or "classify_bricks" in kn) else "fuse_window_kernel" if "fuse_window" in kn else None
         if k:
             acc[(k, r["Counter_Name"])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
     for (k, c), v in acc.items():

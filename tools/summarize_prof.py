@@ -39,7 +39,7 @@ if os.path.exists(f"{src}/bench_under_rocprof.json"):
 
 def name_of(k):
     if "classify_bricks_kernel" in k:
-        return "classify_window_kernel"  # the brick-shaped form of the same launch
+        return "classify_bricks_kernel"
     for n in ("fuse_window_kernel", "classify_window_kernel", "fuse_rows_kernel", "fuse_kernel", "sweep_kernel",
               "prep_rows_kernel", "prep_kernel", "query_kernel"):
         if n in k:
@@ -68,7 +68,7 @@ if out:
                   "depth_kind": "B" if "depth-B" in cfg["workload"] else "A",
                   "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one 512-frame job; "
                             "FETCH_SIZE x2 (gfx950 correction), KiB -> bytes"}
-            for kn, key in (("fuse_window_kernel", "hbm"), ("classify_window_kernel", "classify_hbm")):
+            for kn, key in (("fuse_window_kernel", "hbm"), ("classify_bricks_kernel", "classify_hbm")):
                 f = out["FETCH_SIZE"][kn]["mean_KiB"] * 1024 * 2
                 w = out["WRITE_SIZE"][kn]["mean_KiB"] * 1024
                 wt[f"{key}_read_bytes_per_launch"] = int(f)
