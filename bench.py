@@ -1134,6 +1134,8 @@ def bench_scene(a, device, n_frames=300, out_dir=None):
     from spatially_aware_ai_amd.scene import reconstruct_scene
 
     t_gen = time.perf_counter()
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, host_cores())))  # (the scan is generated on the host: a box that reports 256 CPUs and grants 16 crawls with 256 threads)
     names, colors = syn.scene_class_names(), syn.scene_class_colors()
     cfg = {"voxel_size": 0.02, "trunc_vox": 3, "clip_patch_size": a.height // 3, "clip_patch_stride": a.height // 6}
     warm = syn.SyntheticScan(3, 24, a.width, a.height, a.dim, box_half=syn.REFERENCE_GRID_BOX_HALF)
@@ -1159,7 +1161,7 @@ def bench_scene(a, device, n_frames=300, out_dir=None):
         uo = res.scene_knowledge["unique_objects"]
         out = {
             "total": round(t_rec + t_q1, 3), "reconstruct": round(t_rec, 3), "first_text_query": round(t_q1, 3),
-            "next_text_query": round(t_q2, 3), "stages": {k: round(v, 4) for k, v in res.seconds.items() if k != "text_query"},
+            "next_text_query": round(t_q2, 3), "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.seconds.items() if k != "text_query"},
             "frames": n_frames, "image": [a.width, a.height], "grid": [int(v) for v in res.nvox], "feat_dim": a.dim,
             "fuse_frames_per_s": round(n_frames / res.seconds["fuse"], 1), "objects": len(uo),
             "object_labels": sorted({o["class_label"] for o in uo.values()}), "mesh_vertices": int(len(res.verts)),
@@ -1175,6 +1177,7 @@ def bench_scene(a, device, n_frames=300, out_dir=None):
         torch.cuda.empty_cache()
         return out
     finally:
+        torch.set_num_threads(n_thr)
         if out_dir is None:
             shutil.rmtree(tmp, ignore_errors=True)
 

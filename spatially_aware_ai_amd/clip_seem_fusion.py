@@ -38,7 +38,7 @@ class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_patch_size, clip_patch_stride,
                  clip_model, seg_model, keep_xyz_world=True, feat_dtype=torch.float32, defer_frames=True,
-                 index_offset=(0, 0, 0), x_planes=None, defer_backbone=True):
+                 index_offset=(0, 0, 0), x_planes=None, defer_backbone=True, device=None):
         super().__init__()
         self.__dict__["defer_frames"] = bool(defer_frames)
         self.__dict__["defer_backbone"] = bool(defer_backbone)
@@ -49,7 +49,7 @@ class ClipSeemFusion(_FusionVolumeMixin, torch.nn.Module):
         self.segmentation_model = seg_model
         self.n_classes = N_PANOPTIC_SLOTS
         self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, self.n_classes, keep_xyz_world,
-                          feat_dtype, index_offset, x_planes)
+                          feat_dtype, index_offset, x_planes, device)
         self.debug_counter = 0
 
     def integrate(self, depth_imgs, rgb_imgs, poses, K):

@@ -62,7 +62,11 @@ class _FusionVolumeMixin:
     """Buffers, workspace and the C-ABI call shared by both fusion modules."""
 
     def _init_volume(self, origin, voxel_size, nvox, trunc, feat_dim, n_classes=0, keep_xyz_world=True,
-                     feat_dtype=torch.float32, index_offset=(0, 0, 0), x_planes=None):
+                     feat_dtype=torch.float32, index_offset=(0, 0, 0), x_planes=None, device=None):
+        """``device`` (not in the reference): create the buffers there instead of on the host.  The reference builds its module on
+        the host and moves it (clipfusion.py:1119, clip_seem_fusion.py:291-302) -- gigabytes of zeros through pageable memory
+        (0.7 s at 127 x 104 x 116 x 512); the axis tables are computed on the host either way."""
+        zeros = lambda *a, **k: torch.zeros(*a, device=device, **k)
         nvox = torch.as_tensor(nvox)
         n = int(torch.prod(nvox.long()))
         self.origin = origin
@@ -71,23 +75,25 @@ class _FusionVolumeMixin:
         self.trunc = trunc
         self.n_clip_feats = feat_dim
         self.accum_mode = _abi.SAF_RUNNING_MEAN
-        self.register_buffer("tsdf", torch.zeros(n, dtype=torch.float32))
-        self.register_buffer("rgb", torch.zeros((n, 3), dtype=torch.float32))
+        self.register_buffer("tsdf", zeros(n, dtype=torch.float32))
+        self.register_buffer("rgb", zeros((n, 3), dtype=torch.float32))
         if feat_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("feat_dtype must be torch.float32 (the reference layout) or torch.bfloat16")
-        self.register_buffer("clip_feat", torch.zeros((n, feat_dim), dtype=feat_dtype))
-        self.register_buffer("weight", torch.zeros(n, dtype=torch.int32))
-        self.register_buffer("tsdf_weight", torch.zeros(n, dtype=torch.int32))
+        self.register_buffer("clip_feat", zeros((n, feat_dim), dtype=feat_dtype))
+        self.register_buffer("weight", zeros(n, dtype=torch.int32))
+        self.register_buffer("tsdf_weight", zeros(n, dtype=torch.int32))
         if n_classes:
-            self.register_buffer("labels_one_hot", torch.zeros((n, n_classes), dtype=torch.int32))
+            self.register_buffer("labels_one_hot", zeros((n, n_classes), dtype=torch.int32))
         self.index_offset = tuple(int(v) for v in index_offset)
         self.x_planes = None if x_planes is None else torch.as_tensor(x_planes, dtype=torch.int64).detach().cpu().clone()
         ax = _axis_tables(origin, voxel_size, nvox, self.index_offset, self.x_planes)
+        if device is not None:
+            ax = [t.to(device) for t in ax]
         # not in the reference's state_dict: derived tables the sweep kernel reads instead of xyz_world
         self.register_buffer("axis_x", ax[0], persistent=False)
         self.register_buffer("axis_y", ax[1], persistent=False)
         self.register_buffer("axis_z", ax[2], persistent=False)
-        self.register_buffer("fuse_stats", torch.zeros(_abi.SAF_STATS_WORDS, dtype=torch.int64), persistent=False)
+        self.register_buffer("fuse_stats", zeros(_abi.SAF_STATS_WORDS, dtype=torch.int64), persistent=False)
         if keep_xyz_world:
             nx, ny, nz = (int(v) for v in nvox)
             xyz_world = torch.stack(
@@ -973,7 +979,7 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
 
     def __init__(self, origin, voxel_size, nvox, trunc, scale_patches_by_depth, clip_model, clip_pretraining,
                  clip_patch_size, clip_patch_stride, keep_xyz_world=True, feat_dtype=torch.float32, defer_frames=True,
-                 index_offset=(0, 0, 0), x_planes=None, defer_backbone=True):
+                 index_offset=(0, 0, 0), x_planes=None, defer_backbone=True, device=None):
         super().__init__()
         self.__dict__["defer_frames"] = bool(defer_frames)
         self.__dict__["defer_backbone"] = bool(defer_backbone)
@@ -987,7 +993,7 @@ class ClipFusion(_FusionVolumeMixin, torch.nn.Module):
         self.clip_patch_stride = clip_patch_stride
         self.scale_patches_by_depth = scale_patches_by_depth
         self._init_volume(origin, voxel_size, nvox, trunc, self.clip.feature_dim, 0, keep_xyz_world, feat_dtype, index_offset,
-                          x_planes)
+                          x_planes, device)
 
     def integrate(self, depth_imgs, rgb_imgs, poses, K):
         """Fuse a batch of frames (reference clipfusion.py:627-721).  Batch elements are folded in

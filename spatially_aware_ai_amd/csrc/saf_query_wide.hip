@@ -694,7 +694,8 @@ query_wide2_kernel(Wide2Args wa) {
     W2_STAMP(2);  // the barrier  // the wait for the tile and the barrier
     const bool more = step + 1 < n_steps;
     const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
-    uint4 stage[kDma ? 1 : PPT];
+    typedef unsigned int w2_u4 __attribute__((ext_vector_type(4)));  // (a native vector: HIP's uint4 -- a struct around a union -- stayed in scratch memory here)
+    w2_u4 stage[kDma ? 1 : PPT];
     // the next tile by LDS-DMA, 32 / kWaves pieces per wave, ahead of the tile's first MFMA.  (Tried: of the two waves that
     // share a SIMD one issuing here and the other one behind the first half of its MFMAs -- the second site splits the MFMA
     // loop: heat maps 24.8 vs 23.3 ms --; every wave issuing behind its 8th / 16th MFMA: 17.4 / 17.8 vs 17.7 ms for the row
@@ -713,7 +714,7 @@ query_wide2_kernel(Wide2Args wa) {
           const int p = tid + k * kThreads;
           if (p < PIECES) {
             const int q = p / (D / 8), cc = p - q * (D / 8);
-            stage[k] = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)(qt_next * kWTile + q) * D + cc * 8);
+            stage[k] = *reinterpret_cast<const w2_u4*>(wa.text16 + (int64_t)(qt_next * kWTile + q) * D + cc * 8);
           }
         }
       }
@@ -851,7 +852,7 @@ query_wide2_kernel(Wide2Args wa) {
         const int p = tid + k * kThreads;
         if (p < PIECES) {
           const int q = p / (D / 8), cc = p - q * (D / 8);
-          *reinterpret_cast<uint4*>(nxt + q * ROWB + cc * 16) = stage[k];
+          *reinterpret_cast<w2_u4*>(nxt + q * ROWB + cc * 16) = stage[k];
         }
       }
     }

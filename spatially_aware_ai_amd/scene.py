@@ -129,15 +129,27 @@ def reconstruct_scene(dataset, config, clip_model, seg_model, class_names, class
     origin, nvox = scene_bounds(xyz, config["voxel_size"], trunc_m)
     clk.lap("bounds")
     # ---- the volume and the fusion loop, one frame per call (clip_seem_fusion.py:291-313)
+    # (the reference builds the module on the host and moves it, clip_seem_fusion.py:291-302: gigabytes of zeros through pageable
+    #  memory -- 0.7 s at the reference's largest grid; `device=` lets the buffers be born on the device)
     fusion = ClipSeemFusion(origin, config["voxel_size"], nvox, trunc_m, scale_patches_by_depth, config["clip_patch_size"],
-                            config["clip_patch_stride"], clip_model, seg_model, feat_dtype=feat_dtype).to(device)
+                            config["clip_patch_stride"], clip_model, seg_model, feat_dtype=feat_dtype, device=device).to(device)
     loader = torch.utils.data.DataLoader(dataset, batch_size=1, num_workers=num_workers)
     stage = FrameStager(device)
+    host = {"loader": 0.0, "stage": 0.0, "integrate": 0.0}  # where the host's time in the loop goes (no device sync inside)
+    t_prev = time.perf_counter()
     for rgb_imgs, depth_imgs, poses, K, _ in loader:
+        t0 = time.perf_counter()
         depth_d, rgb_d, poses_d, k_d = stage(depth_imgs.float(), rgb_imgs.float(), poses.float(), K.float())
+        t1 = time.perf_counter()
         fusion.integrate(depth_d, rgb_d, poses_d, k_d)
+        t2 = time.perf_counter()
+        host["loader"] += t0 - t_prev
+        host["stage"] += t1 - t0
+        host["integrate"] += t2 - t1
+        t_prev = t2
     fusion.flush()
     clk.lap("fuse")
+    clk.seconds["fuse_host_split"] = {k: round(v, 4) for k, v in host.items()}
     # ---- labels: argmax with the empty check (:315-333), on the device
     onehot_to_index = fusion.label_index().view(*[int(v) for v in fusion.nvox])
     clk.lap("label_argmax")
