@@ -879,6 +879,7 @@ __device__ __forceinline__ void win_batch_of(const WinCtx<CPL>& cx, const int (&
 }
 
 
+
 template <int CPL, bool SUM, bool BF16, bool OF>
 __global__ __launch_bounds__(kWinThreads)
 __attribute__((amdgpu_waves_per_eu(OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE, OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE))) void
@@ -1167,6 +1168,10 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
         // Several rows with more than 64 hits between them (coherent scenes: ~15 hits per row): the staging entries of the
         // sub-chunk are brought into (frame, row) order first -- ranks from the rows' frame masks as below, for both blocks
         // of 64 hits, every staging field permuted through the free s_hw array -- and the passes then find them sorted.
+        // (round 5, profiles/r05/row_knobs.txt: a FRAME-MAJOR walk instead -- the frames taken in ascending order off the union of
+        //  the rows' masks, per frame the rows and their record lanes found from the masks lane-parallel, nothing sorted: 27 instead
+        //  of 54 vector instructions per hit, bit-identical sums, and 43 % SLOWER on the coherent scene, 9 % on random depth: every
+        //  group costs a serial mask -> ballot -> scalar -> readlane -> load round trip, which the sort pays once per pass)
         const bool presorted = nrows > 1 && nh > 64;
         if (presorted) {
           int rk[2];
@@ -1259,6 +1264,9 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
                 }
               }
             }
+            // (the ranks are only used to sort a sub-chunk of several rows that was not presorted: on a coherent scene -- 85 hits per
+            //  sub-chunk, nearly always presorted -- this loop was ~200 wasted vector instructions per sub-chunk)
+            if (nrows > 1 && !presorted)
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
               if (r < nrows) {
