@@ -290,7 +290,7 @@ def main():
     frames = (_abi.SafFrame * a.frames)()
     for i in range(a.frames):
         frames[i] = arr_u[i % uniq]
-    ws = fusion._get_workspace(npy, npx)
+    ws = fusion._get_workspace(npy, npx, (a.height, a.width))
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
     comm_stream = torch.cuda.Stream() if world > 1 else main_stream
@@ -964,7 +964,7 @@ def side_workloads(a, device, L, frames_A, npy, npx):
         arr = (_abi.SafFrame * n_frames)()
         for i in range(n_frames):
             arr[i] = arr_u[i % d_.shape[0]]
-        ws = fz._get_workspace(npy, npx)
+        ws = fz._get_workspace(npy, npx, (a.height, a.width))
         stream = torch.cuda.current_stream().cuda_stream
         prof = L.saf_profiler_create(3 * n_frames)
         L.saf_profiler_set_stride(prof, 4)
@@ -1406,7 +1406,7 @@ def bench_voxel_sharded(a, dist, sdist, grid, fusions, tensors, new_volume, worl
     planes = sdist.slab_planes_of_rank(nx, rank, world)
     cnt = int(planes.numel())
     slab = new_volume(torch.tensor([cnt, ny, nz], dtype=torch.int32), x_planes=planes)
-    ws = slab._get_workspace(npy, npx)
+    ws = slab._get_workspace(npy, npx, (a.height, a.width))
     stats = slab._buffers["fuse_stats"]
     uniq = tensors[0].shape[0]
     # segments of `seg` frames per rank: at least two windows per fuse call, so that classification and rows overlap inside it
@@ -1482,7 +1482,7 @@ def bench_voxel_sharded(a, dist, sdist, grid, fusions, tensors, new_volume, worl
             sub[r * c + i] = descs[0][0][r * seg + i]
     full = fusions[1]
     full.reset(lazy=False)  # (a handful of frames: the per-frame pipeline reads the rows it updates)
-    wsf = full._get_workspace(npy, npx)
+    wsf = full._get_workspace(npy, npx, (a.height, a.width))
     volf = full._c_volume(for_fuse=True)
     check(L.saf_fuse_frames_profiled(C.byref(volf), sub, world * c, wsf.data_ptr(), wsf.numel(), full._buffers["fuse_stats"].data_ptr(),
                                      None, stream), "check (full volume)")

@@ -114,6 +114,11 @@ size_t saf_fuse_workspace_bytes(int64_t n_voxels, int32_t feat_dim, int32_t npy,
  * 256^3 -- are reserved only when that form would run for it (feat_dim a multiple of 64 that the row kernel does not
  * take, or SAF_WIN_FORM=bricks); the default 512-channel f32 / bf16 volumes end at 0.55 GB.  0 for a bad descriptor. */
 size_t saf_fuse_workspace_bytes_for(const saf_volume* vol, int32_t npy, int32_t npx);
+/* The same, with room for the frames' depth images (height x width) re-laid-out in 4 x 8-pixel tiles, four windows of 128
+ * frames of them (0.63 GB at 640 x 480): with such a workspace the windowed path's classification gathers depth from the
+ * tiled copies -- half the cache lines per brick and frame --, with a smaller one from the frames'
+ * own row-major images; results are identical either way.  New in round 5; nothing to mirror in the reference. */
+size_t saf_fuse_workspace_bytes_for_frames(const saf_volume* vol, int32_t npy, int32_t npx, int32_t height, int32_t width);
 
 /*
  * Fuse ONE frame into the volume: replaces the body of ClipFusion.integrate after the CLIP call

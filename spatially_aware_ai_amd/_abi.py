@@ -69,6 +69,7 @@ PROTOTYPES = {
     "saf_abi_version": (C.c_int, []),
     "saf_fuse_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "saf_fuse_workspace_bytes_for": (C.c_size_t, [C.POINTER(SafVolume), C.c_int32, C.c_int32]),
+    "saf_fuse_workspace_bytes_for_frames": (C.c_size_t, [C.POINTER(SafVolume), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "saf_fuse_frame": (
         C.c_int,
         [C.POINTER(SafVolume), C.POINTER(SafFrame), _fp, C.c_size_t, _fp, _fp],

@@ -134,11 +134,18 @@ class _FusionVolumeMixin:
             p(b["tsdf"]), p(b["tsdf_weight"]), p(b["weight"]), p(b["rgb"]), p(b["clip_feat"]), p(labels),
         )
 
-    def _get_workspace(self, npy, npx):
+    def _get_workspace(self, npy, npx, hw=None):
+        """``hw`` = (height, width) of the frames: a volume of a million voxels or more also gets room for the windowed path's
+        tiled depth copies (0.63 GB at 640 x 480; half the classification's cache lines); the library falls back to
+        the frames' own images when the room is not there -- results are identical either way."""
         tsdf = self._buffers["tsdf"]
         n = tsdf.numel()
         # for THIS volume (width, dtype, SAF_WIN_FORM): the brick form's 6.5 GB of segment pools only where it would run
-        need = lib().saf_fuse_workspace_bytes_for(C.byref(self._c_volume(for_fuse=True)), int(npy), int(npx))
+        if hw is not None and n >= (1 << 20):
+            need = lib().saf_fuse_workspace_bytes_for_frames(C.byref(self._c_volume(for_fuse=True)), int(npy), int(npx),
+                                                             int(hw[0]), int(hw[1]))
+        else:
+            need = lib().saf_fuse_workspace_bytes_for(C.byref(self._c_volume(for_fuse=True)), int(npy), int(npx))
         ws = self._workspace
         if ws is None or ws.numel() < need or ws.device != tsdf.device:
             ws = torch.empty(need, dtype=torch.uint8, device=tsdf.device)
@@ -434,7 +441,7 @@ class _FusionVolumeMixin:
             )
         arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
         vol = self._c_volume(for_fuse=True)
-        ws = self._get_workspace(npy, npx)
+        ws = self._get_workspace(npy, npx, (int(depth_imgs.shape[1]), int(depth_imgs.shape[2])))
         if self.__dict__.get("_feat_stale") and lib().saf_fuse_path(C.byref(vol), arr, len(arr), ws.numel()) != 1:
             # the per-frame pipeline reads every row it updates: the deferred clear has to happen first
             self._sync_volume()

@@ -1033,6 +1033,14 @@ size_t saf_fuse_workspace_bytes_for(const saf_volume* vol, int32_t npy, int32_t 
   return a > b ? a : b;
 }
 
+size_t saf_fuse_workspace_bytes_for_frames(const saf_volume* vol, int32_t npy, int32_t npx, int32_t height, int32_t width) {
+  KVol kv;
+  if (!vol || npy <= 0 || npx <= 0 || height <= 0 || width <= 0 || make_kvol(vol, &kv)) return 0;
+  const size_t a = ws_layout(kv.N, kv.D, npy * npx).total;
+  const size_t b = window_workspace_bytes(kv.N, kv.D, npy * npx, brick_form_ok(kv), height, width);
+  return a > b ? a : b;
+}
+
 int saf_fuse_frames_profiled(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,
                              size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream) {
   KVol kv;

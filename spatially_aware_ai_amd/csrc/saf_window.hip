@@ -61,6 +61,8 @@ struct ClsArgs {
   float guard_x, guard_y;  // SAF_CLS_GUARD: W * 2^-20, H * 2^-20 (2: always the reference's chain -- images wider than 8192)
   float mid_x, mid_y;      // (W - 1) / 2, (H - 1) / 2
   unsigned long long* verify;  // SAF_CLS_GUARD = 2 (development): disagreements of the two paths are counted here
+  int tiles_x8;     // TILED instantiations: 8 x 4-pixel tiles per image row of the frames' tiled depth copies
+  int depth_bytes;  // bytes of one depth image as the launch reads it (the padded tiled copy, or H * W * 4)
   const float* depth[kClsFrames];
   const float* rgb[kClsFrames];
   const float* pose[kClsFrames];
@@ -209,7 +211,29 @@ struct WinCfg {
 // the frame bitmask of voxel j.  KFU frames at a time: their depth gathers are in flight together.
 // The classification of a lane's 4 consecutive voxels (flat indices nb .. nb+3, world coordinates xw/yw/zw,
 // inb = inside the grid) against the frames of `live` (bit k = frame k of the launch), ascending.
-template <int KFU, bool SUM, bool VERIFY = false>
+// Where pixel (x, y) of a frame's depth image lies (in floats).  TILED: in the window's re-laid-out copy, 4 x 8-pixel tiles of
+// 128 bytes -- a brick's footprint in a frame is a blob of a few dozen pixels across SEVERAL image rows, and row-major every one
+// of those rows is a cache line of its own: 37 lines per (brick, frame) against 17 tiled (a simulation of the benchmark's
+// geometry), i.e. half the classification's requests on the L2 -> L1 path it shares with the row kernel.
+#ifndef SAF_CLS_TILE_WL2
+#define SAF_CLS_TILE_WL2 2  // log2 of the tile's width in pixels; its height is 32 / width (a tile = one 128-byte line).  4 x 8: a brick is 16
+                            // voxels tall and scans are gravity-aligned, so its footprint is taller than wide -- 17 lines per (brick, frame)
+                            // against 19 for 8 x 4, 25 for 16 x 2, 37 row-major; job 73.5 / 74.0 / 74.2 / 75.8 ms (profiles/r05/depth_tiles.txt)
+#endif
+constexpr int kTileWL2 = SAF_CLS_TILE_WL2, kTileHL2 = 5 - SAF_CLS_TILE_WL2;
+template <bool TILED>
+__device__ __forceinline__ int depth_offset(int x, int y, int width, int tiles_x8) {
+  return TILED ? (((y >> kTileHL2) * tiles_x8 + (x >> kTileWL2)) << 5) + ((y & ((1 << kTileHL2) - 1)) << kTileWL2) + (x & ((1 << kTileWL2) - 1))
+               : y * width + x;
+}
+// nearest_index (saf_common.h) with the pixel kept as (x, y): offset in the launch's depth layout, or -1
+template <bool TILED>
+__device__ __forceinline__ int nearest_offset(float gx, float gy, const Cam& c, int width, int tiles_x8) {
+  const float xn = __builtin_rintf(unnormalize(gx, c.sfx)), yn = __builtin_rintf(unnormalize(gy, c.sfy));
+  const bool inb = (xn > -1.0f) && (xn < c.fw) && (yn > -1.0f) && (yn < c.fh);
+  return inb ? depth_offset<TILED>((int)xn, (int)yn, width, tiles_x8) : -1;
+}
+template <int KFU, bool SUM, bool VERIFY = false, bool TILED = false>
 __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa, const Cam* __restrict__ s_cam, uint32_t nb,
                                                 const float (&xw)[4], const float (&yw)[4], const float (&zw)[4],
                                                 const bool (&inb)[4], float rtrunc, bool tsdf_aligned,
@@ -285,16 +309,16 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
         if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
           const Proj p = finish_from_uv(cam, hq.u / hq.z, hq.v / hq.z, hq.z);
           const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
-          const int px = nearest_index(p.gx, p.gy, cam, wa.W);
+          const int px = nearest_offset<TILED>(p.gx, p.gy, cam, wa.W, wa.tiles_x8);
           pixel = in_view ? (px >= 0 ? px : -1) : -2;
         } else {
           const bool in_view = on && inb[j] && fabsf(au - wa.mid_x) < cam.sfx && fabsf(av - wa.mid_y) < cam.sfy && (hq.z > 0.0f);
-          pixel = in_view ? (int)rv * wa.W + (int)ru : -2;
+          pixel = in_view ? depth_offset<TILED>((int)ru, (int)rv, wa.W, wa.tiles_x8) : -2;
         }
         if constexpr (VERIFY || SAF_CLS_GUARD > 1) {  // the self-check (SAF_CLS_VERIFY=1 at run time): both paths, disagreements counted in stats[7]
           const Proj p = finish_from_uv(cam, hq.u / hq.z, hq.v / hq.z, hq.z);
           const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
-          const int px = nearest_index(p.gx, p.gy, cam, wa.W);
+          const int px = nearest_offset<TILED>(p.gx, p.gy, cam, wa.W, wa.tiles_x8);
           const int want = in_view ? (px >= 0 ? px : -1) : -2;
           if (want != pixel && wa.verify) atomicAdd(wa.verify, 1ull);
         }
@@ -304,7 +328,7 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
 #endif
         const Proj p = project(cam, xw[j], yw[j], zw[j]);
         const bool in_view = on && inb[j] && (fabsf(p.gx) <= 1.0f) && (fabsf(p.gy) <= 1.0f) && (p.z > 0.0f);
-        const int px = nearest_index(p.gx, p.gy, cam, wa.W);
+        const int px = nearest_offset<TILED>(p.gx, p.gy, cam, wa.W, wa.tiles_x8);
         pix[u][j] = in_view ? (px >= 0 ? px : -1) : -2;
         pz[u][j] = p.z;
       }
@@ -316,7 +340,7 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
       // a 64-bit address, and "no pixel" (pix < 0: an offset beyond the image) reads 0 by the range check -- zeros padding
 #if SAF_CLS_BUFLD
       const __amdgpu_buffer_rsrc_t dimg = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(wa.depth[fr[u] >= 0 ? fr[u] : 0]), 0, wa.H * wa.W * 4, 0x00020000);
+          const_cast<float*>(wa.depth[fr[u] >= 0 ? fr[u] : 0]), 0, wa.depth_bytes, 0x00020000);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         depth[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dimg, pix[u][j] * 4, 0, 0));
@@ -324,7 +348,7 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = pix[u][j] / wa.W, col = pix[u][j] - row * wa.W;
-        const int twin = pix[u][j] >= 0 ? row * wa.W + (wa.W - 1 - col) : pix[u][j];
+        const int twin = pix[u][j] >= 0 && !TILED ? row * wa.W + (wa.W - 1 - col) : pix[u][j];
         const float d2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dimg, twin * 4, 0, 0));
         asm volatile("" ::"v"(d2));
       }
@@ -418,9 +442,13 @@ constexpr int kMaxDepthTiles = 4096;  // tiles per frame of the depth pyramid's 
 // workspace: the tile maxima of up to kTileWindows windows of a call (a window's slabs, and the same window of later slabs of a
 // slab-by-slab call, reuse them: 128 depth launches of a 512-frame job in eight slabs were 4.7 % of it), each window: 4 KB for
 // the frames' largest / smallest tile maximum, then kWin x kMaxDepthTiles floats
-constexpr int kTileWindows = 8;
-constexpr size_t kTileWinBytes = 4096 + (size_t)kWin * kMaxDepthTiles * sizeof(float);
-constexpr size_t kTileBytes = kTileWindows * kTileWinBytes;
+constexpr int kTileWindows = 4;  // (8 until round 5: with the tiled depth copies a slot is 160 MB at 640 x 480; a 512-frame call has four windows)
+// ... and, when the workspace was sized for the frames' image size (saf_fuse_workspace_bytes_for_frames), the window's depth
+// images re-laid-out in 8 x 4-pixel tiles (depth_px_pad floats per frame; 0: the classification reads the frames' own images)
+constexpr size_t tile_win_bytes(size_t depth_px_pad) { return 4096 + (size_t)kWin * kMaxDepthTiles * sizeof(float) + (size_t)kWin * depth_px_pad * sizeof(float); }
+inline size_t depth_px_padded(int H, int W) {
+  return (size_t)((H + (1 << (5 - SAF_CLS_TILE_WL2)) - 1) >> (5 - SAF_CLS_TILE_WL2)) * (size_t)((W + (1 << SAF_CLS_TILE_WL2) - 1) >> SAF_CLS_TILE_WL2) * 32;
+}
 
 // Largest depth of every frame of a launch, and of every tile of 2^ts_log2 x 2^ts_log2 pixels of it: max(depth, 0), NaN
 // ignored, +inf kept.  dmax_bits[k] (non-negative floats order like their bit patterns: an integer atomicMax) feeds the
@@ -431,10 +459,14 @@ constexpr size_t kTileBytes = kTileWindows * kTileWinBytes;
 // brick nearer than the smallest tile maximum + trunc cannot be occluded anywhere in the frame and skips the tile lookups.
 // A first form added every tile's maximum to the two words of its frame with atomics: 2400 atomics per address and frame
 // serialise in L2 -- 0.3 ms per launch, more than the whole classification of a 128^3 grid.)
-__global__ __launch_bounds__(256) void depth_max_kernel(ClsArgs wa, int ts_log2, int tiles_x, int n_tiles, float* __restrict__ tmax) {
+// `tiled` (optional): the frames' depth images re-laid-out in 8 x 4-pixel tiles (depth_offset<true>), `img_pad` floats per frame --
+// this kernel reads every pixel of the window's depth images once anyway.
+__global__ __launch_bounds__(256) void depth_max_kernel(ClsArgs wa, int ts_log2, int tiles_x, int n_tiles, float* __restrict__ tmax,
+                                                        float* __restrict__ tiled, int tiles_x8, int img_pad) {
   const int lane = threadIdx.x & 63, tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= n_tiles) return;
   const float* __restrict__ d = wa.depth[blockIdx.y];
+  float* __restrict__ td = tiled ? tiled + (size_t)blockIdx.y * img_pad : nullptr;
   const int ts = 1 << ts_log2, tx = tile % tiles_x, ty = tile / tiles_x;
   float m = 0.0f;
   // four loads in flight per lane (a 16 x 16 tile is exactly one round)
@@ -444,7 +476,9 @@ __global__ __launch_bounds__(256) void depth_max_kernel(ClsArgs wa, int ts_log2,
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + 64 * k;
       const int px = (tx << ts_log2) + (i & (ts - 1)), py = (ty << ts_log2) + (i >> ts_log2);
-      x[k] = (i < ts * ts && px < wa.W && py < wa.H) ? d[(size_t)py * wa.W + px] : 0.0f;
+      const bool ok = i < ts * ts && px < wa.W && py < wa.H;
+      x[k] = ok ? d[(size_t)py * wa.W + px] : 0.0f;
+      if (ok && td) td[depth_offset<true>(px, py, wa.W, tiles_x8)] = x[k];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) m = x[k] > m ? x[k] : m;
@@ -481,7 +515,7 @@ __global__ __launch_bounds__(256) void depth_reduce_kernel(const float* __restri
   }
 }
 
-template <bool SUM, bool VERIFY = false>
+template <bool SUM, bool VERIFY = false, bool TILED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE))) void classify_bricks_kernel(
     KVol v, ClsArgs wa, const float* __restrict__ dmax, const float* __restrict__ tmax, int ts_log2, int tiles_x,
     uint32_t* __restrict__ hitmask,
@@ -610,7 +644,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   unsigned long long nt_done = 0, tsdf_rows_done = 0;
   uint32_t mk4[4] = {0u, 0u, 0u, 0u};
   if (live)
-    classify_voxels<SAF_CLS_FU, SUM, VERIFY>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
+    classify_voxels<SAF_CLS_FU, SUM, VERIFY, TILED>(v, wa, s_cam, nb, xw, yw, zw, inb, rtrunc, tsdf_aligned, live, mk4, nt_done, tsdf_rows_done);
   // every voxel of the grid gets its mask word (the row kernel reads them all); 16 bytes at once where the four lie in the grid
   // and the run is aligned (always, when nz is a multiple of 4)
   if (kZS == 1 && inb[3] && (nb & 3u) == 0u) {
@@ -1493,17 +1527,18 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
 // window's frame bitmasks (kMaskWords words per voxel).
 // ---------------------------------------------------------------------------------------------
 struct WinLayout {
-  size_t img_bytes, maps_bytes, mask_bytes, tile_off, cmax_off, total;
+  size_t img_bytes, maps_bytes, mask_bytes, tile_off, tile_win, cmax_off, total;
   uint32_t mask_plane;
 };
-WinLayout win_layout(int64_t n_vox, int D, int P, bool bricks = false) {
+WinLayout win_layout(int64_t n_vox, int D, int P, bool bricks = false, size_t depth_px_pad = 0) {
   WinLayout w;
   w.img_bytes = ((size_t)D * (P + 1) * sizeof(float) + 255) & ~(size_t)255;
   w.maps_bytes = (size_t)kWin * w.img_bytes;
   w.mask_plane = (uint32_t)((n_vox + 63) & ~(int64_t)63);  // words per mask plane (16-byte aligned planes)
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
   w.tile_off = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;  // the classification's depth tile maxima (one launch's)
-  w.cmax_off = w.tile_off + kTileBytes;  // the brick form's channel maxima and camera table
+  w.tile_win = (tile_win_bytes(depth_px_pad) + 255) & ~(size_t)255;
+  w.cmax_off = w.tile_off + kTileWindows * w.tile_win;  // the brick form's channel maxima and camera table
   // the brick form's segment pools (6.5 GB at 256^3) only where that form can run: the row forms end at cmax_off
   w.total = w.cmax_off + (bricks ? brick_aux_bytes_est(n_vox, D) : 0);
   return w;
@@ -1529,7 +1564,9 @@ WinFn pick_win(bool sum, bool bf16, bool of, size_t* lds) {
 // Shapes the windowed path takes; everything else runs the per-frame pipeline.
 }  // namespace
 
-size_t window_workspace_bytes(int64_t n_vox, int D, int P, bool bricks) { return win_layout(n_vox, D, P, bricks).total; }
+size_t window_workspace_bytes(int64_t n_vox, int D, int P, bool bricks, int H, int W) {
+  return win_layout(n_vox, D, P, bricks, H > 0 && W > 0 ? depth_px_padded(H, W) : 0).total;
+}
 
 // SAF_WIN_FORM (read per call): "rows" = the frame-ordered row kernel (bit-identical to fusing frame after frame), "sums" =
 // its order-free form (a row's samples of the window summed in registers, one blend per row: feature values within fp32
@@ -1615,7 +1652,19 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if ((rc = make_kframe(&frames[i], &t))) return rc;
   }
   const int P = kf0.npy * kf0.npx;
-  const WinLayout wl = win_layout(kv.N, kv.D, P);
+  // Two layouts of the workspace: with room for the window's depth images re-laid-out in tiles (a workspace sized by
+  // saf_fuse_workspace_bytes_for_frames) or without (the classification then reads the frames' own row-major images).
+  // SAF_CLS_TILED=0 (read per call): never tiled.
+  const size_t dpx = depth_px_padded(kf0.H, kf0.W);
+  const WinLayout wl_lin = win_layout(kv.N, kv.D, P), wl_til = win_layout(kv.N, kv.D, P, false, dpx);
+  const char* til_env = getenv("SAF_CLS_TILED");
+  bool tiled = !(til_env && til_env[0] == '0') && dpx * sizeof(float) < (size_t)1 << 31 && workspace_bytes >= wl_til.cmax_off;
+  if (tiled && brick_form_ok(kv)) {  // the brick form's pools follow the tile region: both must fit, or neither moves
+    const size_t a_lin = workspace_bytes > wl_lin.cmax_off ? workspace_bytes - wl_lin.cmax_off : 0;
+    const size_t a_til = workspace_bytes - wl_til.cmax_off;
+    if (a_lin > 0 && brick_aux_fits(kv, a_lin) && !(a_til > 0 && brick_aux_fits(kv, a_til))) tiled = false;
+  }
+  const WinLayout wl = tiled ? wl_til : wl_lin;
   const bool sum = kv.accum == SAF_SUM;
   int img_vecs = (int)(wl.img_bytes / sizeof(float4));
   const int prep_blocks = (kv.D * (P + 1) + 255) / 256;
@@ -1734,8 +1783,9 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
     // the window's depth tile maxima: computed when a unit of the window first needs them
     const int widx = f0 / wlen, tslot = widx % kTileWindows;
-    float* dmax_w = reinterpret_cast<float*>(ws + wl.tile_off + (size_t)tslot * kTileWinBytes);  // [kWin] largest, [kWin] smallest
+    float* dmax_w = reinterpret_cast<float*>(ws + wl.tile_off + (size_t)tslot * wl.tile_win);  // [kWin] largest, [kWin] smallest
     float* tmax_w = dmax_w + 1024;
+    float* tdepth_w = tmax_w + (size_t)kWin * kMaxDepthTiles;  // (tiled layout only) the window's depth images in 8 x 4-pixel tiles
     const bool tiles_cached = tile_window[tslot] == widx;
     tile_window[tslot] = widx;
     unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
@@ -1753,6 +1803,8 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       ca.guard_y = kf0.H <= 8192 ? (float)kf0.H * SAF_CLS_GUARD_EPS : 2.0f;
       ca.mid_x = (float)(kf0.W - 1) * 0.5f; ca.mid_y = (float)(kf0.H - 1) * 0.5f;
       ca.verify = stats ? reinterpret_cast<unsigned long long*>(stats) + 7 : nullptr;
+      ca.tiles_x8 = (kf0.W + (1 << SAF_CLS_TILE_WL2) - 1) >> SAF_CLS_TILE_WL2;  // tiles per image row
+      ca.depth_bytes = tiled ? (int)(dpx * sizeof(float)) : kf0.H * kf0.W * 4;
       for (int k = 0; k < kClsFrames; ++k) {
         const saf_frame& fr = frames[f0 + fb + (k < ca.n ? k : 0)];
         ca.depth[k] = fr.depth; ca.rgb[k] = fr.rgb; ca.pose[k] = fr.pose; ca.K[k] = fr.K; ca.label_map[k] = fr.label_map;
@@ -1762,16 +1814,22 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       // the frames' largest depths feed the bricks' frame cull
       float* dmax = dmax_w + fb;
       float* tmax = tmax_w + (size_t)fb * kMaxDepthTiles;
-      if (!tiles_cached) {
-        hipLaunchKernelGGL(depth_max_kernel, dim3((n_tiles + 3) / 4, ca.n), dim3(256), 0, cs, ca, ts_log2, tiles_x, n_tiles, tmax);
+      float* tdepth = tdepth_w + (size_t)fb * dpx;
+      if (!tiles_cached) {  // (reads the frames' own images; writes the tile maxima and, in the tiled layout, the re-laid-out copies)
+        hipLaunchKernelGGL(depth_max_kernel, dim3((n_tiles + 3) / 4, ca.n), dim3(256), 0, cs, ca, ts_log2, tiles_x, n_tiles, tmax,
+                           tiled ? tdepth : nullptr, ca.tiles_x8, (int)dpx);
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, cs, tmax, n_tiles, dmax);
       }
+      if (tiled)
+        for (int k = 0; k < kClsFrames; ++k) ca.depth[k] = tdepth + (size_t)(k < ca.n ? k : 0) * dpx;
       ScopedPair t(prof, 1, f0 + fb, cs);
       // SAF_CLS_VERIFY=1 (read per call): the self-checking classification -- every voxel slot computes the reference's pixel chain
       // as well and counts disagreements with the guarded path in stats[7] (tests; tools/cls_guard_verify.py)
       const bool verify = getenv("SAF_CLS_VERIFY") && getenv("SAF_CLS_VERIFY")[0] == '1' && stats;
-      auto kfn = verify ? (sum ? classify_bricks_kernel<true, true> : classify_bricks_kernel<false, true>)
-                        : (sum ? classify_bricks_kernel<true, false> : classify_bricks_kernel<false, false>);
+      auto kfn = tiled ? (verify ? (sum ? classify_bricks_kernel<true, true, true> : classify_bricks_kernel<false, true, true>)
+                                 : (sum ? classify_bricks_kernel<true, false, true> : classify_bricks_kernel<false, false, true>))
+                       : (verify ? (sum ? classify_bricks_kernel<true, true, false> : classify_bricks_kernel<false, true, false>)
+                                 : (sum ? classify_bricks_kernel<true, false, false> : classify_bricks_kernel<false, false, false>));
       hipLaunchKernelGGL(kfn, dim3(g.cls_wgs), dim3(256), 0, cs, u.kv, ca, dmax, tmax, ts_log2, tiles_x, plane,
                          reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
     }
