@@ -61,7 +61,7 @@ struct ClsArgs {
   float guard_x, guard_y;  // SAF_CLS_GUARD: W * 2^-20, H * 2^-20 (2: always the reference's chain -- images wider than 8192)
   float mid_x, mid_y;      // (W - 1) / 2, (H - 1) / 2
   unsigned long long* verify;  // SAF_CLS_GUARD = 2 (development): disagreements of the two paths are counted here
-  int tiles_x8;     // TILED instantiations: 8 x 4-pixel tiles per image row of the frames' tiled depth copies
+  int tiles_x8;     // TILED instantiations: tiles per image row of the frames' tiled depth copies
   int depth_bytes;  // bytes of one depth image as the launch reads it (the padded tiled copy, or H * W * 4)
   const float* depth[kClsFrames];
   const float* rgb[kClsFrames];
@@ -444,7 +444,7 @@ constexpr int kMaxDepthTiles = 4096;  // tiles per frame of the depth pyramid's 
 // the frames' largest / smallest tile maximum, then kWin x kMaxDepthTiles floats
 constexpr int kTileWindows = 4;  // (8 until round 5: with the tiled depth copies a slot is 160 MB at 640 x 480; a 512-frame call has four windows)
 // ... and, when the workspace was sized for the frames' image size (saf_fuse_workspace_bytes_for_frames), the window's depth
-// images re-laid-out in 8 x 4-pixel tiles (depth_px_pad floats per frame; 0: the classification reads the frames' own images)
+// images re-laid-out in tiles of one cache line (depth_px_pad floats per frame; 0: the classification reads the frames' own images)
 constexpr size_t tile_win_bytes(size_t depth_px_pad) { return 4096 + (size_t)kWin * kMaxDepthTiles * sizeof(float) + (size_t)kWin * depth_px_pad * sizeof(float); }
 inline size_t depth_px_padded(int H, int W) {
   return (size_t)((H + (1 << (5 - SAF_CLS_TILE_WL2)) - 1) >> (5 - SAF_CLS_TILE_WL2)) * (size_t)((W + (1 << SAF_CLS_TILE_WL2) - 1) >> SAF_CLS_TILE_WL2) * 32;
@@ -459,7 +459,7 @@ inline size_t depth_px_padded(int H, int W) {
 // brick nearer than the smallest tile maximum + trunc cannot be occluded anywhere in the frame and skips the tile lookups.
 // A first form added every tile's maximum to the two words of its frame with atomics: 2400 atomics per address and frame
 // serialise in L2 -- 0.3 ms per launch, more than the whole classification of a 128^3 grid.)
-// `tiled` (optional): the frames' depth images re-laid-out in 8 x 4-pixel tiles (depth_offset<true>), `img_pad` floats per frame --
+// `tiled` (optional): the frames' depth images re-laid-out in tiles (depth_offset<true>), `img_pad` floats per frame --
 // this kernel reads every pixel of the window's depth images once anyway.
 __global__ __launch_bounds__(256) void depth_max_kernel(ClsArgs wa, int ts_log2, int tiles_x, int n_tiles, float* __restrict__ tmax,
                                                         float* __restrict__ tiled, int tiles_x8, int img_pad) {
@@ -1785,7 +1785,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     const int widx = f0 / wlen, tslot = widx % kTileWindows;
     float* dmax_w = reinterpret_cast<float*>(ws + wl.tile_off + (size_t)tslot * wl.tile_win);  // [kWin] largest, [kWin] smallest
     float* tmax_w = dmax_w + 1024;
-    float* tdepth_w = tmax_w + (size_t)kWin * kMaxDepthTiles;  // (tiled layout only) the window's depth images in 8 x 4-pixel tiles
+    float* tdepth_w = tmax_w + (size_t)kWin * kMaxDepthTiles;  // (tiled layout only) the window's depth images in tiles
     const bool tiles_cached = tile_window[tslot] == widx;
     tile_window[tslot] = widx;
     unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
