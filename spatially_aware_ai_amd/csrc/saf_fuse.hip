@@ -848,7 +848,7 @@ constexpr int kEvRing = 4;
 struct PipeRes {
   int device;
   hipStream_t aux;
-  hipEvent_t fork, join, fused[kEvRing];
+  hipEvent_t fork, join, fused[kEvRing], tiles;
   PipeRes* next;
 };
 std::mutex g_pipe_mu;
@@ -872,7 +872,8 @@ PipeRes* pipe_acquire() {
   r->next = nullptr;
   bool ok = hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&r->join, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&r->join, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&r->tiles, hipEventDisableTiming) == hipSuccess;
   for (int b = 0; ok && b < kEvRing; ++b) ok = hipEventCreateWithFlags(&r->fused[b], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     delete r;  // (handles created so far are leaked: this only happens when the runtime is out of resources)
@@ -951,6 +952,7 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
     WinOverlap ov;
     ov.aux = pr->aux; ov.fork = pr->fork; ov.join = pr->join;
     ov.cls_done[0] = pr->fused[0]; ov.cls_done[1] = pr->fused[1]; ov.fuse_done[0] = pr->fused[2]; ov.fuse_done[1] = pr->fused[3];
+    ov.tiles = pr->tiles;
     rc = fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, &ov, slabs);
     pipe_release(pr);
     return rc;

@@ -294,6 +294,7 @@ bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
 struct WinOverlap {
   hipStream_t aux;
   hipEvent_t fork, join, cls_done[2], fuse_done[2];
+  hipEvent_t tiles;  // (may be NULL) the later windows' depth tiles, computed on the caller's stream ahead of their classification
 };
 // saf_fuse_frames_slabs: every frame into x-planes [x0[k], x0[k] + nx[k]) for k = 0 .. n - 1 in turn; done[k] (may be NULL):
 // a hipEvent_t recorded on the caller's stream behind slab k's last row kernel.

@@ -1775,6 +1775,34 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       fprintf(stderr, "[win trace] %8.3f ms  %s %d\n",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), what, w);
   };
+  // The depth tile maxima (and tiled copies) of one window: depth_max_kernel + depth_reduce_kernel per 32 frames, on stream `st`.
+  auto depth_tiles = [&](int widx, int f0, int F, hipStream_t st) {
+    float* dmax_w = reinterpret_cast<float*>(ws + wl.tile_off + (size_t)(widx % kTileWindows) * wl.tile_win);
+    float* tmax_w = dmax_w + 1024;
+    float* tdepth_w = tmax_w + (size_t)kWin * kMaxDepthTiles;
+    for (int fb = 0; fb < F; fb += kClsFrames) {
+      ClsArgs ca;
+      ca.n = fb + kClsFrames < F ? kClsFrames : F - fb;
+      ca.H = kf0.H; ca.W = kf0.W;
+      for (int k = 0; k < kClsFrames; ++k) ca.depth[k] = frames[f0 + fb + (k < ca.n ? k : 0)].depth;
+      float* tmax = tmax_w + (size_t)fb * kMaxDepthTiles;
+      hipLaunchKernelGGL(depth_max_kernel, dim3((n_tiles + 3) / 4, ca.n), dim3(256), 0, st, ca, ts_log2, tiles_x, n_tiles, tmax,
+                         tiled ? tdepth_w + (size_t)fb * dpx : nullptr, (kf0.W + (1 << SAF_CLS_TILE_WL2) - 1) >> SAF_CLS_TILE_WL2, (int)dpx);
+      hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, st, tmax, n_tiles, dmax_w + fb);
+    }
+  };
+  // The later windows' tiles AHEAD of time, on the caller's stream: it is idle until the first window has been classified, and
+  // every such pair of small launches inside the classification chain (16 per 512-frame job, ~70 us each beside a row kernel)
+  // lengthens the chain that a job's time follows.  Window 0's stay in front of its classification.
+  const bool pre_tiles = ov && ov->tiles && !(slabs && slabs->n > 0) && n_units == n_win && n_win >= 2 &&
+                         !(getenv("SAF_WIN_PRETILES") && getenv("SAF_WIN_PRETILES")[0] == '0');
+  if (pre_tiles) {
+    for (int w = 1; w < n_win && w < kTileWindows; ++w) {
+      depth_tiles(w, w * wlen, win_frames(w), s);
+      tile_window[w % kTileWindows] = w;
+    }
+    if (hipEventRecord(ov->tiles, s) != hipSuccess) return fail(SAF_E_HIP, "hipEventRecord(tiles)");
+  }
   auto classify = [&](int ui) -> int {
     const WinUnit& u = units[ui];
     const Geom g = geom(u.kv);
@@ -1792,6 +1820,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     WinTable* tab = reinterpret_cast<WinTable*>(hdr + kTableOff);
     mark("classify: begin", ui);
     if (ov && ui >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
+    if (pre_tiles && ui == 1 && hipStreamWaitEvent(cs, ov->tiles, 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent(tiles)");
     // header: unit counters, dmax, the classification launches' counter shards, the frame table
     if (hipMemsetAsync(hdr, 0, kHdrBytes, cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
     mark("classify: header memset queued", ui);
@@ -1815,11 +1844,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       float* dmax = dmax_w + fb;
       float* tmax = tmax_w + (size_t)fb * kMaxDepthTiles;
       float* tdepth = tdepth_w + (size_t)fb * dpx;
-      if (!tiles_cached) {  // (reads the frames' own images; writes the tile maxima and, in the tiled layout, the re-laid-out copies)
-        hipLaunchKernelGGL(depth_max_kernel, dim3((n_tiles + 3) / 4, ca.n), dim3(256), 0, cs, ca, ts_log2, tiles_x, n_tiles, tmax,
-                           tiled ? tdepth : nullptr, ca.tiles_x8, (int)dpx);
-        hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, cs, tmax, n_tiles, dmax);
-      }
+      if (!tiles_cached && fb == 0) depth_tiles(widx, f0, F, cs);  // (reads the frames' own images; writes the tile maxima and, in the tiled layout, the copies)
       if (tiled)
         for (int k = 0; k < kClsFrames; ++k) ca.depth[k] = tdepth + (size_t)(k < ca.n ? k : 0) * dpx;
       ScopedPair t(prof, 1, f0 + fb, cs);

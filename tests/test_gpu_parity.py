@@ -951,7 +951,7 @@ def test_full_size_oracle_parity_config3_256_bf16_labels(oracle, monkeypatch):
         else:
             scale = want.float().abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
             worst = float(((got.float() - want.float()).abs() / scale).max())
-            assert worst <= 8 * 2.0 ** -8, f"order-free bf16 rows: {worst:.3g} of the row's largest magnitude from the oracle's bf16 mode"
+            assert worst <= 4 * 2.0 ** -8, f"order-free bf16 rows: {worst:.3g} of the row's largest magnitude from the oracle's bf16 mode"
         _close(fusion.rgb[pick.cuda()], vol.rgb[pick], "rgb rows")
         assert torch.equal(fusion.labels_one_hot[lab_pick.cuda()].cpu(), vol.labels_one_hot[lab_pick]), "label histogram rows differ"
         assert int(fusion.labels_one_hot.sum(dtype=torch.int64)) == int(vol.labels_one_hot.sum(dtype=torch.int64)) == st["valid"]

@@ -48,10 +48,10 @@ def test_sums_form_against_the_sequential_path_and_the_oracle(oracle, monkeypatc
     for name in EXACT + (("labels_one_hot",) if seem else ()):
         assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs from the sequential path"
     # bf16: the sequential path (and the oracle's bf16 mode) round to bf16 after EVERY hit, this form once per window -- it is
-    # compared with the fp32 oracle within a handful of bf16 roundings (2^-8 each); per-hit rounding is no closer.  (The bf16
+    # compared with the fp32 oracle within three bf16 roundings (2^-8 each); per-hit rounding is no closer.  (The bf16
     # volume's order-free form also reads its taps from bf16 map images: one more rounding of that size per tap, averaged
     # over the row's hits.)
-    tol = 8 * 2.0 ** -8 if fdt == torch.bfloat16 else 1e-4
+    tol = 3 * 2.0 ** -8 if fdt == torch.bfloat16 else 1e-4  # (measured: 1.7-2.2 x 2^-8 on the three bf16 cases, tools/probe_bf16_tol.py)
     vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, dim, 143 if seem else 0, accum)
     cat = lambda k: torch.cat([f[k] for f in frames])
     vol.integrate(cat("depth"), cat("rgb"), cat("pose"), cat("K"), cat("feat"),
