@@ -1833,7 +1833,11 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       ca.mid_x = (float)(kf0.W - 1) * 0.5f; ca.mid_y = (float)(kf0.H - 1) * 0.5f;
       ca.verify = stats ? reinterpret_cast<unsigned long long*>(stats) + 7 : nullptr;
       ca.tiles_x8 = (kf0.W + (1 << SAF_CLS_TILE_WL2) - 1) >> SAF_CLS_TILE_WL2;  // tiles per image row
-      ca.depth_bytes = tiled ? (int)(dpx * sizeof(float)) : kf0.H * kf0.W * 4;
+      // (unit 0 has the chip to itself -- everything the caller queued before is done, nothing of this call runs yet --, where the
+      //  classification is bound by its vector instructions and the tile offset costs 5 % (0.92 vs 0.97 ms per launch): it reads the
+      //  frames' own images; the tiled copies pay where the address path is shared, i.e. for every later unit)
+      const bool use_tiled = tiled && ui > 0;
+      ca.depth_bytes = use_tiled ? (int)(dpx * sizeof(float)) : kf0.H * kf0.W * 4;
       for (int k = 0; k < kClsFrames; ++k) {
         const saf_frame& fr = frames[f0 + fb + (k < ca.n ? k : 0)];
         ca.depth[k] = fr.depth; ca.rgb[k] = fr.rgb; ca.pose[k] = fr.pose; ca.K[k] = fr.K; ca.label_map[k] = fr.label_map;
@@ -1845,13 +1849,13 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       float* tmax = tmax_w + (size_t)fb * kMaxDepthTiles;
       float* tdepth = tdepth_w + (size_t)fb * dpx;
       if (!tiles_cached && fb == 0) depth_tiles(widx, f0, F, cs);  // (reads the frames' own images; writes the tile maxima and, in the tiled layout, the copies)
-      if (tiled)
+      if (use_tiled)
         for (int k = 0; k < kClsFrames; ++k) ca.depth[k] = tdepth + (size_t)(k < ca.n ? k : 0) * dpx;
       ScopedPair t(prof, 1, f0 + fb, cs);
       // SAF_CLS_VERIFY=1 (read per call): the self-checking classification -- every voxel slot computes the reference's pixel chain
       // as well and counts disagreements with the guarded path in stats[7] (tests; tools/cls_guard_verify.py)
       const bool verify = getenv("SAF_CLS_VERIFY") && getenv("SAF_CLS_VERIFY")[0] == '1' && stats;
-      auto kfn = tiled ? (verify ? (sum ? classify_bricks_kernel<true, true, true> : classify_bricks_kernel<false, true, true>)
+      auto kfn = use_tiled ? (verify ? (sum ? classify_bricks_kernel<true, true, true> : classify_bricks_kernel<false, true, true>)
                                  : (sum ? classify_bricks_kernel<true, false, true> : classify_bricks_kernel<false, false, true>))
                        : (verify ? (sum ? classify_bricks_kernel<true, true, false> : classify_bricks_kernel<false, true, false>)
                                  : (sum ? classify_bricks_kernel<true, false, false> : classify_bricks_kernel<false, false, false>));

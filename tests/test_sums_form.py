@@ -181,7 +181,7 @@ def test_classification_from_tiled_depth_copies_is_bit_identical(monkeypatch, w,
     lines per brick and frame -- and must decide exactly what it decides from the frames' own images (SAF_CLS_TILED=0), for
     image sizes that are no multiple of the tile (a ragged last tile column and row), missing depth included; and its
     self-check against the reference's pixel chain stays at zero."""
-    nvox, dim, n = (104, 100, 104), 256, 40
+    nvox, dim, n = (104, 100, 104), 256, 150  # two windows: the first unit of a call, alone on the chip, reads the frames' own images
     grid = syn.make_grid(nvox, side=2.56)
     frames = _frames(6000 + w, n, dim, kind, w=w, h=h)
     monkeypatch.setenv("SAF_CLS_VERIFY", "1")
