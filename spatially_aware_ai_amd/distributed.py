@@ -173,8 +173,8 @@ def sparse_threshold(sparse=None):
 
 
 def _touched_rows(weight_total, plan, world):
-    """From the all-reduced weight of the rows the plan covers: (idx, offs) -- idx = the touched rows (global indices,
-    ascending, on the device), offs[j][k] = position in idx of the first touched row of part k of piece j (k = world: the
+    """From the all-reduced weight of the rows the plan covers: (idx_of, offs) -- idx_of() = the touched rows (global indices,
+    ascending, on the device), offs[j][k] = position in that list of the first touched row of part k of piece j (k = world: the
     piece's end, the tail rows included in the last part's count are NOT -- they are reduced on their own).  One host sync."""
     first0 = plan[0][0]
     n_rows = plan[-1][0] + plan[-1][1] - first0
@@ -184,9 +184,9 @@ def _touched_rows(weight_total, plan, world):
         bounds += [first - first0 + k * c for k in range(world + 1)]
     cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=touched.device), torch.cumsum(touched, 0, dtype=torch.int64)])
     pre = cs[torch.tensor(bounds, dtype=torch.int64, device=touched.device)].cpu().tolist()
-    idx = torch.nonzero(touched).squeeze(1) + first0
     offs = [pre[j * (world + 1) : (j + 1) * (world + 1)] for j in range(len(plan))]
-    return idx, offs
+    # (the index list -- 8 bytes per touched row -- only when some piece will travel packed: `idx` is a thunk)
+    return (lambda: torch.nonzero(touched).squeeze(1) + first0), offs
 
 
 def _reduce_scatter_packed(t, idx, offs_j, group, rank, world):
@@ -216,10 +216,13 @@ def _merge_rows(tensors, plan, group, rank, world, sparse=None):
         first0 = plan[0][0]
         n_rows = plan[-1][0] + plan[-1][1] - first0
         _all_reduce(w[first0 : first0 + n_rows], group)  # the job's weight on EVERY rank: also the union of the touched rows
-        idx, offs = _touched_rows(w, plan, world)
+        idx_of, offs = _touched_rows(w, plan, world)
+        idx = None
         for j, (first, rows, c) in enumerate(plan):
             frac = (offs[j][world] - offs[j][0]) / max(1, world * c)
             go_packed = c > 0 and frac <= thr
+            if go_packed and idx is None:
+                idx = idx_of()
             packed += 1 if go_packed else 0
             for name, t in tensors.items():
                 if name == "weight":
@@ -230,7 +233,7 @@ def _merge_rows(tensors, plan, group, rank, world, sparse=None):
                         dist.reduce(t[first + world * c : first + rows], dst=_global_rank(group, world - 1), op=dist.ReduceOp.SUM, group=group)
                 else:
                     _reduce_scatter_striped(t, [(first, rows, c)], group, rank, world)
-        last_merge.update(packed=packed, touched_rows=int(idx.numel()))
+        last_merge.update(packed=packed, touched_rows=int(sum(o[world] - o[0] for o in offs)))
         return packed
     for t in tensors.values():
         _reduce_scatter_striped(t, plan, group, rank, world)
