@@ -212,7 +212,7 @@ def discover_objects(labels_grid, class_names, class_colors=None, null_class=133
         unique_objects[obj_id] = {
             "class_id": class_id,
             "class_label": class_label,
-            "voxels": [tuple(int(c) for c in v) for v in coords[offs[k]:offs[k + 1]]],
+            "voxels": list(map(tuple, coords[offs[k]:offs[k + 1]].tolist())),  # (tuples of Python ints, as flood_fill_3d lists them)
             "object_index": object_index,
             "gt_label": obj_id,
             "user_modified": user_modified,
