@@ -252,12 +252,18 @@ __global__ __launch_bounds__(256) void stage_frame_kernel(StageArgs a) {
 // is recycled for a new scan need not be cleared up front -- the windowed fuse path never reads such rows -- as long as
 // the rows that are STILL unwritten are zeroed before anyone else looks: this kernel.  A wave checks 64 weights at a
 // time and writes zeros only where needed (after a 512-frame scan: almost nowhere).
+// Round 5: on a coherent scene most rows ARE unwritten (83 % at 256^3: 28 GB of zeros, a fifth of the job).  The zeros leave as
+// ONE 16-byte store per lane -- a native vector type: HIP's `uint4` (a struct around a union) assigned from make_uint4 compiled
+// to narrower stores and the kernel wrote at half the rate of a memset (3.4 against 6.8 TB/s; now 5.4: tools/probe_clear_rate.py;
+// rows per wave and iteration, nontemporal stores and the grid size were swept and change nothing).
 template <int ESZ>
 __global__ __launch_bounds__(256) void clear_unwritten_kernel(void* __restrict__ feat, const int* __restrict__ weight, int64_t first,
                                                               int64_t count, int row_bytes) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  typedef unsigned int clr_v4u __attribute__((ext_vector_type(4)));
+  const clr_v4u z4 = {0u, 0u, 0u, 0u};
   for (int64_t i0 = wave * 64; i0 < count; i0 += n_waves * 64) {
     const int64_t n = first + i0 + lane;
     unsigned long long zero = __ballot(i0 + lane < count && weight[n] == 0);
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void clear_unwritten_kernel(void* __restrict__
       zero &= zero - 1ull;
       unsigned char* row = static_cast<unsigned char*>(feat) + (first + i0 + l) * (int64_t)row_bytes;
       if ((row_bytes & 15) == 0) {
-        for (int o = lane * 16; o < row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(row + o) = make_uint4(0u, 0u, 0u, 0u);
+        for (int o = lane * 16; o < row_bytes; o += 64 * 16) *reinterpret_cast<clr_v4u*>(row + o) = z4;
       } else {
         for (int o = lane * ESZ; o < row_bytes; o += 64 * ESZ) {
           if (ESZ == 4) *reinterpret_cast<uint32_t*>(row + o) = 0u;
