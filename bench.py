@@ -305,8 +305,13 @@ def main():
 
     def fuse_into(fz, frame_arr, n_frames, profiler):
         vol = fz._c_volume(for_fuse=True)  # (neither the frame queue nor the deferred clear of reset() is resolved here)
-        if fz._feat_stale and L.saf_fuse_path(C.byref(vol), frame_arr, n_frames, ws.numel()) != 1:
-            fz.flush()  # a short call takes the per-frame pipeline, which reads the rows it updates: clear first
+        if fz._feat_stale:
+            # the volume was reset() without clearing its feature rows: the rows still unwritten after these frames are zeroed
+            # inside the call (beside the last window's row kernel), as ClipFusion._fuse_now does
+            rc = L.saf_fuse_frames_recycled(C.byref(vol), frame_arr, n_frames, ws.data_ptr(), ws.numel(), stats_ptr, profiler, stream)
+            check(rc, "saf_fuse_frames_recycled")
+            fz.__dict__["_feat_stale"] = False
+            return
         rc = L.saf_fuse_frames_profiled(C.byref(vol), frame_arr, n_frames, ws.data_ptr(), ws.numel(),
                                         stats_ptr, profiler, stream)
         check(rc, "saf_fuse_frames_profiled")
@@ -350,8 +355,8 @@ def main():
             if merge_done[slot] is not None:  # this volume's previous merge must have drained
                 main_stream.wait_event(merge_done[slot])
             # reset(): the small buffers are zeroed, the 34 GB of feature rows are NOT -- the windowed path never reads a
-            # row whose weight is 0 -- and the rows still unwritten at the end of the job are zeroed below (flush / merge),
-            # inside the timed region: every buffer ends bit-identical to an up-front clear
+            # row whose weight is 0 -- and the rows still unwritten at the end of the job are zeroed by the fusing call itself
+            # (saf_fuse_frames_recycled), inside the timed region: every buffer ends bit-identical to an up-front clear
             fz.reset(accum_mode=_abi.SAF_SUM if world > 1 else _abi.SAF_RUNNING_MEAN)
             fuse_into(fz, frames, a.frames, profiler)
             if world == 1:
@@ -973,8 +978,10 @@ def side_workloads(a, device, L, frames_A, npy, npx):
         def job(p):
             fz.reset()
             vol = fz._c_volume(for_fuse=True)
-            check(L.saf_fuse_frames_profiled(C.byref(vol), arr, n_frames, ws.data_ptr(), ws.numel(),
+            # (reset() left the feature rows alone: the call zeroes the ones still unwritten, as ClipFusion._fuse_now does)
+            check(L.saf_fuse_frames_recycled(C.byref(vol), arr, n_frames, ws.data_ptr(), ws.numel(),
                                              fz._buffers["fuse_stats"].data_ptr(), p, stream), "side workload")
+            fz.__dict__["_feat_stale"] = False
             fz.flush()
 
         job(None)

@@ -211,6 +211,15 @@ int saf_fuse_frames_profiled(const saf_volume* vol, const saf_frame* frames, int
                              void* workspace, size_t workspace_bytes, uint64_t* stats,
                              saf_profiler* profiler, void* stream);
 
+/* saf_fuse_frames_profiled into a recycled volume (see saf_clear_unwritten_rows), then saf_clear_unwritten_rows over all of
+ * it, as ONE call: when it has completed (stream order) every voxel whose weight is 0 has a zero row, whatever the rows held before.  The reference builds a
+ * new, zeroed module per scan (clip_seem_fusion.py:291-302); this is that scan's fusion with the 4*D*N-byte clear folded in: in
+ * the windowed path the zeros are written beside the last window's row kernel (which leaves most of the HBM bandwidth unused)
+ * and only where no frame of the call wrote; any other path zeroes the rows first.  profiler may be NULL.  n_frames == 0: the clear
+ * alone. */
+int saf_fuse_frames_recycled(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,
+                             size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream);
+
 /* saf_fuse_frames slab by slab (new capability: the frame-sharded multi-GPU job with its merge pipelined behind the fusion,
  * SURVEY 8e): EVERY frame is fused into x-planes [slab_x0[k], slab_x0[k] + slab_nx[k]) of the volume for k = 0 .. n_slabs - 1
  * in turn -- a slab of x-planes is a contiguous range of the flat voxel index and every decision is that of the full volume's

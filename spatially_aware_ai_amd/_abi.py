@@ -96,6 +96,10 @@ PROTOTYPES = {
         C.c_int,
         [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp, _fp, _fp],
     ),
+    "saf_fuse_frames_recycled": (
+        C.c_int,
+        [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp, _fp, _fp],
+    ),
     "saf_backproject_lattice": (
         C.c_int,
         [_fp, C.c_int32, C.c_int32, _fp, _fp, _fp, C.c_int32, _fp, C.c_int32, C.c_float, _fp, _fp, _fp],

@@ -442,16 +442,24 @@ class _FusionVolumeMixin:
         arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
         vol = self._c_volume(for_fuse=True)
         ws = self._get_workspace(npy, npx, (int(depth_imgs.shape[1]), int(depth_imgs.shape[2])))
-        if self.__dict__.get("_feat_stale") and lib().saf_fuse_path(C.byref(vol), arr, len(arr), ws.numel()) != 1:
-            # the per-frame pipeline reads every row it updates: the deferred clear has to happen first
-            self._sync_volume()
+        # after a lazy reset() the feature rows still hold the previous scan: saf_fuse_frames_recycled fuses and leaves every row
+        # of a voxel that is still unwritten zero (beside the last window's row kernel; before the per-frame pipeline, which
+        # reads the rows it updates)
+        stale = bool(self.__dict__.get("_feat_stale"))
         # the module's device, not the caller's current one, owns the launch (and its current stream)
         dev = self._buffers["tsdf"].device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)
-            rc = lib().saf_fuse_frames(
-                C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), stream.cuda_stream
-            )
+            if stale:
+                rc = lib().saf_fuse_frames_recycled(
+                    C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), None, stream.cuda_stream
+                )
+            else:
+                rc = lib().saf_fuse_frames(
+                    C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), stream.cuda_stream
+                )
+            if stale and rc == 0:
+                self.__dict__["_feat_stale"] = False
             # SAF_E_INVALID / _WORKSPACE / _UNSUPPORTED come from the checks at the entry (every frame descriptor is validated
             # before the first launch); a HIP error may have left some windows fused (see _flush_pending)
             self.__dict__["_fuse_launched"] = rc == 0 or rc == _abi.SAF_E_HIP

@@ -939,21 +939,26 @@ int poll_latch() {
 // Everything is ordered after what the caller already queued on `s` (fork event), and complete,
 // as far as `s` is concerned, when the last fuse kernel is (it has waited for every sweep).
 int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
-              uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinSlabs* slabs = nullptr) {
+              uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinSlabs* slabs = nullptr, bool recycled = false) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
+  if (recycled && !window_ok(kv, frames, n_frames, workspace_bytes)) {
+    // the per-frame pipeline reads every row it updates: the rows of weight-0 voxels are zeroed first
+    if ((rc = launch_clear_unwritten(kv, nullptr, 0, 0, s))) return rc;
+    recycled = false;
+  }
   if (window_ok(kv, frames, n_frames, workspace_bytes)) {
     // SAF_WIN_OVERLAP=0: every kernel of the windowed path on the caller's stream (read per call: same-process A/Bs)
     // (a call of one window overlaps too: its first window is classified slab by slab beside its own row kernels)
     const char* ov_env = getenv("SAF_WIN_OVERLAP");
     PipeRes* pr = (ov_env && ov_env[0] == '0') ? nullptr : pipe_acquire();
-    if (!pr) return fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, nullptr, slabs);
+    if (!pr) return fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, nullptr, slabs, recycled);
     WinOverlap ov;
     ov.aux = pr->aux; ov.fork = pr->fork; ov.join = pr->join;
     ov.cls_done[0] = pr->fused[0]; ov.cls_done[1] = pr->fused[1]; ov.fuse_done[0] = pr->fused[2]; ov.fuse_done[1] = pr->fused[3];
     ov.tiles = pr->tiles;
-    rc = fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, &ov, slabs);
+    rc = fuse_many_windowed(kv, frames, n_frames, workspace, workspace_bytes, stats, prof, s, &ov, slabs, recycled);
     pipe_release(pr);
     return rc;
   }
@@ -1053,6 +1058,18 @@ int saf_fuse_frames_profiled(const saf_volume* vol, const saf_frame* frames, int
   if ((rc = poll_latch())) return rc;
   ensure_latch();
   return fuse_many(kv, frames, n_frames, workspace, workspace_bytes, stats, profiler, static_cast<hipStream_t>(stream));
+}
+
+int saf_fuse_frames_recycled(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,
+                             size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream) {
+  KVol kv;
+  int rc = make_kvol(vol, &kv);
+  if (rc) return rc;
+  if (n_frames < 0 || (n_frames > 0 && !frames)) return fail(SAF_E_INVALID, "bad frame array");
+  if ((rc = poll_latch())) return rc;
+  ensure_latch();
+  if (n_frames == 0) return launch_clear_unwritten(kv, nullptr, 0, 0, static_cast<hipStream_t>(stream));
+  return fuse_many(kv, frames, n_frames, workspace, workspace_bytes, stats, profiler, static_cast<hipStream_t>(stream), nullptr, true);
 }
 
 int saf_fuse_frames_slabs(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, const int32_t* slab_x0,

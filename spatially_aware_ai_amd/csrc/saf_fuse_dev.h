@@ -303,8 +303,20 @@ struct WinSlabs {
   const int32_t *x0, *nx;
   void* const* done;
 };
+// recycled: the volume's feature rows were not cleared when its scalars were (saf_fuse_frames_recycled) -- the rows of voxels
+// whose weight is still 0 when the call is over are zeroed by it, beside the last window's row kernel where the schedule allows.
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
-                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs = nullptr);
+                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs = nullptr,
+                       bool recycled = false);
+// saf_misc.hip (clear_rows): zero the feature rows of the voxels n in [0, kv.N) with weight[n] == 0 and -- masks may be NULL -- no
+// bit set in masks[p * mask_plane + n] for p < n_planes (the hit masks of a window whose row kernel may be running: it writes exactly
+// the rows with a bit set, this kernel only the others).
+int clear_rows(void* feat, const int* weight, int64_t first, int64_t n_rows, int esz, int row_bytes, const uint32_t* masks,
+               size_t mask_plane, int n_planes, hipStream_t s);
+inline int launch_clear_unwritten(const KVol& kv, const uint32_t* masks, size_t mask_plane, int n_planes, hipStream_t s) {
+  const int esz = kv.bf16 ? 2 : 4;
+  return clear_rows(kv.feat, kv.weight, 0, (int64_t)kv.N, esz, kv.D * esz, masks, mask_plane, n_planes, s);
+}
 KVol slab_kvol(const KVol& kv, int x0, int nx);
 
 }  // namespace saf

@@ -256,9 +256,12 @@ __global__ __launch_bounds__(256) void stage_frame_kernel(StageArgs a) {
 // ONE 16-byte store per lane -- a native vector type: HIP's `uint4` (a struct around a union) assigned from make_uint4 compiled
 // to narrower stores and the kernel wrote at half the rate of a memset (3.4 against 6.8 TB/s; now 5.4: tools/probe_clear_rate.py;
 // rows per wave and iteration, nontemporal stores and the grid size were swept and change nothing).
+// `masks` (may be NULL): the hit masks of a window whose row kernel may be running beside this kernel -- n_planes planes of one
+// word per voxel; a voxel with a bit set is that kernel's to write (it does not read the old row of a weight-0 voxel either).
 template <int ESZ>
 __global__ __launch_bounds__(256) void clear_unwritten_kernel(void* __restrict__ feat, const int* __restrict__ weight, int64_t first,
-                                                              int64_t count, int row_bytes) {
+                                                              int64_t count, int row_bytes, const uint32_t* __restrict__ masks,
+                                                              size_t mask_plane, int n_planes) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -266,7 +269,13 @@ __global__ __launch_bounds__(256) void clear_unwritten_kernel(void* __restrict__
   const clr_v4u z4 = {0u, 0u, 0u, 0u};
   for (int64_t i0 = wave * 64; i0 < count; i0 += n_waves * 64) {
     const int64_t n = first + i0 + lane;
-    unsigned long long zero = __ballot(i0 + lane < count && weight[n] == 0);
+    bool mine = i0 + lane < count && weight[n] == 0;
+    if (masks && mine) {
+      uint32_t any = 0u;
+      for (int p = 0; p < n_planes; ++p) any |= masks[(size_t)p * mask_plane + (size_t)(i0 + lane)];
+      mine = any == 0u;
+    }
+    unsigned long long zero = __ballot(mine);
     while (zero) {
       const int l = __ffsll((long long)zero) - 1;
       zero &= zero - 1ull;
@@ -282,6 +291,33 @@ __global__ __launch_bounds__(256) void clear_unwritten_kernel(void* __restrict__
     }
   }
 }
+
+}  // namespace
+
+// (declared in saf_fuse_dev.h: the windowed path launches it beside its last row kernel)
+int clear_rows(void* feat, const int* weight, int64_t first, int64_t n_rows, int esz, int row_bytes, const uint32_t* masks,
+               size_t mask_plane, int n_planes, hipStream_t s) {
+  if (n_rows <= 0) return SAF_OK;
+  // Beside a row kernel (masks given) half the grid.  Measured (profiles/r05/clear_beside.txt): the two kernels do run side by side
+  // -- with 2 or 4 workgroups per CU the row kernel beside the clear takes 5 ms longer on the coherent scene, which is what the
+  // clear takes alone: the zeros leave through the same per-CU address / store path the row kernel is bound by -- so folding the
+  // clear into the call is worth 0.2-0.4 ms of 42.7 there and nothing on depth A; 8 per CU was the best of 2 / 4 / 8 / 16.
+  const char* bpc_env = getenv("SAF_CLEAR_WGS");
+  const int per_cu = bpc_env && atoi(bpc_env) > 0 ? atoi(bpc_env) : (masks ? 8 : 16);
+  if ((uintptr_t)feat & 15) return fail(SAF_E_INVALID, "clear_unwritten_rows: clip_feat must be 16-byte aligned");
+  int64_t blocks = (n_rows + 255) / 256;
+  const int64_t cap = (int64_t)device_cus() * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (esz == 4)
+    hipLaunchKernelGGL(clear_unwritten_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, feat, weight, first, n_rows, row_bytes, masks,
+                       mask_plane, n_planes);
+  else
+    hipLaunchKernelGGL(clear_unwritten_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, feat, weight, first, n_rows, row_bytes, masks,
+                       mask_plane, n_planes);
+  return check_launch("clear_unwritten_kernel");
+}
+
+namespace {
 
 // ---- the tiled CLIP front-end in one pass (clipfusion.py:789-823) ----
 // normalize_img (:783-784), Unfold into overlapping p x p tiles at stride s (:797-804) and the bilinear resize of every
@@ -422,21 +458,8 @@ int saf_clear_unwritten_rows(const saf_volume* vol, int64_t first_voxel, int64_t
   if (!vol || !vol->clip_feat || !vol->weight) return fail(SAF_E_INVALID, "clear_unwritten_rows: volume has a NULL buffer");
   const int64_t N = n_voxels(vol);
   if (first_voxel < 0 || n_rows < 0 || first_voxel + n_rows > N) return fail(SAF_E_INVALID, "clear_unwritten_rows: bad voxel range");
-  if (n_rows == 0) return SAF_OK;
   const int esz = vol->feat_dtype == SAF_F32 ? 4 : 2;
-  const int row_bytes = vol->feat_dim * esz;
-  int64_t blocks = (n_rows + 255) / 256;
-  const int64_t cap = (int64_t)device_cus() * 16;
-  if (blocks > cap) blocks = cap;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if ((uintptr_t)vol->clip_feat & 15) return fail(SAF_E_INVALID, "clear_unwritten_rows: clip_feat must be 16-byte aligned");
-  if (esz == 4)
-    hipLaunchKernelGGL(clear_unwritten_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, vol->clip_feat, vol->weight, first_voxel,
-                       n_rows, row_bytes);
-  else
-    hipLaunchKernelGGL(clear_unwritten_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, vol->clip_feat, vol->weight, first_voxel,
-                       n_rows, row_bytes);
-  return check_launch("clear_unwritten_kernel");
+  return clear_rows(vol->clip_feat, vol->weight, first_voxel, n_rows, esz, vol->feat_dim * esz, nullptr, 0, 0, static_cast<hipStream_t>(stream));
 }
 
 int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_stride_c, int64_t feat_stride_y,

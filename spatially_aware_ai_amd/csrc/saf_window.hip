@@ -1642,7 +1642,7 @@ struct WinUnit {
 };
 
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
-                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs) {
+                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs, bool recycled) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   KFrame kf0;
@@ -1877,6 +1877,15 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     return SAF_OK;
   };
   if ((rc = classify(0))) return rc;
+  // A recycled volume (saf_fuse_frames_recycled): the rows of the voxels that are still unwritten when the call is over have to be
+  // zeroed -- on a coherent scene five sixths of the volume, 28 GB of stores at 256^3 x 512 and a tenth of the job when they follow
+  // it.  When every unit covers the whole volume they are written on the classification stream BESIDE the last unit's row kernel
+  // instead (that stream has nothing left to do): by then every earlier unit has updated `weight`, and the last unit's hit masks
+  // say which rows its row kernel writes -- the two kernels' rows are disjoint.  What it buys is small (the row kernel slows down
+  // by nearly what the clear takes: saf_misc.hip, clear_rows).  SAF_WIN_CLEAR_BESIDE=0 (read per call): behind the last row
+  // kernel, on the caller's stream.
+  const bool clear_beside = recycled && ov && !brick_form && !(slabs && slabs->n > 0) && n_units == n_win &&
+                            !(getenv("SAF_WIN_CLEAR_BESIDE") && getenv("SAF_WIN_CLEAR_BESIDE")[0] == '0');
   int maps_of = -1;  // the window whose map images the workspace holds
   for (int ui = 0; ui < n_units && rc == SAF_OK; ++ui) {
     const WinUnit& u = units[ui];
@@ -1889,6 +1898,11 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
     if (ov && ui + 1 < n_units && (rc = classify(ui + 1))) break;  // queued now: it runs beside this unit's row kernel
     if (ov && hipStreamWaitEvent(s, ov->cls_done[par], 0) != hipSuccess) { rc = fail(SAF_E_HIP, "hipStreamWaitEvent"); break; }
+    if (clear_beside && ui + 1 == n_units) {
+      // (queued behind this unit's classification; the row kernel of the unit before must have stored its weights)
+      if (ui >= 1 && hipStreamWaitEvent(cs, ov->fuse_done[par ^ 1], 0) != hipSuccess) { rc = fail(SAF_E_HIP, "hipStreamWaitEvent"); break; }
+      if ((rc = launch_clear_unwritten(u.kv, masks, wl.mask_plane, (F + kClsFrames - 1) / kClsFrames, cs))) break;
+    }
     if (maps_of != u.window) {  // (the slabs of one window share its map images)
       ScopedPair t(prof, 0, f0, s);
       hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, static_cast<void*>(maps),
@@ -1919,6 +1933,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   if (ov) {  // whatever was queued on the classification stream is ordered before later work of the caller (error paths too)
     if (hipEventRecord(ov->join, cs) == hipSuccess) (void)hipStreamWaitEvent(s, ov->join, 0);
   }
+  if (recycled && !clear_beside && rc == SAF_OK) rc = launch_clear_unwritten(kv, nullptr, 0, 0, s);
 #ifdef SAF_WIN_TIMING
   {
     (void)hipStreamSynchronize(s);

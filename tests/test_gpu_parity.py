@@ -1239,13 +1239,15 @@ def test_reset_defers_the_feature_clear_invisibly(oracle):
     npy, npx = syn.feature_map_shape(w, h)
     grid = syn.make_grid(nvox, side=2.56 * nvox[0] / max(nvox))
     old = syn.make_frames(71, 40, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="A")
-    new = syn.make_frames(72, 40, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="B", radius=1.9)
+    new = syn.make_frames(72, 150, width=w, height=h, feat_dim=dim, npy=npy, npx=npx, depth_kind="B", radius=1.9)
     cat = lambda k, fs: torch.cat([f[k] for f in fs]).cuda()
     args = lambda fs: [cat(k, fs) for k in ("depth", "rgb", "pose", "K", "feat")]
     build = lambda: ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, FakeClip(dim), None, 10, 10,
                                keep_xyz_world=False).cuda()
     names = ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat")
-    for n_new in (40, 5, 0):  # windowed call, per-frame call, nothing
+    # two windows (the zeros are written beside the second one's row kernel: 22 frames, one mask plane of four in use), one
+    # window, the per-frame pipeline (cleared first), nothing
+    for n_new in (150, 40, 5, 0):
         fz = build()
         fz.integrate_features(*args(old))
         assert float(fz.clip_feat.abs().sum()) > 0
