@@ -577,15 +577,17 @@ __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((a
           const uint32_t nx_seg = ahead_same ? ahead_seg : (uint32_t)rfl((int)nx_ent[0]);
           const int next_n16 = (int)(kSegFixed / 16) + 1 + min(rfl((int)(ahead_same ? L.rows[cur].hdr[4] : nx_ent[2])), kHC);
           if (p + 1 == n_pass && ahead && (ahead_same || rfl((int)nx_ent[3]) != 0)) {
-            const uint4* next_sg = reinterpret_cast<const uint4*>(pool.segs + (size_t)nx_seg * kSegBytes);
-            uint4 img[kImgRegs];
+            // (a native vector type: as HIP's uint4 -- a struct around a union -- the conditionally loaded image lived in scratch)
+            typedef unsigned int img_u4 __attribute__((ext_vector_type(4)));
+            const img_u4* next_sg = reinterpret_cast<const img_u4*>(pool.segs + (size_t)nx_seg * kSegBytes);
+            img_u4 img[kImgRegs];
 #pragma unroll
             for (int k = 0; k < kImgRegs; ++k) {
               const int i16 = tid + k * kHitThreads;
               if (i16 < next_n16) img[k] = next_sg[i16];
             }
-            uint4* d_rows = reinterpret_cast<uint4*>(&L.rows[cur ^ 1]);
-            uint4* d_walk = reinterpret_cast<uint4*>(&L.walk) - kRows16;
+            img_u4* d_rows = reinterpret_cast<img_u4*>(&L.rows[cur ^ 1]);
+            img_u4* d_walk = reinterpret_cast<img_u4*>(&L.walk) - kRows16;
 #pragma unroll
             for (int k = 0; k < kImgRegs; ++k) {
               const int i16 = tid + k * kHitThreads;

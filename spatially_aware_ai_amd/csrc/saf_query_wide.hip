@@ -163,7 +163,8 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
       // straight into the other buffer with no registers; it lands while this tile's MFMAs run and
       // is covered by the barrier's vmcnt(0).  Narrower rows are staged through registers.
       constexpr bool kDma = (D == 512);
-      uint4 stage[kDma ? 1 : PPT];
+      typedef unsigned int w1_u4 __attribute__((ext_vector_type(4)));  // (native: as HIP's uint4 the conditionally loaded pieces lived in scratch)
+      w1_u4 stage[kDma ? 1 : PPT];
       const bool more = qt + 1 < n_qt;
       if (more) {
         if (kDma) {
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
             const int p = tid + k * kWThreads;
             if (p < PIECES) {
               const int q = p / (D / 8), c = p - q * (D / 8);
-              stage[k] = *reinterpret_cast<const uint4*>(text16 + (int64_t)((qt + 1) * kWTile + q) * D + c * 8);
+              stage[k] = *reinterpret_cast<const w1_u4*>(text16 + (int64_t)((qt + 1) * kWTile + q) * D + c * 8);
             }
           }
         }
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
           const int p = tid + k * kWThreads;
           if (p < PIECES) {
             const int q = p / (D / 8), c = p - q * (D / 8);
-            *reinterpret_cast<uint4*>(nxt + q * ROWB + c * 16) = stage[k];
+            *reinterpret_cast<w1_u4*>(nxt + q * ROWB + c * 16) = stage[k];
           }
         }
       }
@@ -945,12 +946,16 @@ int launch_wide2_nf(const Wide2Args& wa, hipStream_t s) {
   return check_launch("query_wide2_kernel");
 }
 
-// SAF_WIDE_ROWS=32 / 64 in the environment picks the geometry (development; the default is the measured-faster one)
+// The shipped geometry is 32 rows per wave, 8 waves per workgroup.  Development builds: -DSAF_W2_NF2 adds the 64-row instantiations
+// (SAF_WIDE_ROWS=64 in the environment picks them; the fp32-out heat maps among them spill ten registers), -DSAF_W2_TWO_WGS two
+// workgroups of four waves per CU (SAF_WIDE_ROWS=33).
 template <int FT, int OT, int KS, int EPI>
 int launch_wide2(const Wide2Args& wa, hipStream_t s) {
   const int rows_env = getenv("SAF_WIDE_ROWS") ? atoi(getenv("SAF_WIDE_ROWS")) : 0;
+  (void)rows_env;
+#ifdef SAF_W2_NF2
   if (rows_env == 64) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
-  if (rows_env == 32) return launch_wide2_nf<FT, OT, KS, EPI, 1, 512>(wa, s);
+#endif
 #ifdef SAF_W2_TWO_WGS
   if (rows_env == 33) return launch_wide2_nf<FT, OT, KS, EPI, 1, 256>(wa, s);  // two workgroups of 4 waves per CU
 #endif

@@ -169,3 +169,37 @@ def test_committed_bench_line_keeps_the_contract():
         rr = side[k]["roofline"]
         assert rr["bound"] in ("hbm", "mfma") and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3
     assert d["slab_by_slab_fuse"]["ratio"] < 1.25
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
+    """Every kernel of libsaf_hip.so keeps its working set in registers: no private segment, no vector register spilled to
+    memory (the code objects' metadata notes; scalar registers parked in lanes of a vector register are not memory).  Round 5: locals of HIP's `uint4` -- a struct around a union -- that are loaded under a condition
+    stayed in scratch memory (the brick form's segment image, the wide scan's staged text pieces); native vectors do not."""
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        import pytest
+
+        pytest.skip("no llvm-objdump in this image")
+    _lib.build()
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")  # (the bundles are extracted next to the file)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    objects = sorted(p for p in os.listdir(tmp_path) if "gfx950" in p)
+    assert objects, "no gfx950 code object in the library"
+    kernels, bad = 0, []
+    for obj in objects:
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / obj)], check=True,
+                               capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s*\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+                kernels += 1
+            m = re.match(r"\s*\.(private_segment_fixed_size|vgpr_spill_count):\s+(\d+)", line)
+            if m and int(m.group(2)) != 0:
+                bad.append((name, m.group(1), int(m.group(2))))
+    assert kernels > 100, kernels
+    assert not bad, bad
