@@ -746,7 +746,7 @@ def main():
             fusion.reset()
             fusion.flush()
             vol = fusion._c_volume(for_fuse=True)
-            check(L.saf_fuse_frames_slabs(C.byref(vol), frames, a.frames, x0s, nxs, len(bounds), None, ws.data_ptr(), ws.numel(),
+            check(L.saf_fuse_frames_slabs(C.byref(vol), frames, a.frames, x0s, nxs, len(bounds), None, 0, ws.data_ptr(), ws.numel(),
                                           stats_ptr, None, stream), "slab-wise fuse")
 
         def timed2(fn):

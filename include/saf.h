@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAF_ABI_VERSION 1
+#define SAF_ABI_VERSION 2
 
 enum saf_status {
   SAF_OK = 0,
@@ -227,10 +227,12 @@ int saf_fuse_frames_recycled(const saf_volume* vol, const saf_frame* frames, int
  * slab is never touched again.  slab_done_events (may be NULL, entries may be NULL): hipEvent_t handles, event k is recorded
  * on `stream` behind the last kernel that writes slab k -- the caller's reduce-scatter of that slab waits for it on its own
  * stream.  One call: the first window of slab k + 1 is classified beside the last row kernel of slab k.  Slabs must not
- * overlap; multiples of 16 x-planes keep the fast unit orders.  profiler may be NULL. */
+ * overlap; multiples of 16 x-planes keep the fast unit orders.  profiler may be NULL.  recycled != 0: the volume is a recycled
+ * one (saf_fuse_frames_recycled) -- the rows of a slab that are still unwritten are zeroed behind the slab's last row kernel,
+ * before its event; voxels outside every slab are not touched. */
 int saf_fuse_frames_slabs(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, const int32_t* slab_x0,
-                          const int32_t* slab_nx, int32_t n_slabs, void* const* slab_done_events, void* workspace,
-                          size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream);
+                          const int32_t* slab_nx, int32_t n_slabs, void* const* slab_done_events, int32_t recycled,
+                          void* workspace, size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream);
 
 /*
  * Depth un-projection of a lattice of pixels to world points: the per-frame body of

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SAF_OK = 0
 SAF_E_INVALID = -1
@@ -83,7 +83,7 @@ PROTOTYPES = {
     "saf_fuse_frames_slabs": (
         C.c_int,
         [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
-         C.POINTER(C.c_void_p), _fp, C.c_size_t, _fp, C.c_void_p, C.c_void_p],
+         C.POINTER(C.c_void_p), C.c_int32, _fp, C.c_size_t, _fp, C.c_void_p, C.c_void_p],
     ),
     "saf_fuse_path": (C.c_int, [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, C.c_size_t]),
     "saf_clear_unwritten_rows": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),

@@ -944,8 +944,16 @@ int fuse_many(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* w
   int rc = SAF_OK;
   if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
   if (recycled && !window_ok(kv, frames, n_frames, workspace_bytes)) {
-    // the per-frame pipeline reads every row it updates: the rows of weight-0 voxels are zeroed first
-    if ((rc = launch_clear_unwritten(kv, nullptr, 0, 0, s))) return rc;
+    // the per-frame pipeline reads every row it updates: the rows of weight-0 voxels are zeroed first (of the slabs, if the
+    // call names slabs: voxels outside them are not this call's)
+    if (slabs && slabs->n > 0) {
+      for (int k = 0; k < slabs->n; ++k) {
+        if (slabs->x0[k] < 0 || slabs->nx[k] <= 0 || slabs->x0[k] + slabs->nx[k] > kv.nx) return fail(SAF_E_INVALID, "slab %d outside the volume", k);
+        if ((rc = launch_clear_unwritten(slab_kvol(kv, slabs->x0[k], slabs->nx[k]), nullptr, 0, 0, s))) return rc;
+      }
+    } else if ((rc = launch_clear_unwritten(kv, nullptr, 0, 0, s))) {
+      return rc;
+    }
     recycled = false;
   }
   if (window_ok(kv, frames, n_frames, workspace_bytes)) {
@@ -1073,18 +1081,27 @@ int saf_fuse_frames_recycled(const saf_volume* vol, const saf_frame* frames, int
 }
 
 int saf_fuse_frames_slabs(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, const int32_t* slab_x0,
-                          const int32_t* slab_nx, int32_t n_slabs, void* const* slab_done_events, void* workspace,
-                          size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream) {
+                          const int32_t* slab_nx, int32_t n_slabs, void* const* slab_done_events, int32_t recycled,
+                          void* workspace, size_t workspace_bytes, uint64_t* stats, saf_profiler* profiler, void* stream) {
   KVol kv;
   int rc = make_kvol(vol, &kv);
   if (rc) return rc;
   if (n_frames < 0 || (n_frames > 0 && !frames)) return fail(SAF_E_INVALID, "bad frame array");
   if (n_slabs <= 0 || !slab_x0 || !slab_nx) return fail(SAF_E_INVALID, "bad slab list");
-  if (n_frames == 0) return SAF_OK;
   if ((rc = poll_latch())) return rc;
   ensure_latch();
   const WinSlabs sl{n_slabs, slab_x0, slab_nx, slab_done_events};
-  return fuse_many(kv, frames, n_frames, workspace, workspace_bytes, stats, profiler, static_cast<hipStream_t>(stream), &sl);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_frames == 0) {  // nothing to fuse: a recycled volume's slabs are cleared, every event is recorded
+    for (int k = 0; k < n_slabs; ++k) {
+      if (slab_x0[k] < 0 || slab_nx[k] <= 0 || slab_x0[k] + slab_nx[k] > kv.nx) return fail(SAF_E_INVALID, "slab %d outside the volume", k);
+      if (recycled && (rc = launch_clear_unwritten(slab_kvol(kv, slab_x0[k], slab_nx[k]), nullptr, 0, 0, s))) return rc;
+      if (slab_done_events && slab_done_events[k] && hipEventRecord(static_cast<hipEvent_t>(slab_done_events[k]), s) != hipSuccess)
+        return fail(SAF_E_HIP, "hipEventRecord(slab done)");
+    }
+    return SAF_OK;
+  }
+  return fuse_many(kv, frames, n_frames, workspace, workspace_bytes, stats, profiler, s, &sl, recycled != 0);
 }
 
 int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,

@@ -1925,6 +1925,8 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     }
     if (rc) break;
     mark("rows: queued", ui);
+    // a finished slab of a recycled volume: its rows that are still unwritten are zeroed before anyone is told it is finished
+    if (u.done >= 0 && recycled && (rc = launch_clear_unwritten(u.kv, nullptr, 0, 0, s))) break;
     if (u.done >= 0 && slabs && slabs->done && slabs->done[u.done] &&
         hipEventRecord(static_cast<hipEvent_t>(slabs->done[u.done]), s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord(slab done)"); break; }
     if (ov && hipEventRecord(ov->fuse_done[par], s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord"); break; }
@@ -1933,7 +1935,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   if (ov) {  // whatever was queued on the classification stream is ordered before later work of the caller (error paths too)
     if (hipEventRecord(ov->join, cs) == hipSuccess) (void)hipStreamWaitEvent(s, ov->join, 0);
   }
-  if (recycled && !clear_beside && rc == SAF_OK) rc = launch_clear_unwritten(kv, nullptr, 0, 0, s);
+  if (recycled && !clear_beside && !(slabs && slabs->n > 0) && rc == SAF_OK) rc = launch_clear_unwritten(kv, nullptr, 0, 0, s);
 #ifdef SAF_WIN_TIMING
   {
     (void)hipStreamSynchronize(s);

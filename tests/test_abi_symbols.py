@@ -67,7 +67,7 @@ def test_slab_entry_rejects_bad_lists_on_the_host():
     l = _lib.lib()
     vol = _abi.SafVolume()
     fr = _abi.SafFrame()
-    rc = l.saf_fuse_frames_slabs(ctypes.byref(vol), ctypes.byref(fr), 1, None, None, 0, None, None, 0, None, None, None)
+    rc = l.saf_fuse_frames_slabs(ctypes.byref(vol), ctypes.byref(fr), 1, None, None, 0, None, 0, None, 0, None, None, None)
     assert rc == _abi.SAF_E_INVALID
 
 

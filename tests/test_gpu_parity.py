@@ -1381,8 +1381,13 @@ def test_slab_by_slab_fusion_equals_the_whole_volume(seem):
                 check(L.saf_fuse_frames(C.byref(vol), arr, n_frames, ws.data_ptr(), ws.numel(), fz._buffers["fuse_stats"].data_ptr(),
                                         stream), "slab fuse")
         else:
+            # a recycled volume: what the previous scan left in the rows must be gone from every slab that is reported finished
+            # (saf_fuse_frames_slabs(recycled = 1) zeroes a slab's still-unwritten rows behind the slab's last row kernel)
+            fz._buffers["clip_feat"].fill_(float("nan"))
             fz.reset(accum_mode=_abi.SAF_SUM)
+            assert fz._feat_stale
             stripes = sdist.fuse_merge_pipelined(fz, arr, n_frames, ws, n_slabs=4, comm_stream=torch.cuda.Stream())
+            assert not fz._feat_stale
             assert sum(c for _, c in stripes) == fz.tsdf.numel()
             fz.accum_mode = _abi.SAF_RUNNING_MEAN
         torch.cuda.synchronize()
