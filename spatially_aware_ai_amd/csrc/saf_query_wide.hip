@@ -12,6 +12,8 @@
 //     ds_read_b128 group hit distinct bank quads; the 8 waves of a workgroup (256 feature rows) share it;
 //   * per tile 32 MFMAs per wave accumulate a 32x32 fp32 block, scaled by the row's 1/norm (computed from
 //     the same registers) and written out as scores in the requested dtype.
+#include <type_traits>
+
 #include "saf_common.h"
 #include "saf_host.h"
 
@@ -879,6 +881,485 @@ query_wide2_kernel(Wide2Args wa) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// v3: the v2 scan on v_mfma_f32_16x16x32 instead of v_mfma_f32_32x32x16 (round 5).
+//
+// Both shapes cost the same cycles per flop, and v2 is bound by the clock the chip holds under the matrix load,
+// not by idle cycles -- and that clock depends on the MFMA shape: MI355X_MICROARCH.md, "DVFS give-back" item 7, measures
+// 1.12-1.14 x the FLOP/s for 16x16x32 loops whose operands are re-read from LDS (cdna_hip_programming.md rule 28: build both at
+// the same output tile per wave, keep the faster by wall, on random data).  Same tile per wave as v2's default geometry (32 rows
+// x 32 queries, 8 waves, two per SIMD), same LDS tiles, transfers, barrier and waits; what changes is the operand layout:
+//   lane (c = lane & 15, g = lane >> 4) holds, of the wave's 32 rows, rows c and 16 + c (row blocks rb = 0, 1) -- 16 bytes of
+//   every 64-byte k-step (k = 32 s + 8 g + j): a[rb][s], KS registers-of-four in all, as before;
+//   a text fragment m = 2 s + qb is query block qb (16 queries) x k-step s: 1 KiB, read once from LDS, feeds the two row blocks'
+//   MFMAs (2 x 16 cycles: the LDS bytes per matrix cycle of v2);
+//   acc[rb][qb] (4 registers): query 16 qb + 4 g + i of the tile x the lane's row of block rb (QUERY_MAX, operands swapped:
+//   row 16 rb + 4 g + i of the wave x query 16 qb + c).
+// A row is shared by four lanes (v2: two): the reductions over a row's queries meet over xor 16 and xor 32; 16-bit scores leave as
+// 16-byte stores after v_permlane16_swap (the odd 16-lane rows of one operand against the even rows of the other).
+// ------------------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int FT>
+__device__ __forceinline__ f32x4_t mfma32(const uint4& a, const uint4& b, const f32x4_t& c) {
+  if (FT == SAF_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+}
+
+struct W3Tile {
+  float inv[2];     // scale / row norm of the lane's row of block rb
+  int64_t row[2];   // its true index (may be >= n_rows on the last block)
+  int qt;
+};
+struct W3State {
+  float best_v[2];
+  float lse0, lse1;  // VS_BACKGROUND: log-sum-exp of the backgrounds of the lane's rows (two scalars: as an array indexed by the row
+                     // block the fp32-output instantiations kept the whole struct in scratch memory)
+  int best_q[2];
+  const float* inv_lds;  // QUERY_MAX: the wave's 32 (scale / norm) values in LDS, by row of the wave
+};
+
+template <int OT, int EPI>
+__device__ __forceinline__ void w3_epilogue(const Wide2Args& wa, const f32x4_t (&acc)[2][2], const W3Tile& t, W3State& st, int c,
+                                            int g, int n_qt, bool vec_ok) {
+  const int qlane = t.qt * kWTile + 4 * g;  // the lane's first query of block qb = 0 (plain layout)
+  if (EPI == SAF_QW_SCORES || EPI == SAF_QW_VS_BACKGROUND) {
+    // (the two row blocks as two instances of one body with a constant index: left as a loop, the fp32-output instantiations kept
+    //  it rolled -- `st` indexed at run time, i.e. in scratch memory)
+    auto block = [&](auto rb_c) {
+      constexpr int rb = decltype(rb_c)::value;
+      float v[8];  // v[4 qb + i]: query 16 qb + 4 g + i of the tile
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = acc[rb][j >> 2][j & 3] * t.inv[rb];
+      int colt = t.qt * kWTile;  // output column of the tile's query 0
+      bool write = true;
+      // (the new log-sum-exp leaves its branch as a VALUE and is stored unconditionally below: a float stored to `st` on one path
+      //  and floats stored to the output on the other were merged into one store through a selected FLAT pointer -- `st` in
+      //  scratch memory in every fp32-output instantiation)
+      float lse_new = rb == 0 ? st.lse0 : st.lse1;
+      if (EPI == SAF_QW_VS_BACKGROUND) {
+        if (t.qt == 0) {  // tile 0 holds the backgrounds: per-row log-sum-exp of their scaled scores, no output
+          float m = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) m = (16 * (j >> 2) + 4 * g + (j & 3) < wa.n_bg) ? fmaxf(m, v[j]) : m;
+          m = fmaxf(m, __shfl_xor(m, 16));
+          m = fmaxf(m, __shfl_xor(m, 32));
+          float e = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e += (16 * (j >> 2) + 4 * g + (j & 3) < wa.n_bg) ? __expf(v[j] - m) : 0.f;
+          e += __shfl_xor(e, 16);
+          e += __shfl_xor(e, 32);
+          lse_new = m + __logf(e);
+          write = false;
+        } else {
+          const bool rescale = (wa.flags & 1) != 0;  // query_mesh.py:39: ((r - 0.5) * 2).clamp(0, 1)
+          const float ka = -t.inv[rb] * 1.4426950408889634f, kb = (rb == 0 ? st.lse0 : st.lse1) * 1.4426950408889634f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rb][j >> 2][j & 3], ka, kb)));
+            v[j] = __builtin_amdgcn_fmed3f(__builtin_fmaf(p, rescale ? 2.0f : 1.0f, rescale ? -1.0f : 0.0f), 0.0f, 1.0f);
+          }
+          colt -= kWTile;
+        }
+      }
+      if (rb == 0) st.lse0 = lse_new; else st.lse1 = lse_new;
+      if (write) {
+        const int ncols = EPI == SAF_QW_VS_BACKGROUND ? wa.Q - kWTile : wa.Q;
+        const int64_t row = t.row[rb];
+        if (OT == SAF_F32) {
+          if (row < wa.n_rows) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+              const int q0 = colt + 16 * qb + 4 * g;
+              float* o = static_cast<float*>(wa.out) + row * wa.ostride + q0;
+              if (vec_ok && q0 + 3 < ncols) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[4 * qb], v[4 * qb + 1], v[4 * qb + 2], v[4 * qb + 3]);
+              } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (q0 + i < ncols) o[i] = v[4 * qb + i];
+              }
+            }
+          }
+        } else {
+          // the lane's two groups of four (8 bytes each) against the neighbouring 16-lane row's: even rows end with queries
+          // 4 g .. 4 g + 7, odd rows with 16 + 4 (g - 1) .. + 7 of their feature row -- one 16-byte store each
+          const uint2 lo = pack4_16<OT>(v[0], v[1], v[2], v[3]);  // block 0: queries 4 g ..
+          const uint2 hi = pack4_16<OT>(v[4], v[5], v[6], v[7]);  // block 1: queries 16 + 4 g ..
+          auto rx = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
+          auto ry = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
+          const uint32_t ww[4] = {rx[0], ry[0], rx[1], ry[1]};
+          const int qv = colt + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);  // first of this lane's 8 columns
+          if (row < wa.n_rows) {
+            uint16_t* o = static_cast<uint16_t*>(wa.out) + row * wa.ostride + qv;
+            if (vec_ok && qv + 7 < ncols) {
+              typedef unsigned int w3_u4 __attribute__((ext_vector_type(4)));
+              const w3_u4 w = {ww[0], ww[1], ww[2], ww[3]};
+              *reinterpret_cast<w3_u4*>(o) = w;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i)
+                if (qv + i < ncols) o[i] = (uint16_t)(ww[i >> 1] >> (16 * (i & 1)));
+            }
+          }
+        }
+      }
+    };
+    block(std::integral_constant<int, 0>{});
+    block(std::integral_constant<int, 1>{});
+  } else if (EPI == SAF_QW_ROW_ARGMAX) {
+    const bool last = t.qt == n_qt - 1;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      float bv = t.qt == 0 ? -INFINITY : st.best_v[rb];
+      int bq = t.qt == 0 ? 0 : st.best_q[rb];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = qlane + 16 * (j >> 2) + (j & 3);
+        float x = acc[rb][j >> 2][j & 3];  // RAW dot products (see w2_epilogue)
+        if (last && q >= wa.Q) x = -INFINITY;
+        if (x > bv) { bv = x; bq = q; }  // the lane's queries ascend: the first maximum stays
+      }
+      if (last) {  // the four lanes of a row: the larger score, the smaller query on ties
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+          const float ov = __shfl_xor(bv, off);
+          const int oq = __shfl_xor(bq, off);
+          if (ov > bv || (ov == bv && oq < bq)) { bv = ov; bq = oq; }
+        }
+        if (g == 0 && t.row[rb] < wa.n_rows) { wa.out_index[t.row[rb]] = bq; wa.out_value[t.row[rb]] = bv * t.inv[rb]; }
+      }
+      st.best_v[rb] = bv;
+      st.best_q[rb] = bq;
+    }
+  } else {  // SAF_QW_QUERY_MAX, operands swapped: acc[rb][qb][i] = row 16 rb + 4 g + i of the wave x query 16 qb + c
+    const int64_t base = t.row[0] - c;  // the wave's first row
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int q = t.qt * kWTile + 16 * qb + c;
+      float bv = -INFINITY;
+      int bm = 0;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const float4 iv = *reinterpret_cast<const float4*>(st.inv_lds + 16 * rb + 4 * g);
+        const float ivs[4] = {iv.x, iv.y, iv.z, iv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * rb + 4 * g + i;
+          const float x = base + m < wa.n_rows ? acc[rb][qb][i] * ivs[i] : -INFINITY;
+          if (x > bv) { bv = x; bm = m; }  // the lane's rows ascend: the first maximum stays
+        }
+      }
+      unsigned long long key = bv > -INFINITY ? ((unsigned long long)ordered_bits(bv) << 32) | (uint32_t) ~(uint32_t)(base + bm + wa.row_offset) : 0ull;
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const unsigned long long other = __shfl_xor(key, off);
+        key = other > key ? other : key;
+      }
+      if (g == 0 && q < wa.Q && key) atomicMax(&wa.qkeys[q], key);
+    }
+  }
+}
+
+// The same epilogue in sixteen pieces that sit BETWEEN the MFMAs of the next tile (see w2_fast_piece: a wave issues in order, and
+// a few vector instructions fit in the shadow of every MFMA), for interior tiles: every row of the wave valid, aligned output, all
+// 32 columns real -- wave-uniform, branch-free.  Piece k finishes one accumulator register per row block (SCORES / VS_BACKGROUND /
+// ROW_ARGMAX: k = 8 rb + j, j = 4 qb + i) or per query block (QUERY_MAX: k = 8 qb + 4 rb + i); what leaves the wave (a store per
+// row block, an atomic per query block) follows pieces 7 and 15.
+struct W3Fast {
+  float v[2][8];     // SCORES / VS_BACKGROUND: the row block's finished values
+  float ka[2], kb[2];
+  float iv[4];       // QUERY_MAX: 1/norm of the four rows behind the current accumulator
+  float cv; int ci;  // the running best of the current chain
+  uint32_t k0hi, k0lo;  // QUERY_MAX: query block 0's key, until block 1's is complete
+};
+template <int OT, int EPI>
+__device__ __forceinline__ void w3_piece(int k, const Wide2Args& wa, const f32x4_t (&pacc)[2][2], const W3Tile& t, W3State& st,
+                                         W3Fast& fs, int c, int g) {
+  if (EPI == SAF_QW_SCORES || EPI == SAF_QW_VS_BACKGROUND) {
+    const int rb = k >> 3, j = k & 7;
+    const float raw = pacc[rb][j >> 2][j & 3];
+    float x;
+    if (EPI == SAF_QW_VS_BACKGROUND) {
+      const bool rescale = (wa.flags & 1) != 0;
+      if (j == 0) {
+        fs.ka[rb] = -t.inv[rb] * 1.4426950408889634f;
+        fs.kb[rb] = (rb == 0 ? st.lse0 : st.lse1) * 1.4426950408889634f;
+      }
+      const float p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(raw, fs.ka[rb], fs.kb[rb])));
+      x = __builtin_amdgcn_fmed3f(__builtin_fmaf(p, rescale ? 2.0f : 1.0f, rescale ? -1.0f : 0.0f), 0.0f, 1.0f);
+    } else {
+      x = raw * t.inv[rb];
+    }
+    fs.v[rb][j] = x;
+    if (j == 7) {
+      const int colt = (EPI == SAF_QW_VS_BACKGROUND ? t.qt - 1 : t.qt) * kWTile;
+      const float* v = fs.v[rb];
+      if (OT == SAF_F32) {
+        float* o = static_cast<float*>(wa.out) + t.row[rb] * wa.ostride + colt + 4 * g;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 16) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        const uint2 lo = pack4_16<OT>(v[0], v[1], v[2], v[3]);
+        const uint2 hi = pack4_16<OT>(v[4], v[5], v[6], v[7]);
+        auto rx = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
+        auto ry = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
+        typedef unsigned int w3_u4 __attribute__((ext_vector_type(4)));
+        const w3_u4 w = {rx[0], ry[0], rx[1], ry[1]};
+        uint16_t* o = static_cast<uint16_t*>(wa.out) + t.row[rb] * wa.ostride + colt + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
+        *reinterpret_cast<w3_u4*>(o) = w;
+      }
+    }
+  } else if (EPI == SAF_QW_ROW_ARGMAX) {
+    const int rb = k >> 3, j = k & 7;
+    const float x = pacc[rb][j >> 2][j & 3];  // raw dot products: see w2_epilogue
+    if (j == 0) {
+      fs.cv = x; fs.ci = 0;
+    } else {
+      const bool better = x > fs.cv;  // the lane's queries ascend: the first maximum stays
+      fs.cv = better ? x : fs.cv;
+      fs.ci = better ? 16 * (j >> 2) + (j & 3) : fs.ci;
+    }
+    if (j == 7) {
+      const bool better = fs.cv > st.best_v[rb];  // tiles ascend: the first maximum stays
+      st.best_v[rb] = better ? fs.cv : st.best_v[rb];
+      st.best_q[rb] = better ? t.qt * kWTile + 4 * g + fs.ci : st.best_q[rb];
+    }
+  } else {  // SAF_QW_QUERY_MAX (operands swapped): the chain over the lane's eight rows of query 16 qb + c
+    const int qb = k >> 3, rb = (k >> 2) & 1, i = k & 3;
+    if (i == 0) {
+      const float4 v4 = *reinterpret_cast<const float4*>(st.inv_lds + 16 * rb + 4 * g);
+      fs.iv[0] = v4.x; fs.iv[1] = v4.y; fs.iv[2] = v4.z; fs.iv[3] = v4.w;
+    }
+    const float x = pacc[rb][qb][i] * fs.iv[i];
+    const int m = 16 * rb + 4 * g + i;
+    if ((k & 7) == 0) {
+      fs.cv = x; fs.ci = m;
+    } else {
+      const bool better = x > fs.cv;  // the lane's rows ascend: the first maximum stays
+      fs.cv = better ? x : fs.cv;
+      fs.ci = better ? m : fs.ci;
+    }
+    if ((k & 7) == 7) {
+      const uint32_t row = (uint32_t)(t.row[0] - c + wa.row_offset) + (uint32_t)fs.ci;
+      const uint32_t khi = ordered_bits(fs.cv), klo = ~row;
+      if (qb == 0) {
+        fs.k0hi = khi; fs.k0lo = klo;
+      } else {
+        // The four lanes of a query meet without the LDS: v_permlane16_swap trades block 0's key of the odd 16-lane rows for
+        // block 1's key of the even rows -- even rows then hold both halves of a pair of rows for block 0, odd rows for block 1 --,
+        // v_permlane32_swap brings the other pair of rows; rows 0 and 1 issue ONE atomic instruction for the tile's 32 queries.
+        auto sh = __builtin_amdgcn_permlane16_swap(fs.k0hi, khi, false, false);
+        auto sl = __builtin_amdgcn_permlane16_swap(fs.k0lo, klo, false, false);
+        const unsigned long long ka = ((unsigned long long)sh[0] << 32) | sl[0], kb = ((unsigned long long)sh[1] << 32) | sl[1];
+        unsigned long long key = ka > kb ? ka : kb;
+        auto th = __builtin_amdgcn_permlane32_swap((uint32_t)(key >> 32), (uint32_t)(key >> 32), false, false);
+        auto tl = __builtin_amdgcn_permlane32_swap((uint32_t)key, (uint32_t)key, false, false);
+        const unsigned long long other = g >= 2 ? ((unsigned long long)th[0] << 32) | tl[0] : ((unsigned long long)th[1] << 32) | tl[1];
+        key = other > key ? other : key;
+        if (g < 2) atomicMax(&wa.qkeys[t.qt * kWTile + 16 * g + c], key);
+      }
+    }
+  }
+}
+
+template <int FT, int OT, int KS, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void query_wide3_kernel(Wide2Args wa) {
+  constexpr int kThreads = 512, kWaves = 8, kRows = 32;
+  constexpr int D = KS * 16, S = KS / 2;  // S k-steps of 32
+  constexpr int ROWB = D * 2 + 16;        // padded LDS row: the 16 lanes of a fragment's row group hit distinct bank quads
+  constexpr bool kDma = (D == 512);
+  constexpr bool kSwap = EPI == SAF_QW_QUERY_MAX;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_tiles[];  // 2 x [32][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n_qt = wa.Qpad / kWTile;
+  const int64_t rows_per_wg = (int64_t)kWaves * kRows;
+  const int64_t n_blocks = (wa.n_rows + rows_per_wg - 1) / rows_per_wg;
+  const int64_t my_blocks = blockIdx.x < n_blocks ? (n_blocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t n_steps = my_blocks * n_qt;
+  if (n_steps == 0) return;
+  constexpr int PIECES = kWTile * (D / 8);
+  constexpr int PPT = (PIECES + kThreads - 1) / kThreads;
+  const bool vec_ok = (wa.ostride % 8 == 0) && (((uintptr_t)wa.out & 15) == 0);
+
+  for (int p = tid; p < PIECES; p += kThreads) {  // tile 0 of the first block
+    const int q = p / (D / 8), cc = p - q * (D / 8);
+    *reinterpret_cast<uint4*>(s_tiles + q * ROWB + cc * 16) = *reinterpret_cast<const uint4*>(wa.text16 + (int64_t)q * D + cc * 8);
+  }
+
+  uint4 a[2][S];
+  W3Tile cur, prev;
+  W3State st;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    st.best_v[rb] = -INFINITY; st.best_q[rb] = 0;
+    cur.inv[rb] = 0.f; cur.row[rb] = 0;
+  }
+  st.lse0 = st.lse1 = 0.f;
+  float* s_inv = reinterpret_cast<float*>(s_tiles + 2 * kWTile * ROWB) + wave * kRows;  // QUERY_MAX only
+  st.inv_lds = s_inv;
+  cur.qt = 0;
+  prev = cur;
+  f32x4_t acc[2][2][2];  // [step parity][row block][query block]
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_tiles;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  int tail_ops = 0;
+  int qt_run = 0;
+  int64_t blk_run = blockIdx.x;
+
+  auto step_body = [&](int64_t step, f32x4_t (&cacc)[2][2], const f32x4_t (&pacc)[2][2]) __attribute__((always_inline)) {
+    const int qt = qt_run;
+    qt_run = qt + 1 < n_qt ? qt + 1 : 0;
+    if (qt == 0) {  // a new row block: its rows per wave, register resident for every query tile
+      const int64_t blk = blk_run;
+      blk_run += gridDim.x;
+      const int64_t row0 = (blk * kWaves + wave) * kRows;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        cur.row[rb] = row0 + 16 * rb + c;
+        const int64_t rr = cur.row[rb] < wa.n_rows ? cur.row[rb] : wa.n_rows - 1;  // padded lanes recompute the last row
+        const uint16_t* pa = wa.feats + rr * wa.fstride + 8 * g;
+#pragma unroll
+        for (int s = 0; s < S; ++s) a[rb][s] = ld_stream_u4(pa + 32 * s);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        cur.inv[rb] = wa.scale;
+        if (wa.normalize) {
+          float ss = 0.f, ss2 = 0.f;
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            const uint32_t w[4] = {a[rb][s].x, a[rb][s].y, a[rb][s].z, a[rb][s].w};
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+              ss = dot2_self<FT>(w[j], ss);
+              ss2 = dot2_self<FT>(w[j + 1], ss2);
+            }
+          }
+          ss += ss2;
+          ss += __shfl_xor(ss, 16);
+          ss += __shfl_xor(ss, 32);
+          cur.inv[rb] = wa.normalize == SAF_NORM_L2_CLAMP ? wa.scale / fmaxf(sqrtf(ss), 0.1f)
+                                                          : (ss > 0.0f ? wa.scale / sqrtf(ss) : 0.0f);
+        }
+      }
+    }
+    cur.qt = qt;
+    const unsigned char* curb = s_tiles + (size_t)(step & 1) * kWTile * ROWB;
+    unsigned char* nxt = s_tiles + (size_t)((step + 1) & 1) * kWTile * ROWB;
+#if SAF_W2_ASMDMA
+    w2_wait_vm(kDma && !wa.safe_wait ? tail_ops : 0);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();  // this tile's text is in LDS, every wave is done reading the other buffer
+    const bool more = step + 1 < n_steps;
+    const int qt_next = qt + 1 < n_qt ? qt + 1 : 0;
+    typedef unsigned int w3s_u4 __attribute__((ext_vector_type(4)));
+    w3s_u4 stage[kDma ? 1 : PPT];
+    if (more) {
+      if (kDma) {
+        constexpr int K = kWTile / kWaves;
+        w2_dma_rows<K, ROWB>(wa.text16 + (int64_t)(qt_next * kWTile + wave_u * K) * D, (uint32_t)lane * 16u,
+                             lds_base + (uint32_t)((step + 1) & 1) * kWTile * ROWB + wave_u * K * ROWB);
+      } else {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const int p = tid + k * kThreads;
+          if (p < PIECES) {
+            const int q = p / (D / 8), cc = p - q * (D / 8);
+            stage[k] = *reinterpret_cast<const w3s_u4*>(wa.text16 + (int64_t)(qt_next * kWTile + q) * D + cc * 8);
+          }
+        }
+      }
+    }
+    constexpr int kAhead = EPI == SAF_QW_QUERY_MAX ? SAF_W2_AHEAD - 2 : SAF_W2_AHEAD;  // (the per-query maximum's chain state: 6 spilled 11 registers)
+    constexpr int AHEAD = KS < kAhead ? KS : kAhead;
+    uint4 t[KS];  // fragment m = 2 s + qb
+    const unsigned char* trow = curb + c * ROWB + 16 * g;
+#define SAF_W3_TOFF(m) ((((m) & 1) * 16) * ROWB + 64 * ((m) >> 1))
+#pragma unroll
+    for (int m = 0; m < AHEAD; ++m) t[m] = *reinterpret_cast<const uint4*>(trow + SAF_W3_TOFF(m));
+    // Is the previous tile an interior one (wave-uniform)?  Then its epilogue rides between this tile's MFMAs.
+    bool fast = step > 0 && __all(prev.row[0] < wa.n_rows && prev.row[1] < wa.n_rows);
+    if (EPI == SAF_QW_SCORES) fast = fast && vec_ok && (prev.qt + 1) * kWTile <= wa.Q;
+    if (EPI == SAF_QW_VS_BACKGROUND) fast = fast && vec_ok && prev.qt > 0 && (prev.qt + 1) * kWTile <= wa.Q;
+    if (EPI == SAF_QW_ROW_ARGMAX) fast = fast && prev.qt > 0 && prev.qt < n_qt - 1;  // first / last tile: reset / write-out
+    if (EPI == SAF_QW_QUERY_MAX) fast = fast && (prev.qt + 1) * kWTile <= wa.Q;
+#ifdef SAF_W3_NO_FAST
+    fast = false;
+#endif
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (!fast) {
+#ifndef SAF_W3_NO_EPI  // (development: the scan without its epilogues -- wrong results, the matrix core's time)
+      if (step > 0) w3_epilogue<OT, EPI>(wa, pacc, prev, st, c, g, n_qt, vec_ok);
+#endif
+#pragma unroll
+      for (int m = 0; m < KS; ++m) {
+        const int s = m >> 1, qb = m & 1;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          cacc[rb][qb] = kSwap ? mfma32<FT>(a[rb][s], t[m], s == 0 ? zero4 : cacc[rb][qb]) : mfma32<FT>(t[m], a[rb][s], s == 0 ? zero4 : cacc[rb][qb]);
+        if (m + AHEAD < KS) t[m + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W3_TOFF(m + AHEAD));
+      }
+      tail_ops = 0;
+    } else {
+      W3Fast fs;
+#pragma unroll
+      for (int m = 0; m < KS; ++m) {
+        const int s = m >> 1, qb = m & 1;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          cacc[rb][qb] = kSwap ? mfma32<FT>(a[rb][s], t[m], s == 0 ? zero4 : cacc[rb][qb]) : mfma32<FT>(t[m], a[rb][s], s == 0 ? zero4 : cacc[rb][qb]);
+        if (m + AHEAD < KS) t[m + AHEAD] = *reinterpret_cast<const uint4*>(trow + SAF_W3_TOFF(m + AHEAD));
+#ifndef SAF_W3_NO_EPI
+#pragma unroll
+        for (int k = (m * 16) / KS; k < ((m + 1) * 16) / KS; ++k) w3_piece<OT, EPI>(k, wa, pacc, prev, st, fs, c, g);
+#endif
+        __builtin_amdgcn_sched_barrier(0);  // keep the pieces where they are: between the MFMAs
+      }
+      // what this step issued behind its transfer, at the very least: a store per row block (two for fp32) or the tile's atomic
+      // -- every one of them by all lanes of a group that always exists
+#ifndef SAF_W3_NO_EPI
+      tail_ops = EPI == SAF_QW_ROW_ARGMAX ? 0 : EPI == SAF_QW_QUERY_MAX ? 1 : (OT == SAF_F32 ? 4 : 2);
+#else
+      tail_ops = 0;
+#endif
+    }
+    if (EPI == SAF_QW_QUERY_MAX && qt == 0) {
+      // the new block's 1/norms, by row of the wave -- only now: this step's epilogue was the LAST tile of the block before
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+        if (g == 0) s_inv[16 * rb + c] = cur.inv[rb];
+    }
+    if (more && !kDma) {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int p = tid + k * kThreads;
+        if (p < PIECES) {
+          const int q = p / (D / 8), cc = p - q * (D / 8);
+          *reinterpret_cast<w3s_u4*>(nxt + q * ROWB + cc * 16) = stage[k];
+        }
+      }
+    }
+    prev = cur;
+  };
+
+  int64_t step = 0;
+  for (; step + 1 < n_steps; step += 2) {
+    step_body(step, acc[0], acc[1]);
+    step_body(step + 1, acc[1], acc[0]);
+  }
+  if (step < n_steps) {
+    step_body(step, acc[0], acc[1]);
+    w3_epilogue<OT, EPI>(wa, acc[0], prev, st, c, g, n_qt, vec_ok);
+  } else {
+    w3_epilogue<OT, EPI>(wa, acc[1], prev, st, c, g, n_qt, vec_ok);
+  }
+}
+
 __global__ void qkeys_decode_kernel(const unsigned long long* __restrict__ keys, int Q, float* __restrict__ out_value,
                                     int64_t* __restrict__ out_row, int64_t row_hi) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -946,6 +1427,22 @@ int launch_wide2_nf(const Wide2Args& wa, hipStream_t s) {
   return check_launch("query_wide2_kernel");
 }
 
+template <int FT, int OT, int KS, int EPI>
+int launch_wide3(const Wide2Args& wa, hipStream_t s) {
+  constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16) + (EPI == SAF_QW_QUERY_MAX ? 8 * 32 * sizeof(float) : 0);
+  auto fn = query_wide3_kernel<FT, OT, KS, EPI>;
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const int64_t rows_per_wg = 8 * 32;
+  int64_t blocks = (wa.n_rows + rows_per_wg - 1) / rows_per_wg;
+  const int64_t cap = (int64_t)device_cus();  // persistent: one workgroup per CU
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(512), shmem, s, wa);
+  return check_launch("query_wide3_kernel");
+}
+
 // The shipped geometry is 32 rows per wave, 8 waves per workgroup.  Development builds: -DSAF_W2_NF2 adds the 64-row instantiations
 // (SAF_WIDE_ROWS=64 in the environment picks them; the fp32-out heat maps among them spill ten registers), -DSAF_W2_TWO_WGS two
 // workgroups of four waves per CU (SAF_WIDE_ROWS=33).
@@ -953,6 +1450,10 @@ template <int FT, int OT, int KS, int EPI>
 int launch_wide2(const Wide2Args& wa, hipStream_t s) {
   const int rows_env = getenv("SAF_WIDE_ROWS") ? atoi(getenv("SAF_WIDE_ROWS")) : 0;
   (void)rows_env;
+  // The scan runs on v_mfma_f32_16x16x32 (query_wide3_kernel: 4-9 % faster than the 32x32x16 form at the same tile per wave, the
+  // chip holds a higher clock on it); SAF_WIDE_MFMA=32 (read per call) selects query_wide2_kernel.
+  const char* shape = getenv("SAF_WIDE_MFMA");
+  if (!(shape && atoi(shape) == 32)) return launch_wide3<FT, OT, KS, EPI>(wa, s);
 #ifdef SAF_W2_NF2
   if (rows_env == 64) return launch_wide2_nf<FT, OT, KS, EPI, 2, 256>(wa, s);
 #endif
