@@ -1275,7 +1275,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     }
-    constexpr int kAhead = EPI == SAF_QW_QUERY_MAX ? SAF_W2_AHEAD - 2 : SAF_W2_AHEAD;  // (the per-query maximum's chain state: 6 spilled 11 registers)
+#ifndef SAF_W3_AHEAD
+#define SAF_W3_AHEAD 4  // text fragments requested ahead of their MFMAs.  One box, ms (heat maps / row argmax / query max / scores): 2: 21.4 / 15.9 / 17.6 / 20.3,
+#endif                  // 3: 21.5 / 15.85 / 17.45 / 20.1, 4: 21.5 / 15.85 / 17.35 / 20.2, 6 (v2's): 21.6 / 16.3 / 17.8 / 20.3; 8 spills (25.3 / 15.7 / 18.8 / 20.5)
+    constexpr int kAhead = EPI == SAF_QW_QUERY_MAX ? SAF_W3_AHEAD - 1 : SAF_W3_AHEAD;  // (the per-query maximum's chain state)
     constexpr int AHEAD = KS < kAhead ? KS : kAhead;
     uint4 t[KS];  // fragment m = 2 s + qb
     const unsigned char* trow = curb + c * ROWB + 16 * g;

@@ -1098,11 +1098,15 @@ def test_failed_flush_never_stages_past_the_ring_and_never_fuses_twice():
     (torch.float16, 512, torch.float16, 1000, 203), (torch.bfloat16, 512, torch.bfloat16, 777, 64),
     (torch.float16, 256, torch.float32, 519, 33), (torch.bfloat16, 256, torch.float16, 256, 1000),
     (torch.float16, 512, torch.float32, 70000, 96)])  # more row blocks than CUs: the persistent loop wraps
-def test_wide_scan_v2_scores_and_epilogues(oracle, dt, dim, out_dt, n, q):
-    """64 rows per wave, one wave per SIMD: scores, the query_mesh softmax-vs-background column, the per-row argmax
-    and the per-query maximum against the oracle's double-precision scores of the SAME rounded operands.  Ragged
-    row / query counts, an all-zero row, tied queries, every output dtype."""
+@pytest.mark.parametrize("mfma", ["16", "32"])
+def test_wide_scan_v2_scores_and_epilogues(oracle, dt, dim, out_dt, n, q, mfma, monkeypatch):
+    """Both forms of the fused scan -- v_mfma_f32_16x16x32 (the default, query_wide3_kernel) and 32x32x16 (SAF_WIDE_MFMA=32,
+    query_wide2_kernel): scores, the query_mesh softmax-vs-background column, the per-row argmax and the per-query maximum
+    against the oracle's double-precision scores of the SAME rounded operands.  Ragged row / query counts, an all-zero row,
+    tied queries and rows (in other lanes and registers of either layout), every output dtype."""
     from spatially_aware_ai_amd.clipfusion import query_scan_wide
+
+    monkeypatch.setenv("SAF_WIDE_MFMA", mfma)
 
     g = torch.Generator().manual_seed(1234 + n)
     feats = torch.randn(n, dim, generator=g).to(dt)
