@@ -1060,7 +1060,7 @@ def side_workloads(a, device, L, frames_A, npy, npx):
         flop = 2.0 * n * d * n_q
         out[name] = {"value": round(q / kern, 1), "unit": "queries/s", "ms": round(kern * 1e3, 3),
                      "workload": f"{q} fp16 queries over {n} voxel rows x {d} (BASELINE config 5)",
-                     "roofline": {"kernel": "query_wide2_kernel", "bound": "mfma", "achieved": round(flop / kern / 1e12, 1),
+                     "roofline": {"kernel": "query_wide3_kernel", "bound": "mfma", "achieved": round(flop / kern / 1e12, 1),
                                   "peak": MFMA16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / kern / 1e12 / MFMA16_PEAK_TFLOPS, 4),
                                   "traffic": None, "algorithmic_bytes_per_launch": int(n * d * 2 + n_q * d * 2 + out_bytes)}}
 
@@ -1324,7 +1324,7 @@ def bench_query(a, world, rank, local_rank):
                                    f"voxel-sharded over {world} rank(s); a step = one scan of the whole volume writing the "
                                    f"[N, {q}] fp16 heat maps", "grid": a.grid, "feat_dim": d, "queries": q, "n_voxels": n_all,
                        "parallelism": f"voxels-shard{world}", "rccl_world": world, "backend": a.backend if world > 1 else None},
-            "roofline": dict(head["roofline"], kernel="query_wide2_kernel"),
+            "roofline": dict(head["roofline"], kernel="query_wide3_kernel"),
             "cases": cases,
             "cpu_baseline": query_cpu_baseline(a, feats_shape=(n_all, d), q=q + n_bg) if world == 1 and a.cpu_frames != 0 else None,
         }

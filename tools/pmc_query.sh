@@ -19,9 +19,9 @@ for d in "abc":
     acc = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(fs[-1])):
         kn = r["Kernel_Name"]
-        if "query_wide2_kernel" not in kn:
+        if "query_wide3_kernel" not in kn:
             continue
-        k = kn.split("query_wide2_kernel")[1].split("(")[0]
+        k = kn.split("query_wide3_kernel")[1].split("(")[0]
         acc[(k, r["Counter_Name"])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
     for (k, c), v in acc.items():
         out[k][c] = v / n[(k, c)]
@@ -30,8 +30,8 @@ for d in "abc":
     if ks:
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(ks[-1])):
-            if "query_wide2_kernel" in r["Kernel_Name"]:
-                dur[r["Kernel_Name"].split("query_wide2_kernel")[1].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            if "query_wide3_kernel" in r["Kernel_Name"]:
+                dur[r["Kernel_Name"].split("query_wide3_kernel")[1].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         for k, v in dur.items():
             out[k]["us_pass_" + d] = sum(v) / len(v)
 json.dump(out, open("$OUT/query_pmc.json", "w"), indent=1)
