@@ -289,10 +289,18 @@ __device__ __forceinline__ void w2_dma_rows(const uint16_t* sbase, uint32_t lane
                                      (__attribute__((address_space(3))) void*)(uintptr_t)(lds_addr + k * ROWB), 16, 0, 0);
 #endif
 }
+// One piece with a per-lane byte offset from a wave-uniform base (the next row block's rows: see query_wide3_kernel).
+__device__ __forceinline__ void w3_dma_piece(const uint16_t* sbase, uint32_t lane_off, uint32_t lds_addr) {
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_nop 0\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved) : "v"(lane_off), "s"(sbase), "s"(lds_addr) : "memory");
+}
 // `s_waitcnt vmcnt(n)` for a wave-uniform n known only at run time (the instruction takes an immediate): the largest listed
 // count <= n -- waiting for more than asked is always correct.
 __device__ __forceinline__ void w2_wait_vm(int n) {
-  if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -899,6 +907,9 @@ query_wide2_kernel(Wide2Args wa) {
 // 16-byte stores after v_permlane16_swap (the odd 16-lane rows of one operand against the even rows of the other).
 // ------------------------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifndef SAF_W3_PREFETCH
+#define SAF_W3_PREFETCH 1  // the next row block's first pieces through the LDS (query_wide3_kernel, kPref); 0: every row from HBM at the block change
+#endif
 
 template <int FT>
 __device__ __forceinline__ f32x4_t mfma32(const uint4& a, const uint4& b, const f32x4_t& c) {
@@ -1208,21 +1219,64 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int tail_ops = 0;
   int qt_run = 0;
   int64_t blk_run = blockIdx.x;
+  // The block change is the scan's largest idle stretch: every wave replaces its 32 KiB of rows at once, a CU pulls HBM at 20-25 GB/s
+  // (profiles/r05/gather_probe_movers.log), nothing computes meanwhile -- 2.9 of 15.4 ms (SAF_W3_NO_RELOAD).  The registers have no
+  // room for a second set, but the LDS has 93 KiB beside the two text tiles: kPref of a wave's 32 one-KiB pieces (piece p = row block
+  // p / S, k-step p % S: exactly register a[p / S][p % S] of every lane, lane-linear) of the NEXT block travel there by LDS-DMA while
+  // this block computes -- one piece per step, issued last in the step so that it is the step's youngest vector-memory operation and
+  // the counted wait in front of the next barrier lets it fly -- and the block change reads them back with ds_read_b128.
+  // Measured, one box, ms with / without (profiles/r05/wide_scan_prefetch_ab.txt): best voxel per query 16.9 / 17.45, raw scores
+  // 20.05 / 20.65 -- a third of the pieces, a sixth of what SAF_W3_NO_RELOAD suggests the block change costs (that ablation also feeds
+  // the matrix pipes constant operands, which raises the clock) --; row argmax 15.8 / 15.85 (its block change already overlaps the
+  // last tile's write-out), heat maps 21.8 / 21.7: those two keep loading every row at the block change.
+  constexpr int kPref = (kDma && SAF_W3_PREFETCH && (EPI == SAF_QW_SCORES || EPI == SAF_QW_QUERY_MAX)) ? 11 : 0;
+  constexpr uint32_t kPrefOff = 2 * kWTile * ROWB + 1024;  // behind the tiles and QUERY_MAX's 1 KiB of 1/norms
+  int pref_cnt = 0;       // pieces of the next block issued so far (wave-uniform)
+  bool pref_ok = false;   // the next block exists and all 32 rows of this wave's part of it do
+  const uint16_t* pref_base = wa.feats;
+  const bool pref_stride_ok = wa.fstride < ((int64_t)1 << 24);  // a lane's byte offset from its wave's first row fits 32 bits
+  const uint32_t pref_lds = lds_base + kPrefOff + (uint32_t)wave_u * (uint32_t)(kPref * 1024);
 
   auto step_body = [&](int64_t step, f32x4_t (&cacc)[2][2], const f32x4_t (&pacc)[2][2]) __attribute__((always_inline)) {
     const int qt = qt_run;
     qt_run = qt + 1 < n_qt ? qt + 1 : 0;
-    if (qt == 0) {  // a new row block: its rows per wave, register resident for every query tile
+#ifdef SAF_W3_NO_RELOAD  // (development: only the first block's rows are loaded -- wrong results, the scan without its block-change bubble)
+    if (qt == 0 && step > 0) {
       const int64_t blk = blk_run;
       blk_run += gridDim.x;
       const int64_t row0 = (blk * kWaves + wave) * kRows;
+      cur.row[0] = row0 + c; cur.row[1] = row0 + 16 + c;
+    }
+    if (qt == 0 && step == 0) {
+#else
+    if (qt == 0) {  // a new row block: its rows per wave, register resident for every query tile
+#endif
+      const int64_t blk = blk_run;
+      blk_run += gridDim.x;
+      const int64_t row0 = (blk * kWaves + wave) * kRows;
+      // pieces of this block that the block before sent to the LDS (none for the first block).  They are old -- the last one was
+      // issued kPref steps into that block and every later step waited for operations younger than it -- unless the block is short
+      const int ready = pref_ok ? pref_cnt : 0;
+      if (kPref && ready > 0 && n_qt < kPref + 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         cur.row[rb] = row0 + 16 * rb + c;
         const int64_t rr = cur.row[rb] < wa.n_rows ? cur.row[rb] : wa.n_rows - 1;  // padded lanes recompute the last row
         const uint16_t* pa = wa.feats + rr * wa.fstride + 8 * g;
 #pragma unroll
-        for (int s = 0; s < S; ++s) a[rb][s] = ld_stream_u4(pa + 32 * s);
+        for (int s = 0; s < S; ++s) {
+          const int p = rb * S + s;
+          if (p < kPref && p < ready)
+            a[rb][s] = *reinterpret_cast<const uint4*>(s_tiles + kPrefOff + (size_t)(wave * kPref + p) * 1024 + lane * 16);
+          else
+            a[rb][s] = ld_stream_u4(pa + 32 * s);
+        }
+      }
+      if (kPref) {  // the block after this one
+        const int64_t row0n = (blk_run * kWaves + wave_u) * kRows;  // (wave-uniform by construction: the transfer's base lives in SGPRs)
+        pref_ok = pref_stride_ok && blk_run < n_blocks && row0n + kRows <= wa.n_rows;
+        pref_base = wa.feats + (pref_ok ? row0n : 0) * wa.fstride;
+        pref_cnt = 0;
       }
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
@@ -1331,6 +1385,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       tail_ops = 0;
 #endif
     }
+    if (kPref && pref_ok && qt >= 1 && pref_cnt < kPref) {
+      // one piece of the next block's rows, the step's youngest operation (see kPref)
+      const int rbp = pref_cnt >= S ? 1 : 0, sp = pref_cnt - rbp * S;
+      const uint32_t lane_off = (uint32_t)((16 * rbp + c) * (int)wa.fstride + 32 * sp + 8 * g) * 2u;
+      w3_dma_piece(pref_base, lane_off, pref_lds + (uint32_t)pref_cnt * 1024u);
+      ++pref_cnt;
+      tail_ops += 1;
+    }
     if (EPI == SAF_QW_QUERY_MAX && qt == 0) {
       // the new block's 1/norms, by row of the wave -- only now: this step's epilogue was the LAST tile of the block before
 #pragma unroll
@@ -1432,7 +1494,9 @@ int launch_wide2_nf(const Wide2Args& wa, hipStream_t s) {
 
 template <int FT, int OT, int KS, int EPI>
 int launch_wide3(const Wide2Args& wa, hipStream_t s) {
-  constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16) + (EPI == SAF_QW_QUERY_MAX ? 8 * 32 * sizeof(float) : 0);
+  // two text tiles, 1 KiB of 1/norms (QUERY_MAX), and at D = 512 eleven 1 KiB pieces per wave of the next block's rows (kPref)
+  constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16) + 1024 +
+                           ((KS == 32 && SAF_W3_PREFETCH && (EPI == SAF_QW_SCORES || EPI == SAF_QW_QUERY_MAX)) ? 8 * 11 * 1024 : 0);
   auto fn = query_wide3_kernel<FT, OT, KS, EPI>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
