@@ -1045,7 +1045,7 @@ def side_workloads(a, device, L, frames_A, npy, npx):
         feats16[s0:s0 + (1 << 20)] = torch.randn((min(1 << 20, n - s0), d), generator=g, device=device).half()
     text = torch.randn((n_bg + q, d), generator=torch.Generator().manual_seed(9))
     text = (text / text.norm(dim=-1, keepdim=True)).to(device)
-    big = torch.empty((n, (q + 7) // 8 * 8), dtype=torch.float16, device=device)[:, :q]
+    big = torch.empty((n, (q + 63) // 64 * 64), dtype=torch.float16, device=device)[:, :q]  # (rows padded to whole 128-byte lines, as query_scan_wide allocates its own output)
 
     def scan_case(name, fn, n_q, out_bytes):
         fn()

@@ -679,7 +679,7 @@ def query_scan_wide(feats, text, epilogue="scores", scale=1.0, normalize=True, n
     * ``"query_max"``      -> (value f32 [Q], row int64 [Q]): best row per query, rows numbered from ``row_offset``
 
     ``out``: an optional preallocated [N, columns] tensor for the two matrix-valued epilogues (row stride a multiple
-    of 8 elements keeps the 16-byte stores of the epilogue aligned).
+    of 8 elements keeps the 16-byte stores of the epilogue aligned; a multiple of 128 bytes is 3-4 % faster at many columns).
     """
     require_cuda(feats, "features")
     if feats.dtype not in (torch.float16, torch.bfloat16) or feats.dim() != 2:
@@ -712,8 +712,12 @@ def query_scan_wide(feats, text, epilogue="scores", scale=1.0, normalize=True, n
     if epi in (_abi.SAF_QW_SCORES, _abi.SAF_QW_VS_BACKGROUND):
         cols = q - (int(n_background) if epi == _abi.SAF_QW_VS_BACKGROUND else 0)
         if out is None:
-            # rows padded to a multiple of 8 columns keep every 16-byte store of the epilogue aligned
-            stride = (cols + 7) // 8 * 8
+            # rows padded to a multiple of 8 columns keep every 16-byte store of the epilogue aligned; wide outputs are padded to
+            # whole 128-byte lines (a tile's 64-byte segment then never straddles two lines: 3-4 % of the scan at 1000 columns,
+            # tools/probe_out_stride.py).  The result is the [:, :cols] view
+            esz = torch.empty((), dtype=out_dtype).element_size()
+            per_line = 128 // esz
+            stride = (cols + per_line - 1) // per_line * per_line if cols >= 4 * per_line else (cols + 7) // 8 * 8
             out = torch.empty((n, stride), dtype=out_dtype, device=dev)[:, :cols]
         else:
             require_cuda(out, "out")

@@ -8,11 +8,13 @@ B="python3 bench.py --query --query-wide-only --steps 2 --warmup 1 --cpu-frames 
 run() { name=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- $B > $OUT/$name.json 2> $OUT/$name.err || echo "FAILED $name"; }
 run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES &&
 run b GRBM_GUI_ACTIVE GRBM_COUNT &&
-run c SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM
+run c SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM &&
+run d FETCH_SIZE &&   # HBM bytes (KiB; x 2 on gfx950 for FETCH_SIZE: MI355X_MICROARCH.md), separate passes
+run e WRITE_SIZE
 python3 - <<PY
 import csv, glob, json, collections, os
 out = collections.defaultdict(dict)
-for d in "abc":
+for d in "abcde":
     fs = sorted(glob.glob("$OUT/%s/*/*_counter_collection.csv" % d), key=os.path.getmtime)
     if not fs:
         continue
