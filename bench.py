@@ -1262,7 +1262,7 @@ def bench_query(a, world, rank, local_rank):
                              "hbm_GBps_of_algorithmic_bytes": round((n * d * 2 + out_bytes) / kern / 1e9, 1)}}
 
     keep = {}
-    qs = (q + 7) // 8 * 8
+    qs = (q + 63) // 64 * 64  # rows padded to whole 128-byte lines (query_scan_wide allocates its own output the same way)
     big = torch.empty((n, qs), dtype=torch.float16, device=device)[:, :q]  # the N x Q output, allocated once
 
     def heat_maps():
