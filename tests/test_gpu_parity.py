@@ -1405,6 +1405,38 @@ def test_slab_by_slab_fusion_equals_the_whole_volume(seem):
             assert s1[k] == s2[k], (mode, k, s1, s2)
 
 
+def test_wide_scan_forms_agree_on_random_shapes(monkeypatch):
+    """The two forms of the fused scan (v_mfma_f32_16x16x32, the default, and 32x32x16) on random shapes -- rows, queries, width,
+    input and output types, number of backgrounds --: matrix outputs equal to the output type's rounding, the reductions' values
+    to fp32 rounding and the same winners (tools/fuzz_wide.py is the longer run of the same check)."""
+    from spatially_aware_ai_amd.clipfusion import query_scan_wide
+
+    g = torch.Generator().manual_seed(11)
+    pick = lambda xs: xs[int(torch.randint(0, len(xs), (1,), generator=g))]
+    for it in range(8):
+        d, dt = pick([256, 512]), pick([torch.float16, torch.bfloat16])
+        odt = pick([torch.float16, torch.bfloat16, torch.float32])
+        n = int(torch.randint(1, 90000, (1,), generator=g))
+        q = int(torch.randint(2, 300, (1,), generator=g))
+        n_bg = int(torch.randint(1, min(q - 1, 32) + 1, (1,), generator=g))
+        feats = torch.randn(n, d, generator=g).to(dt).cuda()
+        text = torch.randn(q, d, generator=g)
+        text = (text / text.norm(dim=-1, keepdim=True)).cuda()
+        res = {}
+        for form in ("16", "32"):
+            monkeypatch.setenv("SAF_WIDE_MFMA", form)
+            res[form] = (query_scan_wide(feats, text, "scores", out_dtype=odt).float(),
+                         query_scan_wide(feats, text, "vs_background", scale=100.0, n_background=n_bg, rescale=bool(it & 1), out_dtype=odt).float(),
+                         query_scan_wide(feats, text, "row_argmax"), query_scan_wide(feats, text, "query_max", row_offset=it))
+        a, b = res["16"], res["32"]
+        tol = {torch.float32: 2e-5, torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}[odt]
+        what = (it, n, q, d, dt, odt, n_bg)
+        assert (a[0] - b[0]).abs().max().item() <= tol, what
+        assert (a[1] - b[1]).abs().max().item() <= max(tol, 3e-3), what
+        assert (a[2][1] - b[2][1]).abs().max().item() <= 2e-5 and (a[2][0] == b[2][0]).float().mean().item() > 0.995, what
+        assert (a[3][0] - b[3][0]).abs().max().item() <= 2e-5 and (a[3][1] == b[3][1]).float().mean().item() > 0.97, what
+
+
 @pytest.mark.parametrize("n,q,dt", [(5000, 7, torch.float16), (70001, 32, torch.bfloat16), (300, 1, torch.float16)])
 def test_wide_scan_single_query_tile(n, q, dt):
     """n_text <= 32: one query tile, so EVERY step of the scan's persistent loop is a row-block change (rows reloaded, the same tile
