@@ -339,7 +339,14 @@ class _FusionVolumeMixin:
         self._sync_volume()
 
     def _sync_volume(self):
-        self._flush_pending()
+        # the frames flushed HERE are the last before somebody looks: if the deferred clear of reset() is still owed, their call
+        # zeroes the unwritten rows beside its last row kernel (_fuse_now).  Flushes the queue starts on its own keep owing it -- a
+        # scan of several flushes would otherwise zero, after its first window, most of a volume that the later windows write
+        self.__dict__["_finishing"] = True
+        try:
+            self._flush_pending()
+        finally:
+            self.__dict__["_finishing"] = False
         if self.__dict__.get("_feat_stale"):
             # reset() did not clear the feature rows: zero the ones that are still unwritten (weight 0)
             self.__dict__["_feat_stale"] = False
@@ -444,8 +451,10 @@ class _FusionVolumeMixin:
         ws = self._get_workspace(npy, npx, (int(depth_imgs.shape[1]), int(depth_imgs.shape[2])))
         # after a lazy reset() the feature rows still hold the previous scan: saf_fuse_frames_recycled fuses and leaves every row
         # of a voxel that is still unwritten zero (beside the last window's row kernel; before the per-frame pipeline, which
-        # reads the rows it updates)
+        # reads the rows it updates).  Used for the per-frame pipeline and for the flush behind which somebody looks
         stale = bool(self.__dict__.get("_feat_stale"))
+        if stale and not self.__dict__.get("_finishing") and lib().saf_fuse_path(C.byref(vol), arr, len(arr), ws.numel()) == 1:
+            stale = False  # the windowed path never reads a weight-0 row: the clear stays owed until somebody looks (_sync_volume)
         # the module's device, not the caller's current one, owns the launch (and its current stream)
         dev = self._buffers["tsdf"].device
         with torch.cuda.device(dev):
@@ -458,7 +467,7 @@ class _FusionVolumeMixin:
                 rc = lib().saf_fuse_frames(
                     C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), stream.cuda_stream
                 )
-            if stale and rc == 0:
+            if stale and rc == 0:  # (the recycled call: every weight-0 row is zero behind it)
                 self.__dict__["_feat_stale"] = False
             # SAF_E_INVALID / _WORKSPACE / _UNSUPPORTED come from the checks at the entry (every frame descriptor is validated
             # before the first launch); a HIP error may have left some windows fused (see _flush_pending)
