@@ -254,8 +254,9 @@ __global__ __launch_bounds__(256) void stage_frame_kernel(StageArgs a) {
 // time and writes zeros only where needed (after a 512-frame scan: almost nowhere).
 // Round 5: on a coherent scene most rows ARE unwritten (83 % at 256^3: 28 GB of zeros, a fifth of the job).  The zeros leave as
 // ONE 16-byte store per lane -- a native vector type: HIP's `uint4` (a struct around a union) assigned from make_uint4 compiled
-// to narrower stores and the kernel wrote at half the rate of a memset (3.4 against 6.8 TB/s; now 5.4: tools/probe_clear_rate.py;
-// rows per wave and iteration, nontemporal stores and the grid size were swept and change nothing).
+// to narrower stores and the kernel wrote at half the rate of a memset (3.4 against 6.8 TB/s; now 5.4-5.6: tools/probe_clear_rate.py;
+// rows per wave and iteration, nontemporal stores, the grid size up to one workgroup per 256 rows, and whole runs of 64 or 256
+// unwritten rows written linearly by the wave / the workgroup without the per-row bookkeeping were measured and change nothing).
 // `masks` (may be NULL): the hit masks of a window whose row kernel may be running beside this kernel -- n_planes planes of one
 // word per voxel; a voxel with a bit set is that kernel's to write (it does not read the old row of a weight-0 voxel either).
 template <int ESZ>
