@@ -194,8 +194,11 @@ __device__ __forceinline__ float half_sum(float x) {
 
 constexpr int kQGroup = 8;  // K chunks (of 8 floats) per prefetch group: 64 floats of every row
 
-template <int EPI, int FT, int TILES>
-__global__ __launch_bounds__(kQThreads) void query_mfma_kernel(const void* __restrict__ feats, int64_t n_rows,
+// TH threads per workgroup: 256, or 512 where the text tiles leave room for only ONE workgroup per CU (two 32-row tiles at D = 512:
+// 132 KB) -- four waves would be one per SIMD, each alone with its loads, LDS reads and MFMA chain: the L = 63 surgery scan over
+// the 256^3 x 512 fp32 volume 14.8 -> 12.0 ms (tools/q_threads_ab.sh); 1024 threads spill (128 registers) and are slower (12.6).
+template <int EPI, int FT, int TILES, int TH>
+__global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__ feats, int64_t n_rows,
                                                                 int64_t fstride, int D, const float* __restrict__ text,
                                                                 int L, int64_t tstride, float scale, int normalize,
                                                                 const float* __restrict__ wts, float* __restrict__ out,
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(kQThreads) void query_mfma_kernel(const void* __res
   extern __shared__ __attribute__((aligned(16))) float s_text[];  // [TILES*32][D + 4], rows >= L are zero
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tstr = D + 4;
-  for (int i = tid; i < TILES * 32 * D; i += kQThreads) {
+  for (int i = tid; i < TILES * 32 * D; i += TH) {
     const int n = i / D, k = i - n * D;
     s_text[n * tstr + k] = n < L ? text[(int64_t)n * tstride + k] : 0.0f;
   }
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kQThreads) void query_mfma_kernel(const void* __res
   const int m = lane & 31, h = lane >> 5;
   const int n_groups = D / (8 * kQGroup);  // full prefetch groups; the remainder is handled chunk by chunk
   const int64_t n_tiles = (n_rows + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * kQWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kQWaves) {
+  for (int64_t tile = (int64_t)blockIdx.x * (TH / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (TH / 64)) {
     int64_t row = tile * 32 + m;
     if (row >= n_rows) row = n_rows - 1;  // padded lanes recompute the last row, never stored
     const int64_t base = row * fstride + 4 * h;
@@ -328,24 +331,35 @@ __global__ __launch_bounds__(kQThreads) void query_mfma_kernel(const void* __res
   }
 }
 
-template <int EPI, int FT, int TILES>
-int launch_mfma_t(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
-                  float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s) {
-  const size_t shmem = (size_t)TILES * 32 * (D + 4) * sizeof(float);
-  auto fn = query_mfma_kernel<EPI, FT, TILES>;
+template <int EPI, int FT, int TILES, int TH>
+int launch_mfma_th(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
+                   float scale, int normalize, const float* wts, float* out, float* out_last, int per_cu, size_t shmem, hipStream_t s) {
+  auto fn = query_mfma_kernel<EPI, FT, TILES, TH>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)shmem);
     if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const int per_cu = (int)((160 * 1024) / (shmem + 256)) > 2 ? 2 : (int)((160 * 1024) / (shmem + 256));
-  int64_t blocks = ((n_rows + 31) / 32 + kQWaves - 1) / kQWaves;
+  constexpr int kWavesTh = TH / 64;
+  int64_t blocks = ((n_rows + 31) / 32 + kWavesTh - 1) / kWavesTh;
   const int64_t cap = (int64_t)device_cus() * (per_cu < 1 ? 1 : per_cu);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kQThreads), shmem, s, feats, n_rows, fstride, D, text, L,
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(TH), shmem, s, feats, n_rows, fstride, D, text, L,
                      tstride, scale, normalize, wts, out, out_last);
   return check_launch("query_mfma_kernel");
+}
+
+template <int EPI, int FT, int TILES>
+int launch_mfma_t(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
+                  float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s) {
+  const size_t shmem = (size_t)TILES * 32 * (D + 4) * sizeof(float);
+  const int per_cu = (int)((160 * 1024) / (shmem + 256)) > 2 ? 2 : (int)((160 * 1024) / (shmem + 256));
+  // SAF_Q_THREADS (read per call; development): 256 or 512 threads per workgroup whatever the tiles leave room for
+  const char* th_env = getenv("SAF_Q_THREADS");
+  const bool wide = th_env ? atoi(th_env) == 512 : per_cu <= 1;
+  return wide ? launch_mfma_th<EPI, FT, TILES, 512>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s)
+              : launch_mfma_th<EPI, FT, TILES, 256>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s);
 }
 
 // true if the MFMA scan can take this shape
