@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--depth-kind", default="A", choices=["A", "B", "Z"],
                     help="A: iid depth per pixel (the worst case); B: a coherent analytic scene; Z: no valid depth (nothing hits: the fixed cost)")
+    ap.add_argument("--pose-kind", default="look_at", choices=["look_at", "free"],
+                    help="look_at: SURVEY 8d's cameras (no roll, centred isotropic K); free: rolled / off-centre cameras with fx != fy "
+                         "(synthetic.family_pose): what a hand-held scan's poses look like (clipfusion.py:308-312)")
     ap.add_argument("--unique-frames", type=int, default=512,
                     help="distinct synthetic frames resident per rank (cycled to --frames)")
     ap.add_argument("--merge", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
@@ -129,13 +132,19 @@ def parse():
     return a
 
 
-def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device):
+def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device, pose_kind="look_at"):
     """n frames resident on the device.  Poses/intrinsics come from the seeded CPU generator of
-    synthetic.py; the bulky per-pixel data is drawn on the device (seeded) to keep start-up short."""
+    synthetic.py; the bulky per-pixel data is drawn on the device (seeded) to keep start-up short.
+    pose_kind "free": the camera family real scans have (synthetic.family_pose / family_intrinsics: look-at the origin or an
+    off-centre target, ROLLED by U(-pi, pi) about the view axis; fx != fy, principal point up to 20 % off the centre)."""
     gen = torch.Generator().manual_seed(seed)
     poses, ks = [], []
-    for _ in range(n):
+    for i in range(n):
         c = torch.randn(3, generator=gen)
+        if pose_kind == "free":
+            poses.append(syn.family_pose(gen, c / c.norm() * 2.5, ("roll", "target")[i % 2]))
+            ks.append(syn.family_intrinsics(gen, width, height))
+            continue
         poses.append(syn.look_at_pose(c / c.norm() * 2.5))
         ks.append(syn.intrinsics(width, height))
     poses = torch.stack(poses).to(device)
@@ -147,6 +156,8 @@ def gen_frames_gpu(n, width, height, dim, npy, npx, depth_kind, seed, device):
         depth = torch.zeros((n, height, width), device=device)
     else:
         depth = torch.stack([syn._analytic_depth(p, k, width, height) for p, k in zip(poses, ks)])
+        if pose_kind == "free":  # (a ray that leaves the room backwards: no depth)
+            depth = torch.where(torch.isfinite(depth) & (depth > 0), depth, torch.zeros_like(depth))
     rgb = torch.rand((n, height, width, 3), generator=g, device=device)
     feat = torch.randn((n, dim, npy, npx), generator=g, device=device)
     return depth, rgb, poses, ks, feat
@@ -278,7 +289,7 @@ def main():
 
     uniq = min(a.unique_frames, a.frames)
     depth, rgb, poses, ks, feat = gen_frames_gpu(uniq, a.width, a.height, a.dim, npy, npx, a.depth_kind,
-                                                 1000 + rank, device)
+                                                 1000 + rank, device, pose_kind=a.pose_kind)
     label_maps = None
     if a.labels:
         if a.label_kind == "world":
@@ -769,7 +780,7 @@ def main():
 
     # ---- the other configurations and the copy rate of this box, measured in this run (rank 0, N = 1) ----
     side, copy_rate = None, None
-    if rank == 0 and world == 1 and not a.no_side and isinstance(a.grid, int) and a.grid == 256 and a.depth_kind == "A" and not a.labels \
+    if rank == 0 and world == 1 and not a.no_side and isinstance(a.grid, int) and a.grid == 256 and a.depth_kind == "A" and a.pose_kind == "look_at" and not a.labels \
             and a.feat_dtype == "f32" and a.width == 640 and a.height == 480:
         copy_rate = hbm_copy_rate(device)
         side = side_workloads(a, device, L, (depth, rgb, poses, ks, feat), npy, npx)
@@ -805,7 +816,7 @@ def main():
             "dtype": a.feat_dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{a.frames} frames/rank {a.width}x{a.height} depth-{a.depth_kind}, per-rank "
+                "workload": f"{a.frames} frames/rank {a.width}x{a.height} depth-{a.depth_kind}{' free (rolled, fx != fy) poses' if a.pose_kind == 'free' else ''}, per-rank "
                             f"{a.grid}^3x{a.dim} {a.feat_dtype} grid{' + panoptic label histogram' if a.labels else ''}, frames sharded, "
                             + ((f"one {a.backend} {merge_state['mode']} merge per step, "
                                 + ("issued slab by slab behind the fusion" if headline_region == "slab_pipelined_merge"
@@ -1036,6 +1047,11 @@ def side_workloads(a, device, L, frames_A, npy, npx):
     fuse_case("coherent_scene_depth_B", 256, torch.float32, False, frames_B,
               "the headline job on the coherent analytic scene (sphere in a box, SURVEY 8d depth B): 512 frames (128 unique), 256^3 x 512 fp32")
     del frames_B
+    frames_F = gen_frames_gpu(nb, a.width, a.height, a.dim, npy, npx, "B", 2001, device, pose_kind="free")
+    fuse_case("coherent_scene_free_poses", 256, torch.float32, False, frames_F,
+              "the coherent scene seen by ROLLED cameras with fx != fy and an off-centre principal point (synthetic.family_pose: "
+              "the poses of a hand-held scan, clipfusion.py:308-312): 512 frames (128 unique), 256^3 x 512 fp32")
+    del frames_F
 
     # ---- config 5: 1000 fp16 queries over the 256^3 x 512 volume
     n, d, q, n_bg = 256 ** 3, a.dim, 1000, 4

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAF_ABI_VERSION 2
+#define SAF_ABI_VERSION 3
 
 enum saf_status {
   SAF_OK = 0,
@@ -91,15 +91,22 @@ typedef struct saf_frame {
   int32_t rgb_bilinear;   /* 0: nearest (clipfusion.py:701-706); 1: bilinear (clip_seem_fusion.py:793-798) */
 } saf_frame;
 
-/* Counters the fuse kernels add to (device memory, 8 x u64, caller zeroes them when it wants):
+/* Counters the fuse kernels add to (device memory, SAF_STATS_WORDS x u64 -- 16 since ABI version 3, 8 before --, caller zeroes
+ * them when it wants):
  *  [0] sum of Nv (valid voxels)  [1] sum of Nt (tsdf-valid voxels)  [2] frames fused
  *  [3] labels outside [0,n_classes) that were dropped (the reference raises instead)
  *  [4] fuse workgroups that gave up waiting for their frame's sweep (must stay 0)
  *  [5] feature rows read-modify-written by window kernels (= sum over windows of |union of valid sets|;
  *      0 when the per-frame pipeline ran)  [6] voxels whose TSDF a window's classification updated
  *      (sum over windows of |union of tsdf-valid sets|)  [7] disagreements between the classification's guarded pixel path and
- *      the reference's chain, counted only with SAF_CLS_VERIFY=1 in the environment (a self-check; must stay 0) */
-#define SAF_STATS_WORDS 8
+ *      the reference's chain, counted only with SAF_CLS_VERIFY=1 in the environment (a self-check; must stay 0)
+ *  [8..12] the windowed path's frame cull (a wave tests its 4 x 4 x 16-voxel brick against the 32 frames of a classification
+ *      launch before it classifies any voxel; clipfusion.py:647-679 has no counterpart -- it projects every voxel into every
+ *      frame): [8] (brick, frame) pairs tested, and of those dropped because the brick lies [9] behind the camera, [10]
+ *      farther than the frame's largest depth + trunc, [11] outside the view frustum, [12] more than trunc behind the largest
+ *      depth of the pixels it projects onto (occluded).  A dropped pair has no valid and no tsdf-valid voxel; tests assert that
+ *      every reason fires on the cameras they fuzz.  [13..15] reserved (0). */
+#define SAF_STATS_WORDS 16
 /* frames per window of the windowed path of saf_fuse_frames (stats[5] and [6] count per window); SAF_WIN_FRAMES=64 in the
  * environment selects 64-frame windows */
 #define SAF_WINDOW_FRAMES 128

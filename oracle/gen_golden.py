@@ -274,6 +274,84 @@ def gen_fusion_c1(ref_cf, out_dir):
     print("config-1 digest: Nv/frame", np.mean(nv), "Nt/frame", np.mean(nt))
 
 
+def cameras_scenario():
+    """The camera-family fixture's inputs (regenerated from the seed by the tests): 48 frames 80 x 60 into 44 x 40 x 48 voxels."""
+    from spatially_aware_ai_amd import synthetic as syn
+
+    W, H = 80, 60
+    npy, npx = syn.feature_map_shape(W, H)
+    grid = syn.make_grid((44, 40, 48), side=2.2)
+    return grid, (W, H, npy, npx), 48, 20241006
+
+
+def gen_fusion_cameras(ref_cf, ref_csf, out_dir):
+    """ClipFusion (D = 256: the windowed row kernel's width) and ClipSeemFusion (D = 64, labels: the brick form's) on the camera
+    family real scans have -- rolled / pitched / arbitrary orientations, fx != fy, principal point off the centre
+    (clipfusion.py:308-312, :647-659) -- which every other fusion fixture avoids (look-at poses without roll, centred
+    isotropic K).  Digests in the style of the config-1 fixture: per-frame counts, full index sets, sampled rows."""
+    from spatially_aware_ai_amd import synthetic as syn
+
+    grid, (W, H, npy, npx), n_frames, seed = cameras_scenario()
+    cur = {}
+    rec = {}
+    for tag, D, seem in (("cf", 256, False), ("seem", 64, True)):
+        frames = syn.make_family_frames(seed, n_frames, W, H, D, npy, npx)
+        if seem:
+            class FakeClip:
+                feature_dim = D
+
+                def img_inference_tiled(self, rgb, patch_size, patch_stride):
+                    return cur["feat"]
+
+            class FakeSeg:
+                def run_on_image(self, rgb_chw):
+                    return cur["labels"]
+
+            fusion = ref_csf.ClipSeemFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, 20, 10, FakeClip(), FakeSeg())
+        else:
+            ref_cf.Clip.feature_dim = D
+            fusion = ref_cf.ClipFusion(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, False, "stub", "stub", 20, 10)
+            fusion.n_clip_feats = D
+            fusion.clip_feat = torch.zeros(grid.n_voxels, D)
+            fusion.clip.img_inference_tiled = lambda rgb, patch_size, patch_stride: cur["feat"]
+        nv, nt, in_digest = [], [], []
+        for i, f in enumerate(frames):
+            cur["feat"], cur["labels"] = f["feat"], f["labels"]
+            w0, t0 = fusion.weight.clone(), fusion.tsdf_weight.clone()
+            fusion.integrate(f["depth"], f["rgb"], f["pose"], f["K"])
+            nv.append(int((fusion.weight - w0).sum()))
+            nt.append(int((fusion.tsdf_weight - t0).sum()))
+            in_digest.append([float(f["depth"].double().sum()), float(f["feat"].double().sum()), float(f["pose"].double().sum()),
+                              float(f["K"].double().sum())])
+            if i + 1 in (n_frames // 4, n_frames // 2):
+                rec[f"{tag}_weight_{i + 1}"] = fusion.weight.numpy().astype(np.uint8)
+                rec[f"{tag}_tsdf_weight_{i + 1}"] = fusion.tsdf_weight.numpy().astype(np.uint8)
+        g = torch.Generator().manual_seed(11)
+        touched = torch.nonzero(fusion.weight > 0)[:, 0]
+        rows = touched[torch.randperm(len(touched), generator=g)[:512]].sort().values
+        rec.update({
+            f"{tag}_nv": np.array(nv), f"{tag}_nt": np.array(nt), f"{tag}_in_digest": np.array(in_digest),
+            f"{tag}_weight": fusion.weight.numpy().astype(np.uint8), f"{tag}_tsdf_weight": fusion.tsdf_weight.numpy().astype(np.uint8),
+            f"{tag}_tsdf": fusion.tsdf.numpy().copy(),
+            f"{tag}_clip_col_sum": fusion.clip_feat.double().sum(0).numpy(),
+            f"{tag}_clip_abs_sum": np.float64(fusion.clip_feat.double().abs().sum()),
+            f"{tag}_rgb_col_sum": fusion.rgb.double().sum(0).numpy(),
+            f"{tag}_rows": rows.numpy(), f"{tag}_clip_rows": fusion.clip_feat[rows].numpy(), f"{tag}_rgb_rows": fusion.rgb[rows].numpy(),
+        })
+        if seem:
+            t = fusion.labels_one_hot
+            any_nonzero = t.any(dim=1)
+            mi = torch.argmax(t, dim=1)
+            mi *= any_nonzero
+            mi -= (~any_nonzero).long()
+            rec["seem_onehot_to_index"] = mi.numpy().astype(np.int16)
+            rec["seem_label_rows"] = t[rows].numpy().astype(np.int8)
+            rec["seem_label_col_sum"] = t.long().sum(0).numpy()
+        print(f"camera family ({tag}): Nv/frame", np.mean(nv), "Nt/frame", np.mean(nt), "frames without a valid voxel",
+              int((np.array(nv) == 0).sum()), "touched rows", len(touched))
+    np.savez_compressed(os.path.join(out_dir, "fusion_cameras_digest.npz"), **rec)
+
+
 class _ListDataset(torch.utils.data.Dataset):
     """Yields the reference loaders' 5-tuple (clipfusion.py:190)."""
 
@@ -649,6 +727,7 @@ def main():
     gen_backproject(ref_cf, args.out)
     gen_query(ref_cf, args.out)
     gen_fusion_c1(ref_cf, args.out)
+    gen_fusion_cameras(ref_cf, ref_csf, args.out)
     gen_extract_mesh(ref_cf, ref_csf, args.out)
     gen_label_components(args.out)
     gen_tiled_clip(ref_cf, args.out)

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SAF_OK = 0
 SAF_E_INVALID = -1
@@ -19,7 +19,7 @@ SAF_RUNNING_MEAN, SAF_SUM = 0, 1
 SAF_Q_SCORES, SAF_Q_SOFTMAX, SAF_Q_SURGERY = 0, 1, 2
 SAF_NORM_NONE, SAF_NORM_L2, SAF_NORM_L2_CLAMP = 0, 1, 2
 SAF_QW_SCORES, SAF_QW_VS_BACKGROUND, SAF_QW_ROW_ARGMAX, SAF_QW_QUERY_MAX = 0, 1, 2, 3
-SAF_STATS_WORDS = 8
+SAF_STATS_WORDS = 16
 SAF_WINDOW_FRAMES = 128
 
 _fp = C.c_void_p  # every data pointer travels as an integer address

@@ -141,7 +141,8 @@ class _FusionVolumeMixin:
         tsdf = self._buffers["tsdf"]
         n = tsdf.numel()
         # for THIS volume (width, dtype, SAF_WIN_FORM): the brick form's 6.5 GB of segment pools only where it would run
-        if hw is not None and n >= (1 << 20):
+        # (SAF_TILED_MIN_VOXELS, read per call: the tests ask for the tiled copies on small volumes)
+        if hw is not None and n >= int(os.environ.get("SAF_TILED_MIN_VOXELS", 1 << 20)):
             need = lib().saf_fuse_workspace_bytes_for_frames(C.byref(self._c_volume(for_fuse=True)), int(npy), int(npx),
                                                              int(hw[0]), int(hw[1]))
         else:
@@ -516,8 +517,10 @@ class _FusionVolumeMixin:
         form = {"s": "sums", "r": "rows", "b": "bricks"}.get(form[:1], "sums")
         if form == "sums" and self._buffers["clip_feat"].dtype == torch.bfloat16:
             form = "rows (SAF_WIN_MAPS16=0)" if os.environ.get("SAF_WIN_MAPS16", "1")[:1] == "0" else "sums, bf16 map images"
+        # the windowed path's frame cull: (brick, frame) pairs tested / dropped by reason (include/saf.h, stats[8..12])
+        cull = {"pairs": s[8], "behind": s[9], "far": s[10], "frustum": s[11], "occluded": s[12]}
         return {"valid": s[0], "tsdf_valid": s[1], "frames": s[2], "labels_dropped": s[3], "window_rows": s[5],
-                "window_tsdf_voxels": s[6], "window_form": form}
+                "window_tsdf_voxels": s[6], "window_form": form, "cull": cull}
 
     def sample_mesh_vertices(self, verts_index, voxel_obj_idx=None, objects_segmentation_color=None):
         """The sampling half of ``extract_mesh`` (reference clipfusion.py:741-760, clip_seem_fusion.py:843-878)

@@ -416,6 +416,7 @@ __global__ __launch_bounds__(BUILD ? kBuildThreads : kBThreads) __attribute__((a
       if (c) atomicAdd(&stats[0], c);
       if (d) atomicAdd(&stats[5], d);
     }
+    fold_cull_shards(cls_acc, stats, tid);
   }
   const Cam ucam = load_cam(tab->pose[0], tab->K[0], wa.W, wa.H);  // its image-size terms are the same for every frame
   const int n_pass = v.D / kSlabCh;

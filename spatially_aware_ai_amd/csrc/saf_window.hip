@@ -404,8 +404,11 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
 // two addresses per launch -- they serialise in L2 and took 0.7 ms of a 1.8 ms kernel.  The four waves of a
 // workgroup are summed in LDS and added to one of 64 shards in the workspace header; the window's row kernel
 // folds the shards into stats[].
-__device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsigned long long tsdf_rows_done, int lane, int wave,
-                                               unsigned long long (&s_acc)[4][2], unsigned long long* __restrict__ cls_acc) {
+// `cull`: the wave's (brick, frame) pairs {tested, behind, far, outside the frustum, occluded} (wave-uniform; round 6): the same
+// route, 16 shards of five words behind the frame table -- thread k + 1 of the workgroup adds word k.
+__device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsigned long long tsdf_rows_done, const uint32_t (&cull)[kCullWords],
+                                               int lane, int wave, unsigned long long (&s_acc)[4][2], uint32_t (&s_cull)[4][kCullWords],
+                                               unsigned long long* __restrict__ cls_acc) {
   for (int o = 32; o > 0; o >>= 1) {
     nt_done += __shfl_xor(nt_done, o);
     tsdf_rows_done += __shfl_xor(tsdf_rows_done, o);
@@ -413,6 +416,8 @@ __device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsig
   if (lane == 0) {
     s_acc[wave][0] = nt_done;
     s_acc[wave][1] = tsdf_rows_done;
+#pragma unroll
+    for (int k = 0; k < kCullWords; ++k) s_cull[wave][k] = cull[k];
   }
   __syncthreads();
   if (threadIdx.x == 0 && cls_acc) {
@@ -421,6 +426,12 @@ __device__ __forceinline__ void cls_accumulate(unsigned long long nt_done, unsig
     unsigned long long* shard = cls_acc + 2 * (blockIdx.x % kClsShards);
     if (a) atomicAdd(&shard[0], a);
     if (b) atomicAdd(&shard[1], b);
+  }
+  if (threadIdx.x >= 1 && threadIdx.x <= kCullWords && cls_acc) {
+    const int k = threadIdx.x - 1;
+    const unsigned long long c = (unsigned long long)s_cull[0][k] + s_cull[1][k] + s_cull[2][k] + s_cull[3][k];
+    unsigned long long* cs = cls_acc + (kCullAccOff - kClsAccOff) / sizeof(unsigned long long);
+    if (c) atomicAdd(&cs[k * kCullShards + (blockIdx.x % kCullShards)], c);
   }
 }
 
@@ -522,6 +533,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
     unsigned long long* __restrict__ stats, unsigned long long* __restrict__ cls_acc, WinTable* __restrict__ tab) {
   __shared__ Cam s_cam[kClsFrames];
   __shared__ unsigned long long s_acc[4][2];
+  __shared__ uint32_t s_cull[4][kCullWords];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_f = wa.n;
   if (tid < n_f) s_cam[tid] = load_cam(wa.pose[tid], wa.K[tid], wa.W, wa.H);
@@ -555,6 +567,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
   }
   // ---- which frames can touch this brick at all?  lane k tests frame k
   uint32_t live;
+  uint32_t cull[kCullWords];  // (brick, frame) pairs of this wave: tested, and dropped by reason (stats[8..12])
   {
     // (the brick's voxel centres that lie inside the grid; a brick in the padding is clamped onto the grid: it is not classified)
     const int bx0 = min((int)bx * kBrickX, v.nx - 1), by0 = min((int)by * kBrickY, v.ny - 1), bz0 = min((int)bz * kBrickZ, v.nz - 1);
@@ -565,6 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
     const float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
     const float rho = sqrtf(hx * hx + hy * hy + hz * hz) * 1.02f + 1e-4f;  // voxel CENTRES are what is tested
     bool dead = false;
+    int why = 0;  // what dropped the frame: 1 behind the camera, 2 beyond the frame's largest depth + trunc, 3 outside the frustum, 4 occluded
     if (lane < n_f) {
       const Cam c = s_cam[lane];
       const bool pinhole = c.k01 == 0.0f && c.k10 == 0.0f && c.k20 == 0.0f && c.k21 == 0.0f && c.k22 == 1.0f;
@@ -590,6 +604,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
       const float ext_y = SAF_CLS_BOX ? (fabsf(c.r01) * hx + fabsf(c.r11) * hy + fabsf(c.r21) * hz) * mg + me : rho;
       const float ext_z = SAF_CLS_BOX ? (fabsf(c.r02) * hx + fabsf(c.r12) * hy + fabsf(c.r22) * hz) * mg + me : rho;
       dead = rigid && z_is_depth && (zc + ext_z <= 0.0f || zc - ext_z > far_z);
+      why = dead ? (zc + ext_z <= 0.0f ? 1 : 2) : 0;
       if (pinhole && rigid) {
         // in view <=> -0.5 <= u/z <= W - 0.5 and -0.5 <= v/z <= H - 0.5 with u = k00 x + k02 z, v = k11 y + k12 z:
         // four planes through the camera centre; the brick is outside if its centre is farther than its reach behind one
@@ -606,6 +621,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
         const float re1 = SAF_CLS_BOX ? reach(0.0f, c.k11, b1) / m1 + me : rho, re2 = SAF_CLS_BOX ? reach(0.0f, c.k11, b2) / m2 + me : rho;
         const bool fx_pos = c.k00 > 0.0f, fy_pos = c.k11 > 0.0f;  // the usual orientation; otherwise no frustum cull
         dead = dead || (fx_pos && (d1 < -rd1 || d2 > rd2)) || (fy_pos && (e1 < -re1 || e2 > re2));
+        why = dead && !why ? 3 : why;
         // ---- occlusion: the largest depth over the pixels the brick can project onto (SAF_CLS_OCCL=0 at build time: off).
         // A voxel's pixel is round(u), u = k00 x / z + k02 (clipfusion.py:651-661 undone: grid_sample's un-normalisation gives
         // back the pixel coordinate); over the sphere's bounding box x in [xc - rho, xc + rho], z in [zc - rho, zc + rho] (z > 0)
@@ -632,12 +648,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
 #pragma unroll
               for (int k = 0; k < 16; ++k) m = t[k] > m ? t[k] : m;
               dead = zn > m + v.trunc * 1.01f + 1e-4f;  // (inf: never)
+              why = dead ? 4 : 0;
             }
           }
         }
       }
     }
     live = on ? (uint32_t)__ballot(lane < n_f && !dead) : 0u;
+    cull[0] = on ? (uint32_t)n_f : 0u;
+#pragma unroll
+    for (int k = 1; k < kCullWords; ++k) cull[k] = on ? (uint32_t)__popcll(__ballot(why == k)) : 0u;
   }
   const float rtrunc = 1.0f / v.trunc;
   const bool tsdf_aligned = (((uintptr_t)v.tsdf | (uintptr_t)v.tsdf_w) & 15) == 0;
@@ -654,7 +674,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAF_CLS_WPE
     for (int j = 0; j < 4; ++j)
       if (inb[j]) hitmask[nb + kZS * j] = mk4[j];
   }
-  cls_accumulate(nt_done, tsdf_rows_done, lane, wave, s_acc, stats ? cls_acc : nullptr);
+  cls_accumulate(nt_done, tsdf_rows_done, cull, lane, wave, s_acc, s_cull, stats ? cls_acc : nullptr);
 }
 
 // One hit of a sub-chunk, held by the lane with the hit's index.
@@ -959,6 +979,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
       if (a) atomicAdd(&stats[1], a);
       if (b) atomicAdd(&stats[6], b);
     }
+    fold_cull_shards(cls_acc, stats, tid);
   }
   static_assert(kWinThreads >= kWin, "one thread per frame loads the window's cameras");
   if (tid < wa.F) {
@@ -1654,7 +1675,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   const int P = kf0.npy * kf0.npx;
   // Two layouts of the workspace: with room for the window's depth images re-laid-out in tiles (a workspace sized by
   // saf_fuse_workspace_bytes_for_frames) or without (the classification then reads the frames' own row-major images).
-  // SAF_CLS_TILED=0 (read per call): never tiled.
+  // SAF_CLS_TILED=0 (read per call): never tiled; 2: the first unit of a call reads the tiled copies too (tests: a single-window call).
   const size_t dpx = depth_px_padded(kf0.H, kf0.W);
   const WinLayout wl_lin = win_layout(kv.N, kv.D, P), wl_til = win_layout(kv.N, kv.D, P, false, dpx);
   const char* til_env = getenv("SAF_CLS_TILED");
@@ -1696,7 +1717,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
   const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
   const char* xcd_env = getenv("SAF_WIN_XCD");
-  static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kHdrBytes && kClsAccOff >= 256,
+  static_assert(kClsAccOff + kClsShards * 2 * sizeof(unsigned long long) <= kTableOff && kClsAccOff >= 256,
                 "workspace header layout");
   // the depth tiles of the classification's occlusion cull: 16 x 16 pixels, doubled until a frame has at most kMaxDepthTiles
   int ts_log2 = 4;
@@ -1836,7 +1857,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       // (unit 0 has the chip to itself -- everything the caller queued before is done, nothing of this call runs yet --, where the
       //  classification is bound by its vector instructions and the tile offset costs 5 % (0.92 vs 0.97 ms per launch): it reads the
       //  frames' own images; the tiled copies pay where the address path is shared, i.e. for every later unit)
-      const bool use_tiled = tiled && ui > 0;
+      const bool use_tiled = tiled && (ui > 0 || (til_env && til_env[0] == '2'));
       ca.depth_bytes = use_tiled ? (int)(dpx * sizeof(float)) : kf0.H * kf0.W * 4;
       for (int k = 0; k < kClsFrames; ++k) {
         const saf_frame& fr = frames[f0 + fb + (k < ca.n ? k : 0)];

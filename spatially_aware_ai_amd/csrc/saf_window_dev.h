@@ -31,6 +31,23 @@ static_assert(kTableOff + sizeof(WinTable) <= kHdrBytes, "workspace header layou
 // window's row kernel folds the shards into stats[].
 constexpr int kClsShards = 64;
 constexpr size_t kClsAccOff = 1024;  // 64 x {tsdf updates, tsdf voxels} u64 in the workspace header
+// ... and the bricks' frame cull (round 6): (brick, frame) pairs tested and dropped, by reason -- stats[8..12].  16 shards of
+// {tested, behind the camera, beyond the frame's largest depth, outside the frustum, occluded} behind the frame table.
+constexpr int kCullShards = 16, kCullWords = 5;
+constexpr size_t kCullAccOff = kTableOff + sizeof(WinTable);
+static_assert(kCullAccOff % 8 == 0 && kCullAccOff + kCullShards * kCullWords * sizeof(unsigned long long) <= kHdrBytes, "workspace header layout");
+constexpr int kStatCull = 8;  // first of the five words in stats[]
+// Layout: word k of shard j at k * kCullShards + j.  Folded by the first wave of a window's row kernel (`cls_acc` = header +
+// kClsAccOff as the row kernels receive it; all 64 lanes of the wave call).
+__device__ __forceinline__ void fold_cull_shards(const unsigned long long* __restrict__ cls_acc, unsigned long long* __restrict__ stats, int lane) {
+  const unsigned long long* cull = cls_acc + (kCullAccOff - kClsAccOff) / sizeof(unsigned long long);
+#pragma unroll
+  for (int k = 0; k < kCullWords; ++k) {
+    unsigned long long x = lane < kCullShards ? cull[k * kCullShards + lane] : 0ull;
+    for (int o = kCullShards / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0 && x) atomicAdd(&stats[kStatCull + k], x);
+  }
+}
 
 constexpr uint32_t kTapOutside = 0x80000000u;  // byte offset of a tap outside the map: beyond any buffer
 

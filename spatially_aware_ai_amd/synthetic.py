@@ -74,6 +74,61 @@ def intrinsics(width: int, height: int) -> torch.Tensor:
     return k
 
 
+# ---- the camera family real scans have (clipfusion.py:308-312: an ARKit pose with its y and z columns negated -- arbitrary roll
+# and pitch; clipfusion.py:647-659: K @ xyz_cam with the dataset's own fx != fy and principal point).  `look_at_pose` +
+# `intrinsics` above are one corner of it: up = world z (no roll: pose[2, 0] == 0), fx = fy, principal point at the centre.
+POSE_KINDS = ("look_at", "roll", "target", "so3")
+K_KINDS = ("centred", "free")
+
+
+def _roll(pose: torch.Tensor, angle: float) -> torch.Tensor:
+    """``pose`` with its camera rotated by ``angle`` about its own view axis (the right / down columns turn, forward stays)."""
+    c, s = math.cos(angle), math.sin(angle)
+    r = pose[:3, :3].double()
+    out = pose.clone()
+    out[:3, 0] = (c * r[:, 0] + s * r[:, 1]).float()
+    out[:3, 1] = (-s * r[:, 0] + c * r[:, 1]).float()
+    return out
+
+
+def family_pose(gen: torch.Generator, centre: torch.Tensor, kind: str, target_radius: float = 0.6) -> torch.Tensor:
+    """cam->world 4x4 of a camera at ``centre``: 'roll' = look at the origin, rolled by U(-pi, pi) about the view axis;
+    'target' = look at a point drawn uniformly from the ball of ``target_radius`` (pitch / yaw off the centre), rolled;
+    'so3' = a uniformly random orientation (Gaussian matrix -> QR, det +1): most of the grid is outside the view."""
+    if kind == "look_at":
+        return look_at_pose(centre)
+    if kind == "so3":
+        q, r = torch.linalg.qr(torch.randn(3, 3, generator=gen, dtype=torch.float64))
+        q = q * torch.sign(torch.diagonal(r))[None]
+        if torch.linalg.det(q) < 0:
+            q[:, 2] = -q[:, 2]
+        pose = torch.eye(4, dtype=torch.float64)
+        pose[:3, :3] = q
+        pose[:3, 3] = centre.double()
+        return pose.float()
+    angle = float((torch.rand((), generator=gen, dtype=torch.float64) * 2 - 1) * math.pi)
+    if kind == "roll":
+        return _roll(look_at_pose(centre), angle)
+    if kind == "target":
+        t = torch.randn(3, generator=gen, dtype=torch.float32)
+        t = t / t.norm() * target_radius * float(torch.rand((), generator=gen)) ** (1.0 / 3.0)
+        pose = look_at_pose(centre - t)  # the view direction of a camera at `centre` looking at t
+        pose[:3, 3] = centre
+        return _roll(pose, angle)
+    raise ValueError(kind)
+
+
+def family_intrinsics(gen: torch.Generator, width: int, height: int) -> torch.Tensor:
+    """fx, fy = 0.9 W x U(0.8, 1.3) each (fx != fy), principal point up to 20 % of the image off its centre."""
+    u = torch.rand(4, generator=gen, dtype=torch.float32)
+    k = torch.eye(3, dtype=torch.float32)
+    k[0, 0] = 0.9 * width * (0.8 + 0.5 * float(u[0]))
+    k[1, 1] = 0.9 * width * (0.8 + 0.5 * float(u[1]))
+    k[0, 2] = width * (0.5 + 0.4 * (float(u[2]) - 0.5))
+    k[1, 2] = height * (0.5 + 0.4 * (float(u[3]) - 0.5))
+    return k
+
+
 def _analytic_depth(pose: torch.Tensor, k: torch.Tensor, width: int, height: int) -> torch.Tensor:
     """Depth (camera z) of a sphere r=0.9 m inside an axis-aligned box of half-size 1.2 m.  Works on
     whatever device ``pose`` lives on (the benchmark generates its frames on the GPU)."""
@@ -147,19 +202,24 @@ def make_frame(
     missing_depth_frac: float = 0.0,
     label_kind: str = "iid",
     box_half=1.2,
+    pose_kind: str = "look_at",
+    k_kind: str = "centred",
 ):
     """One frame: dict of CPU f32 tensors shaped like a B=1 batch of the reference's loaders
     (clipfusion.py:190) plus the per-frame feature map and label map that stand in for the
     CLIP / kMaX backbones."""
     c = torch.randn(3, generator=gen, dtype=torch.float32)
     c = c / c.norm() * radius
-    pose = look_at_pose(c)
-    k = intrinsics(width, height)
+    # (the defaults draw nothing more from `gen` than they always did: the committed goldens regenerate byte for byte)
+    pose = look_at_pose(c) if pose_kind == "look_at" else family_pose(gen, c, pose_kind)
+    k = intrinsics(width, height) if k_kind == "centred" else family_intrinsics(gen, width, height)
     surface = None
     if depth_kind == "A":
         depth = torch.rand(height, width, generator=gen, dtype=torch.float32) * 2.0 + 1.5
     elif depth_kind == "B":
         depth, surface = _analytic_scene(pose, k, width, height, box_half)
+        if pose_kind != "look_at":  # a ray that leaves the room backwards (the camera looks away from it): no depth
+            depth = torch.where(torch.isfinite(depth) & (depth > 0), depth, torch.zeros_like(depth))
     else:
         raise ValueError(depth_kind)
     if missing_depth_frac > 0:
@@ -193,6 +253,24 @@ def make_frame(
 def make_frames(seed: int, n_frames: int, **kw):
     gen = torch.Generator().manual_seed(seed)
     return [make_frame(gen, **kw) for _ in range(n_frames)]
+
+
+def make_family_frames(seed: int, n_frames: int, width: int, height: int, feat_dim: int, npy: int, npx: int,
+                       missing_depth_frac: float = 0.08, label_kind: str = "iid"):
+    """``n_frames`` frames of the camera family real scans have (`family_pose` / `family_intrinsics`): rolled look-at, look-at
+    an off-centre target, uniformly random orientations; fx != fy, principal point off the centre; cameras outside, at the
+    edge of and inside a 2.56 m grid; random and analytic depth, some of it missing.  One seeded schedule, shared by the
+    golden generator (the reference runs it) and the tests."""
+    gen = torch.Generator().manual_seed(seed)
+    pose_kinds = ("roll", "target", "target", "so3", "roll", "target")
+    radii = (2.5, 2.5, 1.4, 0.6, 2.0, 0.5, 2.5)
+    depth_kinds = ("A", "B", "A", "B", "B")
+    frames = []
+    for i in range(n_frames):
+        frames.append(make_frame(gen, width, height, feat_dim, npy, npx, depth_kind=depth_kinds[i % 5], radius=radii[i % 7],
+                                 missing_depth_frac=missing_depth_frac if i % 4 == 1 else 0.0, label_kind=label_kind,
+                                 pose_kind=pose_kinds[i % 6], k_kind="free"))
+    return frames
 
 
 def feature_map_shape(width: int, height: int):

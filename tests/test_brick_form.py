@@ -92,6 +92,7 @@ def test_brick_form_against_the_sequential_path_and_the_oracle(oracle, monkeypat
     s1, s2 = one.stats(), win.stats()
     assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0, "the windowed path did not run"
     s1.pop("window_tsdf_voxels"), s2.pop("window_tsdf_voxels")
+    assert s1.pop("cull")["pairs"] == 0 and s2.pop("cull")["pairs"] > 0  # (the frame cull is the windowed path's)
     assert s1 == s2, (s1, s2)
     for name in EXACT + (("labels_one_hot",) if seem else ()):
         assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs from the sequential path"

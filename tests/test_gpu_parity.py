@@ -428,6 +428,7 @@ def test_windowed_voxel_major_path_is_bit_identical(oracle, dim, seem, accum, n_
     s1, s2 = one.stats(), win.stats()
     assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0
     assert s1.pop("window_tsdf_voxels") == 0 and s2.pop("window_tsdf_voxels") > 0
+    assert s1.pop("cull")["pairs"] == 0 and s2.pop("cull")["pairs"] > 0  # (the frame cull is the windowed path's)
     assert s1 == s2, (s1, s2)
     assert int(win.fuse_stats[5]) > 0, "the windowed kernel did not run"
     assert int(win.fuse_stats[5]) < s2["valid"], "no voxel was hit twice inside a window: the test is too weak"
@@ -493,6 +494,7 @@ def test_windowed_path_random_shapes_equal_the_sequential_path(seed):
     s1, s2 = one.stats(), win.stats()
     assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0
     s1.pop("window_tsdf_voxels"), s2.pop("window_tsdf_voxels")
+    assert s1.pop("cull")["pairs"] == 0 and s2.pop("cull")["pairs"] > 0  # (the frame cull is the windowed path's)
     assert s1 == s2, (s1, s2)
     for name in ("weight", "tsdf_weight", "tsdf", "rgb", "clip_feat") + (("labels_one_hot",) if seem else ()):
         assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs (nvox {nvox}, {n_frames} frames, D {dim})"

@@ -127,6 +127,59 @@ def test_config1_digest(oracle, golden_dir):
     assert np.allclose(vol.clip_feat.double().sum(0).numpy(), g["clip_col_sum"], rtol=0, atol=1e-6 * float(g["clip_abs_sum"]))
 
 
+def cameras_inputs(tag):
+    """The camera-family fixture's scenario (oracle/gen_golden.py `cameras_scenario`), regenerated from its seed."""
+    w, h = 80, 60
+    npy, npx = syn.feature_map_shape(w, h)
+    grid = syn.make_grid((44, 40, 48), side=2.2)
+    dim, seem = {"cf": (256, False), "seem": (64, True)}[tag]
+    frames = syn.make_family_frames(20241006, 48, w, h, dim, npy, npx)
+    return grid, frames, dim, seem
+
+
+def check_cameras_digest(g, tag, vol, frames, close, exact_counts=None):
+    """A fused volume (oracle or HIP: anything with the reference's buffer names) against the reference's digest."""
+    assert np.array_equal(np.asarray(vol.weight.cpu()).astype(np.uint8), g[f"{tag}_weight"]), "valid sets differ from the reference's"
+    assert np.array_equal(np.asarray(vol.tsdf_weight.cpu()).astype(np.uint8), g[f"{tag}_tsdf_weight"]), "tsdf sets differ"
+    rows = g[f"{tag}_rows"]
+    close(vol.tsdf.cpu().numpy(), g[f"{tag}_tsdf"], "tsdf")
+    close(vol.clip_feat.float().cpu()[rows].numpy(), g[f"{tag}_clip_rows"], "clip rows")
+    close(vol.rgb.cpu()[rows].numpy(), g[f"{tag}_rgb_rows"], "rgb rows")
+    assert np.allclose(vol.clip_feat.double().sum(0).cpu().numpy(), g[f"{tag}_clip_col_sum"], rtol=0, atol=1e-6 * float(g[f"{tag}_clip_abs_sum"]))
+    assert np.allclose(vol.rgb.double().sum(0).cpu().numpy(), g[f"{tag}_rgb_col_sum"], rtol=1e-6)
+    if tag == "seem":
+        t = vol.labels_one_hot.cpu()
+        assert np.array_equal(t[rows].numpy().astype(np.int8), g["seem_label_rows"])
+        assert np.array_equal(t.long().sum(0).numpy(), g["seem_label_col_sum"]), "label histogram differs"
+
+
+@pytest.mark.parametrize("tag", ["cf", "seem"])
+def test_camera_family_digest(oracle, golden_dir, tag):
+    """The reference's own ClipFusion / ClipSeemFusion on the cameras real scans have (clipfusion.py:308-312: arbitrary roll and
+    pitch; :647-659: fx != fy, principal point off the centre; cameras inside the grid; missing depth): per-frame counts and
+    the index sets after 12, 24 and 48 frames bit-exact, values within 1e-4."""
+    g = _load(golden_dir, "fusion_cameras_digest.npz")
+    grid, frames, dim, seem = cameras_inputs(tag)
+    digest = np.array([[float(f["depth"].double().sum()), float(f["feat"].double().sum()), float(f["pose"].double().sum()),
+                        float(f["K"].double().sum())] for f in frames])
+    assert np.allclose(digest, g[f"{tag}_in_digest"], rtol=1e-12, atol=0), "synthetic inputs differ from the generator's"
+    assert any(abs(float(f["pose"][0, 2, 0])) > 0.3 for f in frames) and any(abs(float(f["K"][0, 0, 0] / f["K"][0, 1, 1]) - 1) > 0.1 for f in frames)
+    vol = oracle.OracleVolume(grid.origin, grid.voxel_size, grid.nvox, grid.trunc, dim, 143 if seem else 0)
+    nv, nt = [], []
+    for i, f in enumerate(frames):
+        s0 = vol.stats.copy()
+        vol.integrate(f["depth"], f["rgb"], f["pose"], f["K"], f["feat"], [f["labels"].float()] if seem else None, rgb_bilinear=seem)
+        nv.append(int(vol.stats[0] - s0[0]))
+        nt.append(int(vol.stats[1] - s0[1]))
+        if f"{tag}_weight_{i + 1}" in g:
+            assert np.array_equal(vol.weight.numpy().astype(np.uint8), g[f"{tag}_weight_{i + 1}"]), f"valid sets differ after frame {i}"
+            assert np.array_equal(vol.tsdf_weight.numpy().astype(np.uint8), g[f"{tag}_tsdf_weight_{i + 1}"])
+    assert nv == g[f"{tag}_nv"].tolist() and nt == g[f"{tag}_nt"].tolist()
+    check_cameras_digest(g, tag, vol, frames, _close)
+    if seem:
+        assert np.array_equal(oracle.label_argmax(vol.labels_one_hot).numpy().astype(np.int16), g["seem_onehot_to_index"])
+
+
 def test_sum_mode_then_finalize_equals_running_mean(oracle, golden_dir):
     """a mean is sum/count, so SAF_SUM + merge_finalize reproduces the
     running-mean volume to rounding, with identical index sets."""

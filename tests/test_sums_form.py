@@ -44,6 +44,7 @@ def test_sums_form_against_the_sequential_path_and_the_oracle(oracle, monkeypatc
     s1, s2 = one.stats(), win.stats()
     assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0, "the windowed path did not run"
     s1.pop("window_tsdf_voxels"), s2.pop("window_tsdf_voxels")
+    assert s1.pop("cull")["pairs"] == 0 and s2.pop("cull")["pairs"] > 0  # (the frame cull is the windowed path's)
     assert s1 == s2, (s1, s2)
     for name in EXACT + (("labels_one_hot",) if seem else ()):
         assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs from the sequential path"
@@ -129,6 +130,7 @@ def test_classification_guard_on_pixel_boundaries(rows_form):
     s1, s2 = one.stats(), win.stats()
     assert s1.pop("window_rows") == 0 and s2.pop("window_rows") > 0, "the windowed path did not run"
     s1.pop("window_tsdf_voxels"), s2.pop("window_tsdf_voxels")
+    assert s1.pop("cull")["pairs"] == 0 and s2.pop("cull")["pairs"] > 0  # (the frame cull is the windowed path's)
     assert s1 == s2 and s1["valid"] > 10000, (s1, s2)
     for name in EXACT:
         assert torch.equal(getattr(one, name), getattr(win, name)), f"{name} differs from the per-frame pipeline"
