@@ -341,7 +341,7 @@ def main():
             # rows no rank touched do not travel (distributed._merge_rows): pieces of the stripe plan whose touched share is at
             # most the threshold go packed through all_to_all_single -- probed first as well; dense throughout if it fails
             why_a2a = sdist.probe_all_to_all(device)
-            merge_state["sparse"] = None if why_a2a is None else 0.0
+            merge_state["sparse"] = sdist.sparse_threshold() if why_a2a is None else 0.0  # (explicit: the library does not probe again)
             merge_state["sparse_note"] = why_a2a
 
     def merge(fz):

@@ -339,6 +339,29 @@ int saf_merge_finalize(const saf_volume* vol, int64_t first_voxel, int64_t n_vox
 int saf_mean_to_sum(const saf_volume* vol, int64_t first_voxel, int64_t n_voxels, void* stream);
 
 /*
+ * The PACKED route of the frame-sharded merge (new capability, nothing to mirror in the reference): after
+ * the all-reduce of `weight` every rank knows which rows ANY rank touched; of a piece whose touched share is small only those
+ * rows travel (all_to_all with uneven splits, issued by the host: spatially_aware_ai_amd/distributed.py).  Rows are indexed
+ * relative to the first row of the slab / volume being merged; `weight` and `pos` cover the same rows.
+ *   saf_merge_scan_touched  pos[i] = number of touched rows (weight > 0) among [0, i), i = 0 .. n_rows (n_rows + 1 words), and
+ *                           offs_host[j] = pos[bounds[j]] (bounds: device memory; offs_host: host memory, pinned for an
+ *                           asynchronous copy) -- the split sizes of the collective; the caller synchronises the stream once
+ *                           before reading them.  workspace: saf_merge_scan_workspace_bytes(n_rows, n_bounds).
+ *   saf_merge_pack_rows     the touched rows of [first, first + n_rows) of `src` (rows of row_bytes bytes, a multiple of 4) ->
+ *                           packed[pos[r] - pos[first]]: the send buffer, touched rows in ascending order.
+ *   saf_merge_add_packed    dst[r] = recv[0][p] + recv[1][p] + ... + recv[world - 1][p] (rank order: deterministic) for the
+ *                           touched rows r of [first, first + n_rows), p = pos[r] - pos[first]; recv = [world][mine] rows as
+ *                           all_to_all_single leaves them; is_float: f32 rows (else i32).
+ */
+size_t saf_merge_scan_workspace_bytes(int64_t n_rows, int32_t n_bounds);
+int saf_merge_scan_touched(const int32_t* weight, int64_t n_rows, int32_t* pos, const int64_t* bounds, int32_t n_bounds,
+                           int32_t* offs_host, void* workspace, size_t workspace_bytes, void* stream);
+int saf_merge_pack_rows(const void* src, int64_t row_bytes, const int32_t* weight, const int32_t* pos, int64_t first,
+                        int64_t n_rows, void* packed, void* stream);
+int saf_merge_add_packed(void* dst, int64_t row_bytes, int32_t is_float, const int32_t* weight, const int32_t* pos, int64_t first,
+                         int64_t n_rows, const void* recv, int64_t mine, int32_t world, void* stream);
+
+/*
  * Vertex sampling half of extract_mesh (clipfusion.py:741-760; clip_seem_fusion.py:843-878): for
  * marching-cubes vertices given in voxel-index coordinates, grid = (v + 0.5) * (1/nvox) * 2 - 1 and
  * 3-D grid_sample(align_corners=False, zeros padding) of the volume:

@@ -134,6 +134,10 @@ PROTOTYPES = {
     ),
     "saf_merge_finalize": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_mean_to_sum": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
+    "saf_merge_scan_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "saf_merge_scan_touched": (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int32, _fp, _fp, C.c_size_t, _fp]),
+    "saf_merge_pack_rows": (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int64, C.c_int64, _fp, _fp]),
+    "saf_merge_add_packed": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, _fp, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int32, _fp]),
     "saf_label_argmax": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, _fp]),
     "saf_sample_vertices": (C.c_int, [C.POINTER(SafVolume), _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "saf_clip_tiles": (

@@ -159,11 +159,12 @@ def _all_gather_striped(t, plan, group, rank, world):
 _SPARSE_TENSORS = ("clip_feat", "rgb", "labels_one_hot")
 _SPARSE_DEFAULT = 0.5
 last_merge = {"pieces": 0, "packed": 0, "rows": 0, "touched_rows": 0}  # of this process's latest _merge_rows (bench / tests)
+_a2a_probe = {}  # (group, device type) -> None (the packed route's collective works) or what went wrong: probed ONCE per process
 
 
 def sparse_threshold(sparse=None):
-    """The touched fraction of a piece up to which it travels packed: ``sparse`` if given, else SAF_MERGE_SPARSE (0 = the
-    dense route always), else 0.5."""
+    """THIS rank's wish for the touched fraction of a piece up to which it travels packed: ``sparse`` if given, else
+    SAF_MERGE_SPARSE (0 = the dense route always), else 0.5.  What a merge uses is ``agree_sparse``'s answer."""
     import os
 
     if sparse is None:
@@ -172,70 +173,143 @@ def sparse_threshold(sparse=None):
     return max(0.0, float(sparse))
 
 
-def _touched_rows(weight_total, plan, world):
-    """From the all-reduced weight of the rows the plan covers: (idx_of, offs) -- idx_of() = the touched rows (global indices,
-    ascending, on the device), offs[j][k] = position in that list of the first touched row of part k of piece j (k = world: the
-    piece's end, the tail rows included in the last part's count are NOT -- they are reduced on their own).  One host sync."""
-    first0 = plan[0][0]
-    n_rows = plan[-1][0] + plan[-1][1] - first0
-    touched = weight_total[first0 : first0 + n_rows] > 0
-    bounds = []
-    for first, rows, c in plan:
-        bounds += [first - first0 + k * c for k in range(world + 1)]
-    cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=touched.device), torch.cumsum(touched, 0, dtype=torch.int64)])
-    pre = cs[torch.tensor(bounds, dtype=torch.int64, device=touched.device)].cpu().tolist()
-    offs = [pre[j * (world + 1) : (j + 1) * (world + 1)] for j in range(len(plan))]
-    # (the index list -- 8 bytes per touched row -- only when some piece will travel packed: `idx` is a thunk)
-    return (lambda: torch.nonzero(touched).squeeze(1) + first0), offs
+def sparse_wish(sparse, device, group=None):
+    """THIS rank's threshold for the packed route, safe to offer: ``sparse_threshold`` -- but with ``sparse=None`` (the library
+    default) only if ``probe_all_to_all`` succeeded, run once per process and group and cached: a collective that raises
+    part-way through a volume cannot be retried (``probe_collectives``), so the route is tried on a small tensor before any
+    volume is touched.  An explicit ``sparse`` means the caller has probed (``bench.py`` does) or knows its backend.  What a
+    merge USES is the minimum of the ranks' wishes (``_merge_rows``): ranks whose SAF_MERGE_SPARSE differ would otherwise pick
+    different collectives for the same piece and hang."""
+    thr = sparse_threshold(sparse)
+    if sparse is None:  # (every rank that was not told probes, whatever its own wish: the probe is itself a collective)
+        key = (id(group) if group is not None else None, torch.device(device).type)
+        if key not in _a2a_probe:
+            _a2a_probe[key] = probe_all_to_all(device, group)
+        if _a2a_probe[key] is not None:
+            thr = 0.0
+    return thr
 
 
-def _reduce_scatter_packed(t, idx, offs_j, group, rank, world):
-    """One piece, packed: the touched rows of part k (idx[offs_j[k] : offs_j[k + 1]]) go to rank k, which adds the world
-    contributions (rank order: deterministic) and writes them back in place."""
+class _Touched:
+    """What one merge knows about the rows any rank touched (from the all-reduced weight of the rows the plan covers):
+    ``offs[j][k]`` = position, among the touched rows in ascending order, of the first touched row of part k of piece j
+    (k = world: the end of the piece's world equal parts; a tail of fewer than world rows is reduced on its own), after ONE
+    host synchronisation.  Device tensors: a scan kernel and the boundaries' positions copied to pinned memory
+    (``saf_merge_scan_touched``; no index list -- pack / add read the positions).  CPU tensors (the gloo tests): torch."""
+
+    def __init__(self, weight_total, plan, world):
+        self.first0 = plan[0][0]
+        self.n_rows = plan[-1][0] + plan[-1][1] - self.first0
+        self.w = weight_total[self.first0 : self.first0 + self.n_rows]
+        self.world = world
+        bounds = []
+        for first, rows, c in plan:
+            bounds += [first - self.first0 + k * c for k in range(world + 1)]
+        self.hip = self.w.is_cuda
+        self._idx = None
+        if self.hip:
+            L = lib()
+            dev = self.w.device
+            self.pos = torch.empty(self.n_rows + 1, dtype=torch.int32, device=dev)
+            b = torch.tensor(bounds, dtype=torch.int64).to(dev, non_blocking=False)
+            need = L.saf_merge_scan_workspace_bytes(self.n_rows, len(bounds))
+            ws = torch.empty(max(1, need), dtype=torch.uint8, device=dev)
+            host = torch.empty(len(bounds), dtype=torch.int32).pin_memory()
+            with torch.cuda.device(dev):
+                check(L.saf_merge_scan_touched(self.w.data_ptr(), self.n_rows, self.pos.data_ptr(), b.data_ptr(), len(bounds),
+                                               host.data_ptr(), ws.data_ptr(), ws.numel(), current_stream_ptr()), "saf_merge_scan_touched")
+                torch.cuda.current_stream(dev).synchronize()  # the one host sync of a merge: the collective's split sizes
+            pre = host.tolist()
+        else:
+            touched = self.w > 0
+            cs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(touched, 0, dtype=torch.int64)])
+            pre = cs[torch.tensor(bounds, dtype=torch.int64)].tolist()
+            self._touched = touched
+        self.offs = [pre[j * (world + 1) : (j + 1) * (world + 1)] for j in range(len(plan))]
+
+    def idx(self):  # (CPU route only: the touched rows' indices, relative to first0)
+        if self._idx is None:
+            self._idx = torch.nonzero(self._touched).squeeze(1)
+        return self._idx
+
+
+def _reduce_scatter_packed(t, touched, j, first, c, group, rank, world):
+    """One piece, packed: the touched rows of part k go to rank k, which adds the world contributions (rank order:
+    deterministic) and writes them back in place.  On the device the send buffer is packed and the received contributions
+    are added by two HIP passes (``saf_merge_pack_rows`` / ``saf_merge_add_packed``); CPU tensors take the same steps in torch."""
+    offs_j = touched.offs[j]
     counts = [offs_j[k + 1] - offs_j[k] for k in range(world)]
-    if sum(counts) == 0:
+    total, mine = offs_j[world] - offs_j[0], counts[rank]
+    if total == 0:
         return
-    send = t.index_select(0, idx[offs_j[0] : offs_j[world]])
-    mine = counts[rank]
-    recv = torch.empty((world * mine,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    row_shape = tuple(t.shape[1:])
+    view = t[touched.first0 : touched.first0 + touched.n_rows]
+    rel = first - touched.first0
+    send = torch.empty((total,) + row_shape, dtype=t.dtype, device=t.device)
+    recv = torch.empty((world * mine,) + row_shape, dtype=t.dtype, device=t.device)
+    if touched.hip:
+        L = lib()
+        row_bytes = (view[0].numel() if view.dim() > 1 else 1) * t.element_size()
+        if not view.is_contiguous() or t.element_size() != 4:
+            raise SafError("the packed merge moves contiguous rows of 4-byte elements")
+        with torch.cuda.device(t.device):
+            check(L.saf_merge_pack_rows(view.data_ptr(), row_bytes, touched.w.data_ptr(), touched.pos.data_ptr(), rel, world * c,
+                                        send.data_ptr(), current_stream_ptr()), "saf_merge_pack_rows")
+            dist.all_to_all_single(recv, send, [mine] * world, counts, group=group)
+            check(L.saf_merge_add_packed(view.data_ptr(), row_bytes, 1 if t.dtype.is_floating_point else 0, touched.w.data_ptr(),
+                                         touched.pos.data_ptr(), rel + rank * c, c, recv.data_ptr(), mine, world, current_stream_ptr()),
+                  "saf_merge_add_packed")
+        return
+    idx = touched.idx()
+    torch.index_select(view, 0, idx[offs_j[0] : offs_j[world]], out=send)
     dist.all_to_all_single(recv, send, [mine] * world, counts, group=group)
     if mine:
-        red = recv.view((world, mine) + tuple(t.shape[1:])).sum(dim=0, dtype=t.dtype)
-        t.index_copy_(0, idx[offs_j[rank] : offs_j[rank + 1]], red)
+        parts = recv.view((world, mine) + row_shape)
+        red = parts[0].clone()
+        for k in range(1, world):  # rank order, as the device pass adds them
+            red += parts[k]
+        view.index_copy_(0, idx[offs_j[rank] : offs_j[rank + 1]], red)
 
 
-def _merge_rows(tensors, plan, group, rank, world, sparse=None):
-    """SUM the rows the plan covers across the ranks; rank k ends with the reduced rows of its stripes.  Returns the number of
-    pieces that travelled packed (0: the dense route throughout)."""
-    thr = sparse_threshold(sparse)
+def _merge_rows(tensors, plan, group, rank, world, wish):
+    """SUM the rows the plan covers across the ranks; rank k ends with the reduced rows of its stripes, the other rows keep
+    this rank's partial sums -- except ``weight``, which is ALL-REDUCED (whatever the route: 0.2 % of the volume): every rank
+    ends with the job's total weight on every row, i.e. the union of the touched rows.  ``wish``: this rank's threshold for the
+    packed route (``sparse_wish``); the ranks use the MINIMUM of their wishes (one 8-byte all_reduce, read in the same host
+    synchronisation as the split sizes); pieces whose touched share is at most that travel packed.  Returns their number."""
     w = tensors.get("weight")
     wide = [k for k in _SPARSE_TENSORS if tensors.get(k) is not None]
     packed = 0
     last_merge.update(pieces=len(plan), packed=0, rows=sum(r for _, r, _ in plan), touched_rows=-1)
-    if thr > 0 and w is not None and wide and plan:
+    if not plan:
+        return 0
+    if w is not None:
         first0 = plan[0][0]
         n_rows = plan[-1][0] + plan[-1][1] - first0
-        _all_reduce(w[first0 : first0 + n_rows], group)  # the job's weight on EVERY rank: also the union of the touched rows
-        idx_of, offs = _touched_rows(w, plan, world)
-        idx = None
+        _all_reduce(w[first0 : first0 + n_rows], group)
+    rest = {k: t for k, t in tensors.items() if k != "weight"}
+    thr = 0.0
+    if w is not None and wide:
+        agreed = torch.tensor([float(wish)], dtype=torch.float64, device=w.device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
+        if wish > 0:  # (a rank that wishes 0 knows the minimum without looking: no scan, no host sync)
+            touched = _Touched(w, plan, world)
+            thr = float(agreed)
+    if thr > 0:
         for j, (first, rows, c) in enumerate(plan):
-            frac = (offs[j][world] - offs[j][0]) / max(1, world * c)
+            frac = (touched.offs[j][world] - touched.offs[j][0]) / max(1, world * c)
             go_packed = c > 0 and frac <= thr
-            if go_packed and idx is None:
-                idx = idx_of()
             packed += 1 if go_packed else 0
-            for name, t in tensors.items():
-                if name == "weight":
-                    continue
+            for name, t in rest.items():
                 if go_packed and name in wide:
-                    _reduce_scatter_packed(t, idx, offs[j], group, rank, world)
+                    _reduce_scatter_packed(t, touched, j, first, c, group, rank, world)
                     if rows > world * c:
                         dist.reduce(t[first + world * c : first + rows], dst=_global_rank(group, world - 1), op=dist.ReduceOp.SUM, group=group)
                 else:
                     _reduce_scatter_striped(t, [(first, rows, c)], group, rank, world)
-        last_merge.update(packed=packed, touched_rows=int(sum(o[world] - o[0] for o in offs)))
+        last_merge.update(packed=packed, touched_rows=int(sum(o[world] - o[0] for o in touched.offs)))
         return packed
-    for t in tensors.values():
+    for t in rest.values():
         _reduce_scatter_striped(t, plan, group, rank, world)
     return 0
 
@@ -445,11 +519,12 @@ def slab_rows(fusion, x0: int, count: int):
 
 
 def merge_slab_sums(tensors: dict, first_row: int, n_rows: int, group=None, mode: str = "reduce_scatter", piece_bytes=None,
-                    sparse=None, plans_out=None):
+                    sparse=None, plans_out=None, wish=None):
     """SUM rows [first_row, first_row + n_rows) of every tensor across the ranks; with ``reduce_scatter`` rank k ends with
     its stripes of the slab (returned as a list of (first, count) in volume rows: the k-th part of every piece of the slab),
-    the other rows keep partial sums (``weight``: the job's total, when the sparse route ran -- ``_merge_rows``).
-    ``plans_out``: a list the slab's stripe plan is appended to (``gather_shards`` all-gathers along it)."""
+    the other rows keep partial sums (``weight``: the job's total on every row, whatever the route -- ``_merge_rows``).
+    ``plans_out``: a list the slab's stripe plan is appended to (``gather_shards`` all-gathers along it).  ``wish``: this rank's
+    threshold for the packed route when the caller has settled it for all slabs at once (``sparse_wish``); else it is settled here."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [(first_row, n_rows)]
     world = dist.get_world_size(group)
@@ -459,7 +534,8 @@ def merge_slab_sums(tensors: dict, first_row: int, n_rows: int, group=None, mode
             _all_reduce(t[first_row : first_row + n_rows], group)
         return [(first_row, n_rows)]
     plan = _plan_for(tensors, n_rows, world, first_row, piece_bytes)
-    _merge_rows(tensors, plan, group, rank, world, sparse)
+    wish = sparse_wish(sparse, next(iter(tensors.values())).device, group) if wish is None else wish
+    _merge_rows(tensors, plan, group, rank, world, wish)
     if plans_out is not None:
         plans_out.append(plan)
     return stripes_of_rank(plan, rank, world)
@@ -481,6 +557,9 @@ def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, grou
     module in running-mean mode with those stripes recorded (``_shard_stripes``): it refuses further ``integrate`` calls
     until ``gather_shards``.  The caller's stream ends ordered after the last collective."""
     _require_f32_sums(fusion, "fuse_merge_pipelined")
+    check_poisoned = getattr(fusion, "_check_poisoned", None)
+    if check_poisoned is not None:
+        check_poisoned()  # (a volume a failed flush or merge left half-done stays unusable until reset())
     if getattr(fusion, "_shard_stripes", None) is not None:
         raise SafError("this volume was already merged and holds only its voxel stripes")
     # frames still queued behind integrate() belong to the volume.  A volume fresh from a lazy reset() keeps its deferred clear:
@@ -502,6 +581,10 @@ def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, grou
     n = fusion._buffers["tsdf"].numel()
     slabs = slab_bounds(nx, n_slabs, ramp=ramp)
     k = len(slabs)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    # the packed route: probed (once per process) BEFORE anything touches the volume; one wish for every slab of this job
+    wish = sparse_wish(sparse, dev, group) if world > 1 and mode == "reduce_scatter" else 0.0
+    touched_volume = False  # has any kernel or collective of this job written to the volume?
     # ONE C call fuses every frame into slab 0, slab 1, ... (the first window of a slab is classified beside the last row
     # kernel of the slab before it) and records an event behind each slab; the collectives wait for those on `comm`
     try:
@@ -513,22 +596,26 @@ def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, grou
             nxs = (C.c_int32 * k)(*[s_[1] for s_ in slabs])
             handles = (C.c_void_p * k)(*[int(ev.cuda_event) for ev in events])
             vol = fusion._c_volume(for_fuse=True)
-            check(L.saf_fuse_frames_slabs(C.byref(vol), frame_arr, n_frames, x0s, nxs, k, handles, 1 if recycled else 0,
-                                          workspace.data_ptr(), workspace.numel(), stats_ptr, profiler, main.cuda_stream),
-                  "saf_fuse_frames_slabs")
+            rc = L.saf_fuse_frames_slabs(C.byref(vol), frame_arr, n_frames, x0s, nxs, k, handles, 1 if recycled else 0,
+                                         workspace.data_ptr(), workspace.numel(), stats_ptr, profiler, main.cuda_stream)
+            # (SAF_E_INVALID / SAF_E_WORKSPACE are rejections at the entry, before any kernel ran: the volume is as it was)
+            touched_volume = rc == 0 or rc == _abi.SAF_E_HIP
+            check(rc, "saf_fuse_frames_slabs")
             if recycled:  # (the slabs cover the volume: slab_bounds)
                 fusion.__dict__["_feat_stale"] = False
             with torch.cuda.stream(comm):
                 for (x0, cnt), ev in zip(slabs, events):
                     comm.wait_event(ev)
                     r0, nr = slab_rows(fusion, x0, cnt)
-                    for first, count in merge_slab_sums(tensors, r0, nr, group, mode, sparse=sparse, plans_out=plans):
+                    for first, count in merge_slab_sums(tensors, r0, nr, group, mode, plans_out=plans, wish=wish):
                         check(L.saf_merge_finalize(C.byref(vol), first, count, comm.cuda_stream), "saf_merge_finalize")
                         stripes.append((first, count))
     except BaseException:
         # some slabs are reduced / finalised, others not: the volume is neither sums nor means.  Poisoned until reset(),
         # like a failed flush (clipfusion._flush_pending): a later integrate or merge must not count anything twice.
-        fusion.__dict__["_poisoned"] = "fuse_merge_pipelined failed part-way: the volume is half sums, half means"
+        # (Not when the C call refused its arguments at the entry: nothing ran, the caller may fix them and call again.)
+        if touched_volume:
+            fusion.__dict__["_poisoned"] = "fuse_merge_pipelined failed part-way: the volume is half sums, half means"
         raise
     if comm is not main:
         main.wait_event(comm.record_event())
@@ -557,7 +644,7 @@ def merge_sums(tensors: dict, group=None, mode: str = "reduce_scatter", gather: 
     if mode != "reduce_scatter":
         raise ValueError(mode)
     plan = _plan_for(tensors, n, world, 0, piece_bytes)
-    _merge_rows(tensors, plan, group, rank, world, sparse)
+    _merge_rows(tensors, plan, group, rank, world, sparse_wish(sparse, next(iter(tensors.values())).device, group))
     if gather:
         for t in tensors.values():
             _all_gather_striped(t, plan, group, rank, world)
@@ -607,9 +694,18 @@ def merge_volumes(fusion, group=None, mode: str = "reduce_scatter", gather: bool
     tensors = _volume_tensors(fusion)
     n = fusion.tsdf.numel()
     plans = []
-    stripes = merge_sums(tensors, group=group, mode=mode, gather=False, piece_bytes=piece_bytes, sparse=sparse, plans_out=plans)
-    for first, count in stripes:
-        finalize_sums(fusion, first, count)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    # (the packed route is probed -- once per process -- before the first collective touches the volume)
+    wish = sparse_wish(sparse, fusion.tsdf.device, group) if world > 1 and mode == "reduce_scatter" else 0.0
+    try:
+        stripes = merge_sums(tensors, group=group, mode=mode, gather=False, piece_bytes=piece_bytes, sparse=wish, plans_out=plans)
+        for first, count in stripes:
+            finalize_sums(fusion, first, count)
+    except BaseException:
+        # weight is all-reduced, some pieces are summed, others not: neither this rank's sums nor the job's.  Unusable until
+        # reset(), like a failed flush -- a retry would add the other ranks' rows twice.
+        fusion.__dict__["_poisoned"] = "merge_volumes failed part-way: the volume is half merged"
+        raise
     if stripes == [(0, n)]:
         return stripes
     # voxel-sharded result: only the stripes hold the job's means; the other rows hold this rank's partial sums.

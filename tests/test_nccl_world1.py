@@ -40,6 +40,21 @@ _CHILD = textwrap.dedent('''
     out = sd.gather_frames(fr)
     assert out[1] is None and torch.equal(out[0], fr[0]) and torch.equal(out[2], fr[2])
     assert sd.probe_collectives(dev) is None
+    # the packed route (round 6: scan / pack / add are HIP passes): weight all-reduced, touched rows through all_to_all_single
+    assert sd.probe_all_to_all(dev) is None
+    n = 5000
+    w = (torch.rand(n, generator=g, device=dev) < 0.2).int() * torch.randint(1, 9, (n,), generator=g, device=dev, dtype=torch.int32)
+    tens = {"weight": w.clone(), "clip_feat": torch.randn((n, 512), generator=g, device=dev) * (w > 0)[:, None],
+            "rgb": torch.rand((n, 3), generator=g, device=dev) * (w > 0)[:, None],
+            "labels_one_hot": torch.randint(0, 5, (n, 143), generator=g, device=dev, dtype=torch.int32) * (w > 0)[:, None].int(),
+            "tsdf": torch.randn(n, generator=g, device=dev)}
+    ref = {k: v.clone() for k, v in tens.items()}
+    plan = sd.stripe_plan(n, 1, 700)
+    packed = sd._merge_rows(tens, plan, None, 0, 1, 1.0)
+    torch.cuda.synchronize()
+    assert packed == len(plan) and sd.last_merge["touched_rows"] == int((w > 0).sum()), sd.last_merge
+    for k in tens:
+        assert torch.equal(tens[k], ref[k]), ("the packed route changed a one-rank tensor", k)
     x = torch.ones(5, device=dev)
     dist.all_reduce(x)
     torch.cuda.synchronize()
