@@ -105,7 +105,7 @@ def parse():
     ap.add_argument("--e2e-batch", type=int, default=1, help="frames per integrate() call in the end-to-end pass")
     ap.add_argument("--e2e-dtype", default="bf16", choices=["f32", "bf16"], help="backbone compute dtype")
     ap.add_argument("--e2e-tile-batch", type=int, default=0, help="tiles per encode_image call (0 = the Clip class's default)")
-    ap.add_argument("--api-b1", type=int, default=0, metavar="FRAMES",
+    ap.add_argument("--api-b1", type=int, default=-1, metavar="FRAMES",
                     help="also time FRAMES frames through integrate_features() ONE FRAME PER CALL (the reference's loop, "
                          "clipfusion.py:1125-1133) with the deferred window queue behind it; reported as api_b1")
     ap.add_argument("--queries", type=int, default=1000, help="--query: number of target text queries")
@@ -126,6 +126,8 @@ def parse():
         g3 = g3 * 3
     assert len(g3) == 3 and min(g3) > 0, "--grid takes N or nx,ny,nz"
     a.grid3 = g3
+    if a.api_b1 < 0:  # default: on for the plain single-GPU run (the reference's call pattern, reported beside the bulk rate)
+        a.api_b1 = 512 if (a.gpus == 1 and not a.query and not a.scene and not a.no_side) else 0
     if a.end_to_end < 0:  # default: on for the plain single-GPU run (128 frames, one frame per integrate() call, bf16 tower)
         a.end_to_end = 128 if (a.gpus == 1 and not a.query and not a.labels and a.dim == 512 and not a.no_side) else 0
     a.grid = g3[0] if g3[0] == g3[1] == g3[2] else "x".join(str(x) for x in g3)  # (label; cubic grids keep the integer)
@@ -847,6 +849,8 @@ def main():
         }
         if api_b1 is not None:
             out["api_b1"] = api_b1
+            if side is not None:  # (the driver's default line: the reference's own call pattern beside the other workloads)
+                side["api_b1"] = api_b1
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

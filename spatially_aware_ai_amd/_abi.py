@@ -86,6 +86,12 @@ PROTOTYPES = {
          C.POINTER(C.c_void_p), C.c_int32, _fp, C.c_size_t, _fp, C.c_void_p, C.c_void_p],
     ),
     "saf_fuse_path": (C.c_int, [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, C.c_size_t]),
+    "saf_fuse_session_create": (C.c_void_p, []),
+    "saf_fuse_session_push": (C.c_int, [C.c_void_p, C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp, _fp]),
+    "saf_fuse_session_finish": (C.c_int, [C.c_void_p, _fp]),
+    "saf_fuse_session_abandon": (C.c_int, [C.c_void_p]),
+    "saf_fuse_session_pending": (C.c_int, [C.c_void_p]),
+    "saf_fuse_session_destroy": (None, [C.c_void_p]),
     "saf_clear_unwritten_rows": (C.c_int, [C.POINTER(SafVolume), C.c_int64, C.c_int64, _fp]),
     "saf_profiler_create": (_fp, [C.c_int32]),
     "saf_profiler_destroy": (None, [_fp]),
@@ -148,6 +154,7 @@ PROTOTYPES = {
     "saf_save_npy": (C.c_int, [_fp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_char_p, _fp]),
     "saf_dwconv7x7_nhwc": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "saf_mesh_json": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "saf_array_json": (C.c_int, [_fp, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "saf_free": (None, [C.c_void_p]),
     "saf_save_ply": (C.c_int, [C.c_char_p, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int32]),
     "saf_marching_cubes_workspace_bytes": (C.c_size_t, [C.c_int64]),

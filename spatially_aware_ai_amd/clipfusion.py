@@ -111,6 +111,18 @@ class _FusionVolumeMixin:
         self.__dict__["_pending_n"] = 0
         self.__dict__["_stage"] = None
         self.__dict__["_feat_stale"] = False
+        self.__dict__["_session"] = None       # saf_fuse_session handle of the queue's flushes (created at the first one)
+        self.__dict__["_session_open"] = False  # a pushed window's row kernel is still owed (saf_fuse_session_finish)
+        self.__dict__["_fs"] = None             # the queue's own stream: a flush runs beside the staging of later frames
+        self.__dict__["_fs_event"] = None       # recorded behind the last finish: whoever reads the volume waits for it
+
+    def __del__(self):
+        h = self.__dict__.get("_session")
+        if h:
+            try:
+                lib().saf_fuse_session_destroy(h)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
 
     # -- C structs -------------------------------------------------------------------------
     def _c_volume(self, for_fuse=False):
@@ -210,10 +222,14 @@ class _FusionVolumeMixin:
     # clipfusion.py:1120-1133).  One frame per C call would run the per-frame pipeline; the windowed path
     # (saf_fuse_frames with 16+ frames: every touched feature row travels to HBM once per 128-frame window)
     # needs many frames in one call.  Small calls are therefore queued -- their inputs copied into a staging ring
-    # of four windows (512 slots) -- and fused when the ring is full, when a window is complete and the device is idle,
-    # or when anything reads or replaces the
-    # volume: the registered buffers (attribute access, state_dict, .to()), stats(), extract_mesh, the merge.
-    # The two device paths are bit-identical, so a caller cannot tell -- except by speed.
+    # of four windows (512 slots) -- and handed to the library a WINDOW at a time (round 6): every completed window is pushed
+    # into a streaming session (saf_fuse_session_push) on a stream of the queue's own -- its classification runs beside the row
+    # kernel of the window before it, and the caller's stream goes on staging the next frames into the ring's other quarters
+    # meanwhile (rounds 2-5: one saf_fuse_frames call per flush on the caller's stream -- every flush exposed its first
+    # window's classification, 3.7 ms, and later frames' staging kernels queued behind the flush, 3 ms: 0.86-0.90 of the bulk
+    # rate).  Whatever reads or replaces the volume -- the registered buffers (attribute access, state_dict, .to()), stats(),
+    # extract_mesh, the merge -- pushes what is staged, finishes the session and lets its stream wait for it.
+    # The device paths are bit-identical, so a caller cannot tell -- except by speed.
     _DEFER_MAX_BATCH = 15  # calls of 16+ frames take the windowed path by themselves
     # up to four windows per flush (from the second one on, a window is classified beside its predecessor's rows); a full
     # window is flushed earlier when the device has finished the previous flush and would otherwise idle
@@ -245,7 +261,7 @@ class _FusionVolumeMixin:
         else:
             lazy = None
             if clip_feat_img.dim() != 4 or not self._defer_ok(bsz, int(clip_feat_img.shape[2]), int(clip_feat_img.shape[3])):
-                self._flush_pending()
+                self._flush_pending(final=True)  # (frames are fused in call order)
                 return self._fuse_now(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
             fshape = tuple(int(v) for v in clip_feat_img.shape[1:])
         h, w = int(depth_imgs.shape[1]), int(depth_imgs.shape[2])
@@ -269,13 +285,15 @@ class _FusionVolumeMixin:
         key = (h, w, tuple(fshape), label_maps is not None, bool(rgb_bilinear), None if lazy is None else (id(lazy[0]),) + lazy[1:])
         st = self.__dict__.get("_stage")
         if st is None or st["key"] != key:
-            self._flush_pending()
+            self._flush_pending(final=True)  # (the old ring's frames; the session of the old shape)
             dev = self._buffers["tsdf"].device
             n = self._QUEUE_FRAMES
             mk = lambda *shape: torch.empty((n,) + shape, dtype=torch.float32, device=dev)
             st = {"key": key, "depth": mk(h, w), "rgb": mk(h, w, 3), "pose": mk(4, 4), "K": mk(3, 3),
-                  "feat": mk(*key[2]), "labels": mk(h, w) if label_maps is not None else None, "event": None,
-                  "stream": None, "lazy": lazy,
+                  "feat": mk(*key[2]), "labels": mk(h, w) if label_maps is not None else None, "lazy": lazy,
+                  # the frames staged and not yet handed over lie in slots [ring0, ring0 + _pending_n); free_ev[q]: the event
+                  # behind the row kernel that reads quarter q's frames (None: free); held: quarters whose row kernel is owed
+                  "ring0": 0, "free_ev": [None] * (self._QUEUE_FRAMES // _abi.SAF_WINDOW_FRAMES), "held": [],
                   "src": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0),
                   "dst": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0)}
             # base addresses and byte strides of the ring's slots (no tensor views per call)
@@ -287,47 +305,51 @@ class _FusionVolumeMixin:
             # current_stream(dev), not current_stream(): without a device torch asks is_available() first, which looks up
             # an environment variable by raising and catching a KeyError -- up to 100 us per call in a long-lived process
             stream = torch.cuda.current_stream(dev)
-            if st["event"] is not None and st["stream"] != stream.cuda_stream:
-                stream.wait_event(st["event"])  # the last flush may still be reading the staging ring on its stream
             fast = lazy is not None or (
                 all(t.dtype == f32 for t in (depth_imgs, rgb_imgs, poses, K, clip_feat_img)) and depth_imgs.is_contiguous()
                 and rgb_imgs.is_contiguous() and poses.is_contiguous() and K.is_contiguous() and
                 (label_maps is None or all(m.dtype == f32 and m.is_contiguous() for m in label_maps)))
             src, dst, base, step = st["src"], st["dst"], st["base"], st["step"]
             raw_stream = stream.cuda_stream
+            win = _abi.SAF_WINDOW_FRAMES
             if fast:
                 fs = (0, 0, 0, 0) if lazy is not None else clip_feat_img.stride()
                 sp = (depth_imgs.data_ptr(), rgb_imgs.data_ptr(), poses.data_ptr(), K.data_ptr(),
                       0 if lazy is not None else clip_feat_img.data_ptr())
             for i in range(bsz):
                 k = self.__dict__["_pending_n"]
-                if k >= self._QUEUE_FRAMES:
+                if st["ring0"] + k >= self._QUEUE_FRAMES:
                     # a full ring means an earlier flush failed and kept its frames: try again (it re-raises) -- never
                     # stage into a slot beyond the ring
                     self._flush_pending()
                     k = self.__dict__["_pending_n"]
-                    if k >= self._QUEUE_FRAMES:
+                    if st["ring0"] + k >= self._QUEUE_FRAMES:
                         raise SafError("the staging ring is full and could not be flushed")
+                slot = st["ring0"] + k
+                if slot % win == 0:  # a quarter of the ring is reused: the row kernel that read its frames must be done
+                    ev = st["free_ev"][slot // win]
+                    if ev is not None:
+                        stream.wait_event(ev)
+                        st["free_ev"][slot // win] = None
                 if fast:  # one launch per frame (saf_stage_frame); addresses by arithmetic: no tensor views, no new descriptors
                     src.depth, src.rgb, src.pose = sp[0] + i * step[0], sp[1] + i * step[1], sp[2] + i * 64
                     src.K, src.feat_map = sp[3] + i * 36, (None if lazy is not None else sp[4] + i * fs[0] * 4)
-                    dst.depth, dst.rgb, dst.pose = base[0] + k * step[0], base[1] + k * step[1], base[2] + k * step[2]
-                    dst.K, dst.feat_map = base[3] + k * step[3], base[4] + k * step[4]
+                    dst.depth, dst.rgb, dst.pose = base[0] + slot * step[0], base[1] + slot * step[1], base[2] + slot * step[2]
+                    dst.K, dst.feat_map = base[3] + slot * step[3], base[4] + slot * step[4]
                     if label_maps is not None:
-                        src.label_map, dst.label_map = label_maps[i].data_ptr(), base[5] + k * step[5]
+                        src.label_map, dst.label_map = label_maps[i].data_ptr(), base[5] + slot * step[5]
                     check(lib().saf_stage_frame(C.byref(src), key[2][0], fs[1], fs[2], fs[3], C.byref(dst), raw_stream),
                           "saf_stage_frame")
                 else:  # other dtypes / layouts: PyTorch copies convert
-                    st["depth"][k].copy_(depth_imgs[i], non_blocking=True)
-                    st["rgb"][k].copy_(rgb_imgs[i], non_blocking=True)
-                    st["pose"][k].copy_(poses[i], non_blocking=True)
-                    st["K"][k].copy_(K[i], non_blocking=True)
-                    st["feat"][k].copy_(clip_feat_img[i], non_blocking=True)
+                    st["depth"][slot].copy_(depth_imgs[i], non_blocking=True)
+                    st["rgb"][slot].copy_(rgb_imgs[i], non_blocking=True)
+                    st["pose"][slot].copy_(poses[i], non_blocking=True)
+                    st["K"][slot].copy_(K[i], non_blocking=True)
+                    st["feat"][slot].copy_(clip_feat_img[i], non_blocking=True)
                     if label_maps is not None:
-                        st["labels"][k].copy_(label_maps[i], non_blocking=True)
+                        st["labels"][slot].copy_(label_maps[i], non_blocking=True)
                 self.__dict__["_pending_n"] = k + 1
-                if k + 1 == self._QUEUE_FRAMES or ((k + 1) % _abi.SAF_WINDOW_FRAMES == 0 and
-                                                   (st["event"] is None or st["event"].query())):
+                if (slot + 1) % win == 0:  # a window is complete: hand it over (its classification starts; its rows follow the next push)
                     self._flush_pending()
             if fast:  # the sources are read asynchronously on this stream
                 for t in (depth_imgs, rgb_imgs, poses, K) + (() if lazy is not None else (clip_feat_img,)) + tuple(label_maps or ()):
@@ -340,14 +362,10 @@ class _FusionVolumeMixin:
         self._sync_volume()
 
     def _sync_volume(self):
-        # the frames flushed HERE are the last before somebody looks: if the deferred clear of reset() is still owed, their call
-        # zeroes the unwritten rows beside its last row kernel (_fuse_now).  Flushes the queue starts on its own keep owing it -- a
-        # scan of several flushes would otherwise zero, after its first window, most of a volume that the later windows write
-        self.__dict__["_finishing"] = True
-        try:
-            self._flush_pending()
-        finally:
-            self.__dict__["_finishing"] = False
+        # the frames flushed HERE are the last before somebody looks: the queue's session is finished behind them, the deferred
+        # clear of reset() -- still owed after the flushes the queue started on its own: a scan of several windows would otherwise
+        # zero, after its first window, most of a volume that the later windows write -- is paid, and the current stream waits
+        self._flush_pending(final=True)
         if self.__dict__.get("_feat_stale"):
             # reset() did not clear the feature rows: zero the ones that are still unwritten (weight 0)
             self.__dict__["_feat_stale"] = False
@@ -357,39 +375,84 @@ class _FusionVolumeMixin:
                 check(lib().saf_clear_unwritten_rows(C.byref(vol), 0, self._buffers["tsdf"].numel(), current_stream_ptr()),
                       "saf_clear_unwritten_rows")
 
-    def _flush_pending(self):
+    def _queue_busy(self):
+        """Frames staged but not handed over, or a pushed window whose row kernel is still owed."""
+        return bool(self.__dict__.get("_pending_n", 0) or self.__dict__.get("_session_open"))
+
+    def _wait_for_queue(self):
+        """The current stream waits for what the queue's stream has been given (readers of the volume)."""
+        ev = self.__dict__.get("_fs_event")
+        if ev is not None:
+            dev = self._buffers["tsdf"].device
+            torch.cuda.current_stream(dev).wait_event(ev)
+
+    def _finish_session(self):
+        """Launch the row kernel of the window the session still holds (on the queue's stream) and let the current stream wait."""
+        if not self.__dict__.get("_session_open"):
+            self._wait_for_queue()
+            return
+        dev = self._buffers["tsdf"].device
+        fs = self.__dict__["_fs"]
+        with torch.cuda.device(dev):
+            rc = lib().saf_fuse_session_finish(self.__dict__["_session"], fs.cuda_stream)
+            self.__dict__["_session_open"] = False
+            ev = fs.record_event()
+            self.__dict__["_fs_event"] = ev
+            st = self.__dict__.get("_stage")
+            if st is not None:
+                for q in st["held"]:
+                    st["free_ev"][q] = ev
+                st["held"] = []
+            if rc != 0:  # its windows are classified and partly fused: nothing to retry
+                self.__dict__["_poisoned"] = "the queue's session could not launch its last row kernel; the volume is incomplete: reset() it"
+            check(rc, "saf_fuse_session_finish")
+            torch.cuda.current_stream(dev).wait_event(ev)
+
+    def _flush_pending(self, final=False):
+        """Hand the staged frames to the library.  ``final``: somebody is about to look -- the session is finished behind them
+        (its last window's rows launched, the current stream waits); else (a window just completed) the window is pushed and
+        its row kernel stays owed until the next push."""
         n = self.__dict__.get("_pending_n", 0)
         if not n:
+            if final:
+                self._finish_session()
             return
         self._check_poisoned()
         self.__dict__["_pending_n"] = 0  # first: the buffer accesses below must not re-enter
         self.__dict__["_fuse_launched"] = False
         st = self.__dict__["_stage"]
+        lo = st["ring0"]
+        sl = slice(lo, lo + n)
         try:
-            labs = None if st["labels"] is None else st["labels"][:n]
-            feat = st["feat"][:n]
+            labs = None if st["labels"] is None else st["labels"][sl]
+            feat = st["feat"][sl]
             if st.get("lazy") is not None:  # the queued frames' feature maps, in one backbone batch
                 fn, ac_on, ac_dtype = st["lazy"]
                 with torch.no_grad(), torch.autocast("cuda", dtype=ac_dtype, enabled=ac_on):
-                    feat = fn(st["rgb"][:n])
+                    feat = fn(st["rgb"][sl])
                 if tuple(feat.shape) != (n,) + tuple(st["key"][2]):
                     raise SafError(f"the backbone returned {tuple(feat.shape)} for {n} frames, expected {(n,) + tuple(st['key'][2])}")
-            self._fuse_now(st["depth"][:n], st["rgb"][:n], st["pose"][:n], st["K"][:n], feat, labs, st["key"][4])
+                # into the ring: the last window's row kernel reads its maps when the NEXT push launches it -- a temporary of
+                # this call would be back in the allocator's hands by then (the ring's quarters are guarded by events)
+                st["feat"][sl].copy_(feat)
+                feat = st["feat"][sl]
+            self._fuse_now(st["depth"][sl], st["rgb"][sl], st["pose"][sl], st["K"][sl], feat, labs, st["key"][4], staged=(lo, n, final))
         except BaseException as exc:
             if not self.__dict__.get("_fuse_launched"):
-                # the backbone, the descriptors or the argument checks at the entry of saf_fuse_frames failed (out of
+                # the backbone, the descriptors or the argument checks at the entry of the fuse call failed (out of
                 # memory, an unsupported tiling) BEFORE any kernel touched the volume: the frames stay queued -- the next
                 # access raises again instead of reading a volume that silently lacks them
                 self.__dict__["_pending_n"] = n
             else:
-                # saf_fuse_frames failed after launching some of its windows: fusing the same frames again would count them
+                # the call failed after launching some of its windows: fusing the same frames again would count them
                 # twice, dropping them would lose them silently.  Neither: the volume is unusable until reset().
                 self.__dict__["_poisoned"] = f"a flush of {n} queued frames failed part-way ({exc!r}); the volume is incomplete: reset() it"
             raise
-        dev = self._buffers["tsdf"].device
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev)
-            st["event"], st["stream"] = stream.record_event(), stream.cuda_stream
+        if final:
+            self._finish_session()
+            st["ring0"] = 0  # (every quarter now carries the event of the finish, or of the call on the current stream)
+        else:
+            st["ring0"] = (lo + n) % self._QUEUE_FRAMES  # whole windows: the next frames go to the ring's next quarter
 
     def _check_poisoned(self):
         msg = self.__dict__.get("_poisoned")
@@ -398,7 +461,7 @@ class _FusionVolumeMixin:
 
     @property
     def pending_frames(self):
-        """Frames queued behind integrate() and not yet fused."""
+        """Frames staged behind integrate() and not yet handed to the fuse call (a completed window is handed over at once)."""
         return self.__dict__.get("_pending_n", 0)
 
     def __getattr__(self, name):
@@ -408,19 +471,25 @@ class _FusionVolumeMixin:
                 self._check_poisoned()
             if name == "clip_feat" and self.__dict__.get("_feat_stale"):
                 self._sync_volume()  # queued frames AND the deferred clear: the rows are about to be looked at
-            elif self.__dict__.get("_pending_n", 0):
-                self._flush_pending()
+            elif self.__dict__.get("_pending_n", 0) or self.__dict__.get("_session_open"):
+                self._flush_pending(final=True)
+            elif self.__dict__.get("_fs_event") is not None:
+                self._wait_for_queue()  # (a reader on another stream than the one that finished the session)
         return super().__getattr__(name)
 
     def __setattr__(self, name, value):
-        if (name in _VOLUME_BUFFERS or name == "accum_mode") and (self.__dict__.get("_pending_n", 0) or self.__dict__.get("_feat_stale")):
+        if (name in _VOLUME_BUFFERS or name == "accum_mode") and (self._queue_busy() or self.__dict__.get("_feat_stale")):
             self._sync_volume()  # queued frames belong to the buffers / mode that were current when they were queued
         super().__setattr__(name, value)
 
     def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .cpu() / .float()
-        if self.__dict__.get("_pending_n", 0) or self.__dict__.get("_feat_stale"):
+        if self._queue_busy() or self.__dict__.get("_feat_stale"):
             self._sync_volume()
+        self._wait_for_queue()
         self.__dict__["_stage"] = None
+        self.__dict__["_fs"] = None  # (a stream of the old device)
+        self.__dict__["_fs_event"] = None
+        self.__dict__["_fs_seen"] = None
         return super()._apply(fn, *args, **kwargs)
 
     def _save_to_state_dict(self, *args, **kwargs):
@@ -440,7 +509,28 @@ class _FusionVolumeMixin:
         self._sync_volume()
         return super().named_buffers(*args, **kwargs)
 
-    def _fuse_now(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False):
+    def _queue_stream(self, dev, tensors):
+        """The queue's own stream (created at the first push); ``tensors`` it is about to use are marked for the allocator
+        (record_stream, once per allocation: whoever frees them -- a deleted module, a regrown workspace -- must not hand the
+        memory out while that stream still reads it)."""
+        fs = self.__dict__.get("_fs")
+        if fs is None:
+            fs = torch.cuda.Stream(device=dev)
+            self.__dict__["_fs"] = fs
+            self.__dict__["_fs_seen"] = set()
+        seen = self.__dict__.get("_fs_seen")
+        if seen is None:
+            seen = self.__dict__["_fs_seen"] = set()
+        for t in tensors:
+            if t is not None and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                t.record_stream(fs)
+        return fs
+
+    def _fuse_now(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps=None, rgb_bilinear=False, staged=None):
+        """``staged`` = (first ring slot, frames, final): the frames lie in the queue's staging ring -- where the windowed
+        two-stream path takes them they are PUSHED into the queue's session on its own stream (their last window's row kernel
+        stays owed: ``_finish_session``); everything else is one call on the current stream, behind the session."""
         if getattr(self, "_shard_stripes", None) is not None:
             raise SafError(
                 "this volume holds only its reduce-scattered voxel stripes "
@@ -450,30 +540,60 @@ class _FusionVolumeMixin:
         arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
         vol = self._c_volume(for_fuse=True)
         ws = self._get_workspace(npy, npx, (int(depth_imgs.shape[1]), int(depth_imgs.shape[2])))
-        # after a lazy reset() the feature rows still hold the previous scan: saf_fuse_frames_recycled fuses and leaves every row
-        # of a voxel that is still unwritten zero (beside the last window's row kernel; before the per-frame pipeline, which
-        # reads the rows it updates).  Used for the per-frame pipeline and for the flush behind which somebody looks
-        stale = bool(self.__dict__.get("_feat_stale"))
-        if stale and not self.__dict__.get("_finishing") and lib().saf_fuse_path(C.byref(vol), arr, len(arr), ws.numel()) == 1:
-            stale = False  # the windowed path never reads a weight-0 row: the clear stays owed until somebody looks (_sync_volume)
+        L = lib()
+        windowed = L.saf_fuse_path(C.byref(vol), arr, len(arr), ws.numel()) == 1
         # the module's device, not the caller's current one, owns the launch (and its current stream)
         dev = self._buffers["tsdf"].device
+        st = self.__dict__.get("_stage")
+        win = _abi.SAF_WINDOW_FRAMES
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)
+            if staged is not None and windowed and os.environ.get("SAF_WIN_OVERLAP", "1")[:1] != "0":
+                lo, n, _final = staged
+                b = self._buffers
+                fs = self._queue_stream(dev, [ws, st["depth"], st["rgb"], st["pose"], st["K"], st["feat"], st["labels"]] +
+                                        [b.get(k) for k in ("tsdf", "tsdf_weight", "weight", "rgb", "clip_feat", "labels_one_hot",
+                                                            "axis_x", "axis_y", "axis_z", "fuse_stats")])
+                fs.wait_event(stream.record_event())  # the staging kernels (and a deferred backbone's maps) of these frames
+                if self.__dict__.get("_session") is None:
+                    self.__dict__["_session"] = L.saf_fuse_session_create()
+                rc = L.saf_fuse_session_push(self.__dict__["_session"], C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(),
+                                             b["fuse_stats"].data_ptr(), fs.cuda_stream)
+                # SAF_E_INVALID / _WORKSPACE / _UNSUPPORTED come from the checks at the entry (every frame descriptor is validated
+                # before the first launch); a HIP error may have left some windows fused (see _flush_pending)
+                self.__dict__["_fuse_launched"] = rc == 0 or rc == _abi.SAF_E_HIP
+                if rc == 0:
+                    self.__dict__["_session_open"] = True
+                    ev = fs.record_event()
+                    self.__dict__["_fs_event"] = ev
+                    quarters = list(range(lo // win, (lo + n - 1) // win + 1))
+                    for q in st["held"] + quarters[:-1]:  # their row kernels are queued: behind `ev` their frames are free
+                        st["free_ev"][q] = ev
+                    st["held"] = quarters[-1:]
+                check(rc, "saf_fuse_session_push")
+                return
+            # one call on the current stream: whatever the session still owes comes first
+            self._finish_session()
+            # after a lazy reset() the feature rows still hold the previous scan: the windowed path never reads a weight-0 row
+            # (the clear stays owed until somebody looks: _sync_volume); the per-frame pipeline reads the rows it updates --
+            # saf_fuse_frames_recycled zeroes the unwritten rows first
+            stale = bool(self.__dict__.get("_feat_stale")) and not windowed
             if stale:
-                rc = lib().saf_fuse_frames_recycled(
+                rc = L.saf_fuse_frames_recycled(
                     C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), None, stream.cuda_stream
                 )
             else:
-                rc = lib().saf_fuse_frames(
+                rc = L.saf_fuse_frames(
                     C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(), self._buffers["fuse_stats"].data_ptr(), stream.cuda_stream
                 )
             if stale and rc == 0:  # (the recycled call: every weight-0 row is zero behind it)
                 self.__dict__["_feat_stale"] = False
-            # SAF_E_INVALID / _WORKSPACE / _UNSUPPORTED come from the checks at the entry (every frame descriptor is validated
-            # before the first launch); a HIP error may have left some windows fused (see _flush_pending)
             self.__dict__["_fuse_launched"] = rc == 0 or rc == _abi.SAF_E_HIP
             check(rc, "saf_fuse_frames")
+            if staged is not None:  # the ring's slots of these frames are read on this stream
+                ev = stream.record_event()
+                for q in range(staged[0] // win, (staged[0] + staged[1] - 1) // win + 1):
+                    st["free_ev"][q] = ev
             # the launches are asynchronous: keep inputs alive until the stream has consumed them
             for t in keep[:5]:
                 t.record_stream(stream)
@@ -490,6 +610,20 @@ class _FusionVolumeMixin:
         self.__dict__["_poisoned"] = None
         self.__dict__["_feat_stale"] = False
         b = self._buffers
+        fs = self.__dict__.get("_fs")
+        if fs is not None:
+            # a pushed window whose row kernel is still owed is dropped with the volume; what the queue's stream (and the
+            # library's classification stream behind it) already runs must finish before the buffers are zeroed here
+            if self.__dict__.get("_session") is not None:
+                check(lib().saf_fuse_session_abandon(self.__dict__["_session"]), "saf_fuse_session_abandon")
+            self.__dict__["_session_open"] = False
+            ev = fs.record_event()
+            self.__dict__["_fs_event"] = ev
+            torch.cuda.current_stream(b["tsdf"].device).wait_event(ev)
+            st = self.__dict__.get("_stage")
+            if st is not None:
+                st["held"], st["ring0"] = [], 0
+                st["free_ev"] = [ev] * len(st["free_ev"])
         lazy = bool(lazy) and b["clip_feat"].is_cuda
         for name in ("rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot") + (() if lazy else ("clip_feat",)):
             t = b.get(name)

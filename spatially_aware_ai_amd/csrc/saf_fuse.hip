@@ -1117,6 +1117,80 @@ int saf_fuse_frame(const saf_volume* vol, const saf_frame* frame, void* workspac
 
 int saf_poll_async_error(void) { return poll_latch(); }
 
+// ---- streaming sessions (round 6): consecutive windowed calls as ONE unit pipeline ----
+struct saf_fuse_session {
+  PipeRes* pr = nullptr;
+  WinCarry carry;
+  const void* feat = nullptr;  // identity of the volume and workspace the pending unit belongs to
+  void* workspace = nullptr;
+  size_t workspace_bytes = 0;
+  uint64_t* stats = nullptr;
+};
+
+saf_fuse_session* saf_fuse_session_create(void) {
+  saf_fuse_session* ss = new saf_fuse_session;
+  for (int k = 0; k < 8; ++k) ss->carry.tile_window[k] = -1;
+  return ss;
+}
+
+static int session_run(saf_fuse_session* ss, const KVol& kv, const saf_frame* frames, int32_t n_frames, bool hold, hipStream_t s) {
+  if (!ss->pr && !(ss->pr = pipe_acquire())) return fail(SAF_E_HIP, "could not create the classification stream / events of a session");
+  PipeRes* pr = ss->pr;
+  WinOverlap ov;
+  ov.aux = pr->aux; ov.fork = pr->fork; ov.join = pr->join;
+  ov.cls_done[0] = pr->fused[0]; ov.cls_done[1] = pr->fused[1]; ov.fuse_done[0] = pr->fused[2]; ov.fuse_done[1] = pr->fused[3];
+  ov.tiles = pr->tiles;
+  ss->carry.hold = hold;
+  return fuse_many_windowed(kv, frames, n_frames, ss->workspace, ss->workspace_bytes, ss->stats, nullptr, s, &ov, nullptr, false, &ss->carry);
+}
+
+int saf_fuse_session_push(saf_fuse_session* ss, const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,
+                          size_t workspace_bytes, uint64_t* stats, void* stream) {
+  if (!ss) return fail(SAF_E_INVALID, "session is NULL");
+  KVol kv;
+  int rc = make_kvol(vol, &kv);
+  if (rc) return rc;
+  if (n_frames <= 0 || !frames) return fail(SAF_E_INVALID, "bad frame array");
+  if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
+  if (!window_ok(kv, frames, n_frames, workspace_bytes) || (getenv("SAF_WIN_OVERLAP") && getenv("SAF_WIN_OVERLAP")[0] == '0'))
+    return fail(SAF_E_UNSUPPORTED, "a streaming session takes what the windowed two-stream path takes (saf_fuse_path == 1, SAF_WIN_OVERLAP != 0)");
+  if (ss->carry.pending && (ss->feat != kv.feat || ss->workspace != workspace || ss->workspace_bytes != workspace_bytes || ss->stats != stats))
+    return fail(SAF_E_INVALID, "a session with a pending window continues on the same volume, workspace and counters: finish it first");
+  if ((rc = poll_latch())) return rc;
+  ensure_latch();
+  ss->feat = kv.feat; ss->workspace = workspace; ss->workspace_bytes = workspace_bytes; ss->stats = stats;
+  return session_run(ss, kv, frames, n_frames, true, static_cast<hipStream_t>(stream));
+}
+
+int saf_fuse_session_finish(saf_fuse_session* ss, void* stream) {
+  if (!ss) return fail(SAF_E_INVALID, "session is NULL");
+  int rc = SAF_OK;
+  if (ss->carry.pending) rc = session_run(ss, ss->carry.kv, nullptr, 0, false, static_cast<hipStream_t>(stream));
+  // the next push starts a new pipeline (its first classification alone): counts and tile slots start over
+  ss->carry.pending = false;
+  ss->carry.n_units = 0;
+  ss->carry.n_windows = 0;
+  for (int k = 0; k < 8; ++k) ss->carry.tile_window[k] = -1;
+  return rc;
+}
+
+int saf_fuse_session_abandon(saf_fuse_session* ss) {
+  if (!ss) return fail(SAF_E_INVALID, "session is NULL");
+  ss->carry.pending = false;  // (its classification ran -- TSDF and masks of a volume that is being discarded; no row kernel follows)
+  ss->carry.n_units = 0;
+  ss->carry.n_windows = 0;
+  for (int k = 0; k < 8; ++k) ss->carry.tile_window[k] = -1;
+  return SAF_OK;
+}
+
+int saf_fuse_session_pending(const saf_fuse_session* ss) { return ss && ss->carry.pending ? ss->carry.F : 0; }
+
+void saf_fuse_session_destroy(saf_fuse_session* ss) {
+  if (!ss) return;
+  if (ss->pr) pipe_release(ss->pr);  // (what is queued on its stream stays ordered: the next user queues behind it)
+  delete ss;
+}
+
 int saf_fuse_path(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
   KVol kv;
   if (make_kvol(vol, &kv) || n_frames <= 0 || !frames) return -1;

@@ -207,6 +207,48 @@ int saf_mesh_json(const float* verts, int64_t n_verts, const int32_t* faces, int
   return SAF_OK;
 }
 
+/* A HOST array [rows, cols] as the JSON text of ndarray.tolist(): "[[a, b, c], ...]" (cols == 0: a flat list "[a, b, ...]" of
+ * `rows` numbers), Python's separators.  dtype_code: 0 f32, 3 i32, 4 i64, 6 f64 (saf_save_npy's codes; 6 new).  The voxel lists
+ * and per-object meshes of scene_knowledge.json (clip_seem_fusion.py:393-417, :603-604; handy_utils.py:430-452): the reference
+ * turns them into Python lists of tuples first -- seconds of interpreter time per scan. */
+int saf_array_json(const void* data, int32_t dtype_code, int64_t rows, int32_t cols, char** out, int64_t* out_len) {
+  if (!out || !out_len || rows < 0 || cols < 0 || (rows && !data) || (dtype_code != 0 && dtype_code != 3 && dtype_code != 4 && dtype_code != 6))
+    return fail(SAF_E_INVALID, "array_json: bad arguments");
+  std::string s;
+  const int w = cols > 0 ? cols : 1;
+  s.reserve((size_t)rows * ((size_t)w * (dtype_code == 0 || dtype_code == 6 ? 24 : 12) + 4) + 16);
+  auto put = [&](int64_t i) {
+    switch (dtype_code) {
+      case 0: put_double(s, (double)static_cast<const float*>(data)[i]); break;
+      case 6: put_double(s, static_cast<const double*>(data)[i]); break;
+      case 3: put_int(s, static_cast<const int32_t*>(data)[i]); break;
+      default: put_int(s, static_cast<const int64_t*>(data)[i]); break;
+    }
+  };
+  s += '[';
+  for (int64_t i = 0; i < rows; ++i) {
+    if (cols == 0) {
+      if (i) s += ", ";
+      put(i);
+      continue;
+    }
+    s += i ? ", [" : "[";
+    for (int j = 0; j < cols; ++j) {
+      if (j) s += ", ";
+      put(i * cols + j);
+    }
+    s += ']';
+  }
+  s += ']';
+  char* buf = static_cast<char*>(malloc(s.size() + 1));
+  if (!buf) return fail(SAF_E_INVALID, "array_json: out of memory");
+  memcpy(buf, s.data(), s.size());
+  buf[s.size()] = 0;
+  *out = buf;
+  *out_len = (int64_t)s.size();
+  return SAF_OK;
+}
+
 void saf_free(void* p) { free(p); }
 
 /* Binary little-endian PLY: vertices x y z (float) + red green blue alpha (uchar; colors [n_verts, n_color] f32 in 0..1,

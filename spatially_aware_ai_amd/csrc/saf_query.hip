@@ -181,6 +181,35 @@ __device__ __forceinline__ float4 load_feat4(const void* __restrict__ base, int6
   return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
 }
 
+#ifndef SAF_QM_GROUP
+#define SAF_QM_GROUP 8
+#endif
+#ifndef SAF_QM_SLOTS
+#define SAF_QM_SLOTS 2  // register groups of the row ring (one is multiplied, the others are in flight)
+#endif
+#ifndef SAF_QM_NT
+#define SAF_QM_NT 0     // 1: the rows as non-temporal loads (they are read once)
+#endif
+#ifndef SAF_QM_ABL
+#define SAF_QM_ABL 0    // development (WRONG results): 1 = no row loads (constants), 2 = no MFMAs
+#endif
+constexpr int kQGroup = SAF_QM_GROUP;  // K chunks (of 8 floats) per prefetch group: 64 floats of every row
+constexpr int kQSlots = SAF_QM_SLOTS;
+
+template <int FT>
+__device__ __forceinline__ float4 load_row4(const void* __restrict__ base, int64_t i) {  // the scan's row stream (knobs above)
+#if SAF_QM_ABL & 1
+  return make_float4((float)(i & 7), 1.0f, 0.5f, 0.25f);
+#else
+  if (SAF_QM_NT && FT == SAF_F32) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(static_cast<const float*>(base) + i));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return load_feat4<FT>(base, i);
+#endif
+}
+
 __device__ __forceinline__ float half_max(float x) {  // over the 32 lanes of this half
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
@@ -192,7 +221,7 @@ __device__ __forceinline__ float half_sum(float x) {
   return x;
 }
 
-constexpr int kQGroup = 8;  // K chunks (of 8 floats) per prefetch group: 64 floats of every row
+
 
 // TH threads per workgroup: 256, or 512 where the text tiles leave room for only ONE workgroup per CU (two 32-row tiles at D = 512:
 // 132 KB) -- four waves would be one per SIMD, each alone with its loads, LDS reads and MFMA chain: the L = 63 surgery scan over
@@ -225,33 +254,45 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     float ss = 0.0f;
-    float4 cur[kQGroup], nxt[kQGroup];
-    if (n_groups > 0) {
+    // The wave's rows stream through a RING of kQSlots register groups (a group = kQGroup chunks of 8 floats of every row: 8 KB per
+    // wave): kQSlots - 1 groups are in flight while one is multiplied.  Round 6: one group ahead (rounds 1-5) is 1.7 us of MFMAs --
+    // less than the latency of an HBM request under this load --, and the L = 63 scan ran at matrix time + memory time.
+    float4 ring[kQSlots][kQGroup];
 #pragma unroll
-      for (int q = 0; q < kQGroup; ++q) nxt[q] = load_feat4<FT>(feats, base + 8 * q);
-    }
-    for (int g = 0; g < n_groups; ++g) {
+    for (int sl = 0; sl + 1 < kQSlots; ++sl) {
+      if (sl < n_groups) {
 #pragma unroll
-      for (int q = 0; q < kQGroup; ++q) cur[q] = nxt[q];
-      if (g + 1 < n_groups) {
-#pragma unroll
-        for (int q = 0; q < kQGroup; ++q) nxt[q] = load_feat4<FT>(feats, base + 8 * ((g + 1) * kQGroup + q));
+        for (int q = 0; q < kQGroup; ++q) ring[sl][q] = load_row4<FT>(feats, base + 8 * (sl * kQGroup + q));
       }
+    }
+    for (int g0 = 0; g0 < n_groups; g0 += kQSlots) {
 #pragma unroll
-      for (int q = 0; q < kQGroup; ++q) {
-        const int k0 = 8 * (g * kQGroup + q);
-        const float4 a = cur[q];
-        ss = __builtin_fmaf(a.x, a.x, ss);
-        ss = __builtin_fmaf(a.y, a.y, ss);
-        ss = __builtin_fmaf(a.z, a.z, ss);
-        ss = __builtin_fmaf(a.w, a.w, ss);
+      for (int sl = 0; sl < kQSlots; ++sl) {
+        const int g = g0 + sl;
+        if (g >= n_groups) break;
+        if (g + kQSlots - 1 < n_groups) {
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-          const float4 b = *reinterpret_cast<const float4*>(tb + t * 32 * tstr + k0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+          for (int q = 0; q < kQGroup; ++q)
+            ring[(sl + kQSlots - 1) % kQSlots][q] = load_row4<FT>(feats, base + 8 * ((g + kQSlots - 1) * kQGroup + q));
+        }
+#pragma unroll
+        for (int q = 0; q < kQGroup; ++q) {
+          const int k0 = 8 * (g * kQGroup + q);
+          const float4 a = ring[sl][q];
+          ss = __builtin_fmaf(a.x, a.x, ss);
+          ss = __builtin_fmaf(a.y, a.y, ss);
+          ss = __builtin_fmaf(a.z, a.z, ss);
+          ss = __builtin_fmaf(a.w, a.w, ss);
+#if !(SAF_QM_ABL & 2)
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            const float4 b = *reinterpret_cast<const float4*>(tb + t * 32 * tstr + k0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+          }
+#endif
         }
       }
     }

@@ -1663,14 +1663,24 @@ struct WinUnit {
 };
 
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
-                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs, bool recycled) {
+                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs, bool recycled,
+                       WinCarry* carry) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   KFrame kf0;
-  if ((rc = make_kframe(&frames[0], &kf0))) return rc;
-  for (int32_t i = 1; i < n_frames; ++i) {
-    KFrame t;
-    if ((rc = make_kframe(&frames[i], &t))) return rc;
+  if (carry && (!ov || (slabs && slabs->n > 0) || recycled)) return fail(SAF_E_INVALID, "a streaming session needs the two-stream schedule, whole volumes and no deferred clear");
+  if (n_frames > 0) {
+    if ((rc = make_kframe(&frames[0], &kf0))) return rc;
+    for (int32_t i = 1; i < n_frames; ++i) {
+      KFrame t;
+      if ((rc = make_kframe(&frames[i], &t))) return rc;
+    }
+    if (carry && carry->pending && (kf0.H != carry->kf0.H || kf0.W != carry->kf0.W || kf0.npy != carry->kf0.npy || kf0.npx != carry->kf0.npx ||
+                                    kf0.rgb_bilinear != carry->kf0.rgb_bilinear || (kf0.label_map == nullptr) != (carry->kf0.label_map == nullptr)))
+      return fail(SAF_E_INVALID, "the frames of a streaming session must share their shapes: finish the session first");
+  } else {  // (a session's finish: only the pending unit's row kernel)
+    if (!carry || !carry->pending) return SAF_OK;
+    kf0 = carry->kf0;
   }
   const int P = kf0.npy * kf0.npx;
   // Two layouts of the workspace: with room for the window's depth images re-laid-out in tiles (a workspace sized by
@@ -1723,14 +1733,21 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   int ts_log2 = 4;
   while (((kf0.W + (1 << ts_log2) - 1) >> ts_log2) * ((kf0.H + (1 << ts_log2) - 1) >> ts_log2) > kMaxDepthTiles) ++ts_log2;
   const int tiles_x = (kf0.W + (1 << ts_log2) - 1) >> ts_log2, n_tiles = tiles_x * ((kf0.H + (1 << ts_log2) - 1) >> ts_log2);
-  int tile_window[kTileWindows];  // which window's tile maxima a slot of the tile region holds (-1: none)
-  for (int k = 0; k < kTileWindows; ++k) tile_window[k] = -1;
+  static_assert(kTileWindows <= 8, "WinCarry::tile_window");
+  int tile_window_local[kTileWindows];  // which window's tile maxima a slot of the tile region holds (-1: none)
+  for (int k = 0; k < kTileWindows; ++k) tile_window_local[k] = -1;
+  int* tile_window = carry ? carry->tile_window : tile_window_local;
+  // a session: this call's units continue the session's count (parity of headers and mask planes, tile slots); a pending unit
+  // of the previous call comes first -- it is classified already, only its row kernel is still owed
+  const int first_new = carry && carry->pending ? 1 : 0;
+  const int ubase = carry ? carry->n_units - first_new : 0, wbase = carry ? carry->n_windows : 0;
   const int wlen = window_frames();
   const int n_win = (n_frames + wlen - 1) / wlen;
   auto win_frames = [&](int w) { return n_frames - w * wlen < wlen ? n_frames - w * wlen : wlen; };
 
   // ---- the units of this call
   std::vector<WinUnit> units;
+  if (first_new) units.push_back(WinUnit{carry->kv, 0, carry->F, 0, -1, carry->window});
   if (slabs && slabs->n > 0) {
     for (int k = 0; k < slabs->n; ++k) {
       if (slabs->x0[k] < 0 || slabs->nx[k] <= 0 || slabs->x0[k] + slabs->nx[k] > kv.nx) return fail(SAF_E_INVALID, "slab %d outside the volume", k);
@@ -1753,7 +1770,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     for (int w = 0; w < n_win; ++w) {
       const int n = w == 0 ? n0 : ns;
       for (int k = 0; k < n; ++k)
-        units.push_back(WinUnit{n == 1 ? kv : slab_kvol(kv, k * (kv.nx / n), kv.nx / n), w * wlen, win_frames(w), k == 0, -1, w});
+        units.push_back(WinUnit{n == 1 ? kv : slab_kvol(kv, k * (kv.nx / n), kv.nx / n), w * wlen, win_frames(w), k == 0, -1, wbase + w});
     }
   }
   const int n_units = (int)units.size();
@@ -1815,7 +1832,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   // The later windows' tiles AHEAD of time, on the caller's stream: it is idle until the first window has been classified, and
   // every such pair of small launches inside the classification chain (16 per 512-frame job, ~70 us each beside a row kernel)
   // lengthens the chain that a job's time follows.  Window 0's stay in front of its classification.
-  const bool pre_tiles = ov && ov->tiles && !(slabs && slabs->n > 0) && n_units == n_win && n_win >= 2 &&
+  const bool pre_tiles = ov && ov->tiles && !carry && !(slabs && slabs->n > 0) && n_units == n_win && n_win >= 2 &&
                          !(getenv("SAF_WIN_PRETILES") && getenv("SAF_WIN_PRETILES")[0] == '0');
   if (pre_tiles) {
     for (int w = 1; w < n_win && w < kTileWindows; ++w) {
@@ -1827,11 +1844,11 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   auto classify = [&](int ui) -> int {
     const WinUnit& u = units[ui];
     const Geom g = geom(u.kv);
-    const int F = u.F, f0 = u.f0, par = ui & 1;
+    const int F = u.F, f0 = u.f0, gi = ubase + ui, par = gi & 1;  // gi: the unit's index in the session (= ui without one)
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
     // the window's depth tile maxima: computed when a unit of the window first needs them
-    const int widx = f0 / wlen, tslot = widx % kTileWindows;
+    const int widx = wbase + f0 / wlen, tslot = widx % kTileWindows;
     float* dmax_w = reinterpret_cast<float*>(ws + wl.tile_off + (size_t)tslot * wl.tile_win);  // [kWin] largest, [kWin] smallest
     float* tmax_w = dmax_w + 1024;
     float* tdepth_w = tmax_w + (size_t)kWin * kMaxDepthTiles;  // (tiled layout only) the window's depth images in tiles
@@ -1840,7 +1857,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
     WinTable* tab = reinterpret_cast<WinTable*>(hdr + kTableOff);
     mark("classify: begin", ui);
-    if (ov && ui >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
+    if (ov && gi >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
     if (pre_tiles && ui == 1 && hipStreamWaitEvent(cs, ov->tiles, 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent(tiles)");
     // header: unit counters, dmax, the classification launches' counter shards, the frame table
     if (hipMemsetAsync(hdr, 0, kHdrBytes, cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
@@ -1857,7 +1874,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       // (unit 0 has the chip to itself -- everything the caller queued before is done, nothing of this call runs yet --, where the
       //  classification is bound by its vector instructions and the tile offset costs 5 % (0.92 vs 0.97 ms per launch): it reads the
       //  frames' own images; the tiled copies pay where the address path is shared, i.e. for every later unit)
-      const bool use_tiled = tiled && (ui > 0 || (til_env && til_env[0] == '2'));
+      const bool use_tiled = tiled && (gi > 0 || (til_env && til_env[0] == '2'));
       ca.depth_bytes = use_tiled ? (int)(dpx * sizeof(float)) : kf0.H * kf0.W * 4;
       for (int k = 0; k < kClsFrames; ++k) {
         const saf_frame& fr = frames[f0 + fb + (k < ca.n ? k : 0)];
@@ -1897,7 +1914,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (ov && hipEventRecord(ov->cls_done[par], cs) != hipSuccess) return fail(SAF_E_HIP, "hipEventRecord");
     return SAF_OK;
   };
-  if ((rc = classify(0))) return rc;
+  if (n_units > first_new && (rc = classify(first_new))) return rc;
   // A recycled volume (saf_fuse_frames_recycled): the rows of the voxels that are still unwritten when the call is over have to be
   // zeroed -- on a coherent scene five sixths of the volume, 28 GB of stores at 256^3 x 512 and a tenth of the job when they follow
   // it.  When every unit covers the whole volume they are written on the classification stream BESIDE the last unit's row kernel
@@ -1911,13 +1928,22 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   for (int ui = 0; ui < n_units && rc == SAF_OK; ++ui) {
     const WinUnit& u = units[ui];
     const Geom g = geom(u.kv);
-    const int F = u.F, f0 = u.f0, par = ui & 1;
+    const int F = u.F, f0 = u.f0, par = (ubase + ui) & 1;
+    if (carry && carry->hold && ui + 1 == n_units && ui >= first_new) {
+      // a session's last unit stays pending: classified (queued on the classification stream, its event recorded), its row
+      // kernel launched by the next call of the session -- beside that call's first classification
+      carry->pending = true;
+      carry->kv = u.kv; carry->F = F; carry->window = u.window; carry->kf0 = kf0;
+      break;
+    }
+    if (carry && ui == 0 && first_new) carry->pending = false;
     WinArgs wa;
     wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     const WinTable* tab = reinterpret_cast<const WinTable*>(hdr + kTableOff);
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
-    if (ov && ui + 1 < n_units && (rc = classify(ui + 1))) break;  // queued now: it runs beside this unit's row kernel
+    // queued now: it runs beside this unit's row kernel (unit `first_new` was classified ahead of the loop)
+    if (ov && ui + 1 < n_units && ui + 1 > first_new && (rc = classify(ui + 1))) break;
     if (ov && hipStreamWaitEvent(s, ov->cls_done[par], 0) != hipSuccess) { rc = fail(SAF_E_HIP, "hipStreamWaitEvent"); break; }
     if (clear_beside && ui + 1 == n_units) {
       // (queued behind this unit's classification; the row kernel of the unit before must have stored its weights)
@@ -1952,6 +1978,10 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
         hipEventRecord(static_cast<hipEvent_t>(slabs->done[u.done]), s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord(slab done)"); break; }
     if (ov && hipEventRecord(ov->fuse_done[par], s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord"); break; }
     if (!ov && ui + 1 < n_units) rc = classify(ui + 1);
+  }
+  if (carry) {
+    carry->n_units = ubase + n_units;
+    carry->n_windows = wbase + (n_frames > 0 ? n_win : 0);
   }
   if (ov) {  // whatever was queued on the classification stream is ordered before later work of the caller (error paths too)
     if (hipEventRecord(ov->join, cs) == hipSuccess) (void)hipStreamWaitEvent(s, ov->join, 0);

@@ -565,7 +565,7 @@ def fuse_merge_pipelined(fusion, frame_arr, n_frames, workspace, n_slabs=8, grou
     # frames still queued behind integrate() belong to the volume.  A volume fresh from a lazy reset() keeps its deferred clear:
     # the slab-wise call zeroes a slab's still-unwritten rows behind the slab's last row kernel (0.4 ms in all on the benchmark's
     # depth; the clear up front writes all 34 GB)
-    recycled = bool(fusion.__dict__.get("_feat_stale")) and not fusion.pending_frames
+    recycled = bool(fusion.__dict__.get("_feat_stale")) and not fusion._queue_busy()
     if not recycled:
         fusion.flush()
     if fusion.accum_mode != _abi.SAF_SUM:

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from collections import abc as _abc
 
 import numpy as np
 import torch
@@ -66,6 +67,104 @@ def mesh_to_json(verts, faces, colors=None) -> bytes:
         return C.string_at(out, n.value)
     finally:
         lib().saf_free(out)
+
+
+class ArrayList(_abc.Sequence):
+    """A NumPy array standing in for the nested Python list the reference's data model holds in its place -- the voxel
+    coordinates of an object (``flood_fill_3d`` appends tuples, handy_utils.py:430-452) and the per-object meshes
+    (``.tolist()`` of every vertex, face and colour array, clip_seem_fusion.py:393-417): hundreds of thousands of small
+    Python objects per scan, seconds of interpreter time, only to be turned into JSON text or back into an array by whoever
+    reads them.  Reads like the list (``len``, indexing, iteration, ``==`` against lists), converts with ``tolist()`` or
+    ``np.asarray``, and is written to JSON natively (``dumps_scene_knowledge``)."""
+
+    __slots__ = ("array", "tuples")
+
+    def __init__(self, array, tuples=False):
+        self.array = np.ascontiguousarray(array)
+        self.tuples = bool(tuples)  # rows as tuples (the voxel lists) or as lists (tolist())
+
+    def __len__(self):
+        return len(self.array)
+
+    def __getitem__(self, i):
+        v = self.array[i]
+        if isinstance(i, slice):
+            return ArrayList(v, self.tuples)
+        v = v.tolist()
+        return tuple(v) if self.tuples and isinstance(v, list) else v
+
+    def __iter__(self):
+        rows = self.array.tolist()
+        return iter(map(tuple, rows)) if self.tuples and self.array.ndim > 1 else iter(rows)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.array if dtype is None else self.array.astype(dtype)
+
+    def tolist(self):
+        rows = self.array.tolist()
+        return list(map(tuple, rows)) if self.tuples and self.array.ndim > 1 else rows
+
+    def __eq__(self, other):
+        if isinstance(other, ArrayList):
+            return self.array.shape == other.array.shape and bool((self.array == other.array).all())
+        if isinstance(other, (list, tuple)):
+            return len(other) == len(self) and self.tolist() == [tuple(r) if self.tuples and isinstance(r, (list, tuple)) else r for r in other]
+        return NotImplemented
+
+    def __repr__(self):
+        return f"ArrayList(shape={tuple(self.array.shape)}, dtype={self.array.dtype})"
+
+
+_JSON_CODE = {np.dtype(np.float32): 0, np.dtype(np.int32): 3, np.dtype(np.int64): 4, np.dtype(np.float64): 6}
+
+
+def array_to_json(a) -> str:
+    """The JSON text of ``a.tolist()`` for a 1-D or 2-D host array (f32 / f64 / i32 / i64), rendered natively: parses to
+    exactly what ``json.loads(json.dumps(a.tolist()))`` gives."""
+    a = np.ascontiguousarray(a.array if isinstance(a, ArrayList) else a)
+    if a.dtype not in _JSON_CODE:
+        a = a.astype(np.float64 if a.dtype.kind == "f" else np.int64)
+    if a.ndim > 2:
+        a = a.reshape(a.shape[0], -1)
+    rows, cols = (a.shape[0], 0) if a.ndim == 1 else a.shape
+    if a.ndim == 2 and cols == 0:
+        return "[" + ", ".join("[]" for _ in range(rows)) + "]"
+    out, n = C.c_void_p(), C.c_int64()
+    check(lib().saf_array_json(a.ctypes.data if a.size else None, _JSON_CODE[a.dtype], rows, cols, C.byref(out), C.byref(n)), "saf_array_json")
+    try:
+        return C.string_at(out, n.value).decode()
+    finally:
+        lib().saf_free(out)
+
+
+def dumps_scene_knowledge(obj) -> str:
+    """``json.dumps(obj, default=str)`` (what the reference writes to scene_knowledge.json, clip_seem_fusion.py:603-604) for an
+    object whose bulky lists are ``ArrayList``s: the small skeleton goes through the standard encoder, every array is rendered
+    natively and spliced in.  The text parses to the same object as the reference's."""
+    import json
+
+    arrays = []
+
+    def strip(o):
+        if isinstance(o, ArrayList):
+            arrays.append(o)
+            return f"\u0000saf-array-{len(arrays) - 1}\u0000"
+        if isinstance(o, dict):
+            return {k: strip(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [strip(v) for v in o]
+        return o
+
+    text = json.dumps(strip(obj), default=str)
+    if not arrays:
+        return text
+    parts = text.split('"\\u0000saf-array-')
+    out = [parts[0]]
+    for p in parts[1:]:
+        k, rest = p.split('\\u0000"', 1)
+        out.append(array_to_json(arrays[int(k)]))
+        out.append(rest)
+    return "".join(out)
 
 
 def save_ply(path, verts, faces, vertex_colors=None):

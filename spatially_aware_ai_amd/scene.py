@@ -22,7 +22,7 @@ import torch
 
 from .clip_seem_fusion import ClipSeemFusion, TextQueryEngine, discover_objects, extract_mesh_by_object
 from .clipfusion import backproject_pcd, scene_bounds
-from .io import save_ply, save_scene_arrays
+from .io import ArrayList, dumps_scene_knowledge, save_npy, save_ply, save_scene_arrays
 
 
 @dataclass
@@ -113,14 +113,20 @@ class _Clock:
 
 def reconstruct_scene(dataset, config, clip_model, seg_model, class_names, class_colors=None, device="cuda", out_dir=None,
                       max_depth=4, scale_patches_by_depth=False, feat_dtype=torch.float32, num_workers=0,
-                      object_meshes=True, marching_cubes=None):
+                      object_meshes=True, marching_cubes=None, python_lists=False):
     """``InSituManager.run_clipfusion`` (clip_seem_fusion.py:247-437).
 
     ``dataset`` yields the reference loaders' 5-tuple ``(rgb[H,W,3], depth[H,W], pose[4,4], K[3,3], idx)`` and has
     ``imwidth`` / ``imheight``; ``config`` needs ``voxel_size``, ``trunc_vox``, ``clip_patch_size``,
     ``clip_patch_stride`` (the reference's config dict, clip_seem_fusion.py:63-94).  ``class_names`` /
     ``class_colors`` are kMaX's ``COCO_PANOPTIC_CLASSES`` / ``COCO_PANOPTIC_COLORS`` in the reference
-    (handy_utils.py:23-26).  Returns a ``SceneResult``; ``result.seconds`` holds the wall clock of every stage."""
+    (handy_utils.py:23-26).  Returns a ``SceneResult``; ``result.seconds`` holds the wall clock of every stage.
+
+    ``python_lists``: keep the bulky members of ``scene_knowledge`` -- every object's ``voxels`` and ``mesh`` -- as the nested
+    Python lists the reference builds (handy_utils.py:430-452, clip_seem_fusion.py:393-417); by default they are
+    ``io.ArrayList``s around the arrays (same reads, same JSON: 0.8 s of a 2 s scan were spent building those lists and
+    encoding them).  With ``out_dir`` the volume's ``.npy`` files (3.4 GB at the reference's largest grid) are written by a
+    second thread from the moment the fusion is complete, beside the object / mesh stages."""
     clk = _Clock()
     clk.start()
     # ---- scene bounds (clip_seem_fusion.py:266-287)
@@ -150,11 +156,34 @@ def reconstruct_scene(dataset, config, clip_model, seg_model, class_names, class
     fusion.flush()
     clk.lap("fuse")
     clk.seconds["fuse_host_split"] = {k: round(v, 4) for k, v in host.items()}
+    # ---- the volume's artefacts (save_files_and_broadcast, :566-581) start now, on a thread of their own: nothing below writes
+    #      clip_feat or rgb (the lap above synchronised the device; ctypes releases the interpreter lock for the whole write)
+    writer = None
+    if out_dir is not None:
+        import threading
+
+        os.makedirs(out_dir, exist_ok=True)
+        nx_, ny_, nz_ = (int(v) for v in fusion.nvox)
+        vol_rgb, vol_feat = fusion.rgb.view(nx_, ny_, nz_, 3), fusion.clip_feat.view(nx_, ny_, nz_, -1)
+        wpaths, werr = {}, []
+
+        def _write_volume():
+            try:
+                t_w = time.perf_counter()
+                with torch.cuda.device(vol_feat.device), torch.cuda.stream(torch.cuda.Stream(vol_feat.device)):
+                    wpaths["voxel_rgb"] = save_npy(os.path.join(out_dir, "voxel_rgb.npy"), vol_rgb)
+                    wpaths["voxel_clip_feats"] = save_npy(os.path.join(out_dir, "voxel_clip_feats.npy"), vol_feat)
+                wpaths["_seconds"] = time.perf_counter() - t_w
+            except BaseException as e:  # noqa: BLE001 -- re-raised by the main thread at the join
+                werr.append(e)
+
+        writer = threading.Thread(target=_write_volume, name="saf-scene-writer")
+        writer.start()
     # ---- labels: argmax with the empty check (:315-333), on the device
     onehot_to_index = fusion.label_index().view(*[int(v) for v in fusion.nvox])
     clk.lap("label_argmax")
     # ---- objects (flood_fill_3d, :341-348) and the attributes the manager sets from outside (:351-372)
-    scene_knowledge, voxel_obj_idx = discover_objects(onehot_to_index, class_names, class_colors)
+    scene_knowledge, voxel_obj_idx = discover_objects(onehot_to_index, class_names, class_colors, arrays=not python_lists)
     scene_knowledge["scan_version"] = 0
     fusion.unique_objects = scene_knowledge["unique_objects"]
     fusion.voxel_obj_idx = voxel_obj_idx
@@ -175,14 +204,18 @@ def reconstruct_scene(dataset, config, clip_model, seg_model, class_names, class
         vc_h, vo_h = vertex_colors.cpu().numpy(), vertex_obj_idx.cpu().numpy()
         for obj_key, obj_value in scene_knowledge["unique_objects"].items():
             ov, of_, oc, _ = extract_mesh_by_object(verts, faces, vc_h, vo_h, obj_value["object_index"])
-            scene_knowledge["unique_objects"][obj_key]["mesh"] = (
-                None if len(of_) < 10 else {"vertices": ov.tolist(), "faces": of_.tolist(), "colors": oc.tolist()})
+            if python_lists:
+                mesh = {"vertices": ov.tolist(), "faces": of_.tolist(), "colors": oc.tolist()}
+            else:
+                mesh = {"vertices": ArrayList(ov), "faces": ArrayList(of_), "colors": ArrayList(oc)}
+            scene_knowledge["unique_objects"][obj_key]["mesh"] = None if len(of_) < 10 else mesh
         clk.lap("object_meshes")
     res = SceneResult(fusion, origin, nvox, xyz, onehot_to_index, scene_knowledge, voxel_obj_idx, verts, faces, vertex_colors,
                       vertex_clip_feats, vertex_obj_idx, segmentation_color)
     # ---- artefacts (save_files_and_broadcast, :563-607)
     if out_dir is not None:
-        res.paths = save_scene_arrays(out_dir, fusion, vert_clip_feat=vertex_clip_feats, vertex_obj_idx=vertex_obj_idx)
+        res.paths = {"vertex_clip_feats": save_npy(os.path.join(out_dir, "vertex_clip_feats.npy"), torch.as_tensor(vertex_clip_feats)),
+                     "vertex_obj_idx": save_npy(os.path.join(out_dir, "vertex_obj_idx.npy"), torch.as_tensor(vertex_obj_idx))}
         res.paths["mesh_rgb"] = save_ply(os.path.join(out_dir, "mesh_rgb.ply"), verts, faces, vertex_colors)
         res.paths["mesh_segmentation"] = save_ply(os.path.join(out_dir, "mesh_segmentation.ply"), verts, faces, segmentation_color)
         res.paths["scene_knowledge"] = os.path.join(out_dir, "scene_knowledge.json")
@@ -190,7 +223,14 @@ def reconstruct_scene(dataset, config, clip_model, seg_model, class_names, class
             # the same text as json.dump(scene_knowledge, f, default=str) (clip_seem_fusion.py:603-604) -- but json.dump
             # walks the object with the pure-Python encoder, a chunk at a time: 2.1 s for this scene's voxel lists and
             # meshes; dumps() hands the whole object to the C encoder: 0.5 s
-            f.write(json.dumps(scene_knowledge, default=str))
+            # and the bulky lists (voxels, per-object meshes) are arrays rendered natively: 0.05 s
+            f.write(dumps_scene_knowledge(scene_knowledge))
         clk.lap("save")
+        writer.join()
+        if werr:
+            raise werr[0]
+        clk.seconds["volume_write_beside"] = round(wpaths.pop("_seconds"), 4)
+        res.paths.update(wpaths)
+        clk.lap("save_volume_wait")
     res.seconds = clk.seconds
     return res

@@ -597,6 +597,7 @@ def test_backbone_deferred_to_the_flush_is_invisible(seem, n_frames):
     s1, s2 = now.stats(), later.stats()
     for k in ("window_rows", "window_tsdf_voxels"):  # how the calls fell into windows may differ: flushes are timing dependent
         assert s1.pop(k) > 0 and s2.pop(k) > 0
+    assert s1.pop("cull")["pairs"] > 0 and s2.pop("cull")["pairs"] > 0  # (only frames that took the windowed path are culled brick by brick)
     assert s1 == s2
     for name in ("weight", "tsdf_weight", "tsdf", "rgb") + (("labels_one_hot",) if seem else ()):
         assert torch.equal(getattr(now, name), getattr(later, name)), name
