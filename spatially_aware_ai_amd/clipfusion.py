@@ -222,18 +222,19 @@ class _FusionVolumeMixin:
     # clipfusion.py:1120-1133).  One frame per C call would run the per-frame pipeline; the windowed path
     # (saf_fuse_frames with 16+ frames: every touched feature row travels to HBM once per 128-frame window)
     # needs many frames in one call.  Small calls are therefore queued -- their inputs copied into a staging ring
-    # of four windows (512 slots) -- and handed to the library a WINDOW at a time (round 6): every completed window is pushed
-    # into a streaming session (saf_fuse_session_push) on a stream of the queue's own -- its classification runs beside the row
-    # kernel of the window before it, and the caller's stream goes on staging the next frames into the ring's other quarters
-    # meanwhile (rounds 2-5: one saf_fuse_frames call per flush on the caller's stream -- every flush exposed its first
-    # window's classification, 3.7 ms, and later frames' staging kernels queued behind the flush, 3 ms: 0.86-0.90 of the bulk
-    # rate).  Whatever reads or replaces the volume -- the registered buffers (attribute access, state_dict, .to()), stats(),
+    # of four windows (512 slots) -- and handed to the library 32 at a time (round 6): every 32 staged frames are pushed into a
+    # streaming session (saf_fuse_session_push) on a stream of the queue's own -- one classification launch, which runs beside
+    # the row kernel of the window before; the 128th frame of a window brings its row kernel -- and the caller's stream goes on
+    # staging the next frames into the ring's other quarters meanwhile (rounds 2-5: one saf_fuse_frames call per flush on the
+    # caller's stream -- every flush exposed its first window's classification, 3.7 ms, could not start before the window's
+    # last frame was staged, 3 ms, and later frames' staging kernels queued behind the flush, 3 ms: 0.86-0.90 of the bulk rate).  Whatever reads or replaces the volume -- the registered buffers (attribute access, state_dict, .to()), stats(),
     # extract_mesh, the merge -- pushes what is staged, finishes the session and lets its stream wait for it.
     # The device paths are bit-identical, so a caller cannot tell -- except by speed.
     _DEFER_MAX_BATCH = 15  # calls of 16+ frames take the windowed path by themselves
     # up to four windows per flush (from the second one on, a window is classified beside its predecessor's rows); a full
     # window is flushed earlier when the device has finished the previous flush and would otherwise idle
     _QUEUE_FRAMES = 4 * _abi.SAF_WINDOW_FRAMES
+    _PUSH_FRAMES = 32  # frames of one classification launch (one mask plane of a window): the unit the session takes
 
     def _defer_ok(self, bsz, npy, npx):
         if not self.__dict__.get("defer_frames", True) or bsz > self._DEFER_MAX_BATCH:
@@ -293,7 +294,7 @@ class _FusionVolumeMixin:
                   "feat": mk(*key[2]), "labels": mk(h, w) if label_maps is not None else None, "lazy": lazy,
                   # the frames staged and not yet handed over lie in slots [ring0, ring0 + _pending_n); free_ev[q]: the event
                   # behind the row kernel that reads quarter q's frames (None: free); held: quarters whose row kernel is owed
-                  "ring0": 0, "free_ev": [None] * (self._QUEUE_FRAMES // _abi.SAF_WINDOW_FRAMES), "held": [],
+                  "ring0": 0, "free_ev": [None] * (self._QUEUE_FRAMES // _abi.SAF_WINDOW_FRAMES), "sess_frames": 0,
                   "src": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0),
                   "dst": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0)}
             # base addresses and byte strides of the ring's slots (no tensor views per call)
@@ -349,7 +350,7 @@ class _FusionVolumeMixin:
                     if label_maps is not None:
                         st["labels"][slot].copy_(label_maps[i], non_blocking=True)
                 self.__dict__["_pending_n"] = k + 1
-                if (slot + 1) % win == 0:  # a window is complete: hand it over (its classification starts; its rows follow the next push)
+                if (slot + 1) % self._PUSH_FRAMES == 0:  # one classification launch's worth of frames: hand them over
                     self._flush_pending()
             if fast:  # the sources are read asynchronously on this stream
                 for t in (depth_imgs, rgb_imgs, poses, K) + (() if lazy is not None else (clip_feat_img,)) + tuple(label_maps or ()):
@@ -399,10 +400,9 @@ class _FusionVolumeMixin:
             ev = fs.record_event()
             self.__dict__["_fs_event"] = ev
             st = self.__dict__.get("_stage")
-            if st is not None:
-                for q in st["held"]:
-                    st["free_ev"][q] = ev
-                st["held"] = []
+            if st is not None:  # the open window's frames (and, conservatively, everybody's) are free behind `ev`
+                st["free_ev"] = [ev] * len(st["free_ev"])
+                st["sess_frames"] = 0
             if rc != 0:  # its windows are classified and partly fused: nothing to retry
                 self.__dict__["_poisoned"] = "the queue's session could not launch its last row kernel; the volume is incomplete: reset() it"
             check(rc, "saf_fuse_session_finish")
@@ -452,7 +452,7 @@ class _FusionVolumeMixin:
             self._finish_session()
             st["ring0"] = 0  # (every quarter now carries the event of the finish, or of the call on the current stream)
         else:
-            st["ring0"] = (lo + n) % self._QUEUE_FRAMES  # whole windows: the next frames go to the ring's next quarter
+            st["ring0"] = (lo + n) % self._QUEUE_FRAMES  # the next frames follow in the ring (a session's windows are its quarters)
 
     def _check_poisoned(self):
         msg = self.__dict__.get("_poisoned")
@@ -548,17 +548,27 @@ class _FusionVolumeMixin:
         win = _abi.SAF_WINDOW_FRAMES
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)
-            if staged is not None and windowed and os.environ.get("SAF_WIN_OVERLAP", "1")[:1] != "0":
+            # (a flush of a few frames with no window open takes the per-frame pipeline, as a direct call of that size does)
+            if staged is not None and (self.__dict__.get("_session_open") or len(arr) >= 16) and \
+                    L.saf_fuse_session_ok(C.byref(vol), arr, len(arr), ws.numel()) == 1:
                 lo, n, _final = staged
                 b = self._buffers
                 fs = self._queue_stream(dev, [ws, st["depth"], st["rgb"], st["pose"], st["K"], st["feat"], st["labels"]] +
                                         [b.get(k) for k in ("tsdf", "tsdf_weight", "weight", "rgb", "clip_feat", "labels_one_hot",
                                                             "axis_x", "axis_y", "axis_z", "fuse_stats")])
-                fs.wait_event(stream.record_event())  # the staging kernels (and a deferred backbone's maps) of these frames
+                # the staging kernels (and a deferred backbone's maps) of these frames: what their classification waits for -- NOT
+                # the queue's stream, where the previous window's row kernel sits (the launches are to run beside it).  The
+                # session's first push also orders the queue's stream behind the caller's (reset()'s zeroing, an earlier finish)
+                ready = stream.record_event()
+                if not self.__dict__.get("_session_open"):
+                    fs.wait_event(ready)
                 if self.__dict__.get("_session") is None:
                     self.__dict__["_session"] = L.saf_fuse_session_create()
+                # (the depth tiles of these frames: on the caller's stream, behind their staging -- out of the classification chain)
                 rc = L.saf_fuse_session_push(self.__dict__["_session"], C.byref(vol), arr, len(arr), ws.data_ptr(), ws.numel(),
-                                             b["fuse_stats"].data_ptr(), fs.cuda_stream)
+                                             b["fuse_stats"].data_ptr(), fs.cuda_stream, ready.cuda_event, stream.cuda_stream)
+                st.setdefault("ready_evs", []).append(ready)  # (kept alive while the device may still wait for them)
+                del st["ready_evs"][:-8]
                 # SAF_E_INVALID / _WORKSPACE / _UNSUPPORTED come from the checks at the entry (every frame descriptor is validated
                 # before the first launch); a HIP error may have left some windows fused (see _flush_pending)
                 self.__dict__["_fuse_launched"] = rc == 0 or rc == _abi.SAF_E_HIP
@@ -566,10 +576,12 @@ class _FusionVolumeMixin:
                     self.__dict__["_session_open"] = True
                     ev = fs.record_event()
                     self.__dict__["_fs_event"] = ev
-                    quarters = list(range(lo // win, (lo + n - 1) // win + 1))
-                    for q in st["held"] + quarters[:-1]:  # their row kernels are queued: behind `ev` their frames are free
-                        st["free_ev"][q] = ev
-                    st["held"] = quarters[-1:]
+                    # the session's windows are the ring's quarters (a session starts at slot 0): the windows this push completed
+                    # have their row kernels queued -- behind `ev` their frames are free
+                    w0, w1 = st["sess_frames"] // win, (st["sess_frames"] + n) // win
+                    for w in range(w0, w1):
+                        st["free_ev"][w % len(st["free_ev"])] = ev
+                    st["sess_frames"] += n
                 check(rc, "saf_fuse_session_push")
                 return
             # one call on the current stream: whatever the session still owes comes first
@@ -622,7 +634,7 @@ class _FusionVolumeMixin:
             torch.cuda.current_stream(b["tsdf"].device).wait_event(ev)
             st = self.__dict__.get("_stage")
             if st is not None:
-                st["held"], st["ring0"] = [], 0
+                st["sess_frames"], st["ring0"] = 0, 0
                 st["free_ev"] = [ev] * len(st["free_ev"])
         lazy = bool(lazy) and b["clip_feat"].is_cuda
         for name in ("rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot") + (() if lazy else ("clip_feat",)):

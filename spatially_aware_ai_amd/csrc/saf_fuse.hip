@@ -1120,70 +1120,71 @@ int saf_poll_async_error(void) { return poll_latch(); }
 // ---- streaming sessions (round 6): consecutive windowed calls as ONE unit pipeline ----
 struct saf_fuse_session {
   PipeRes* pr = nullptr;
-  WinCarry carry;
-  const void* feat = nullptr;  // identity of the volume and workspace the pending unit belongs to
+  WinStream st;
+  const void* feat = nullptr;  // identity of the volume and workspace the open window belongs to
   void* workspace = nullptr;
   size_t workspace_bytes = 0;
   uint64_t* stats = nullptr;
 };
 
-saf_fuse_session* saf_fuse_session_create(void) {
-  saf_fuse_session* ss = new saf_fuse_session;
-  for (int k = 0; k < 8; ++k) ss->carry.tile_window[k] = -1;
-  return ss;
+saf_fuse_session* saf_fuse_session_create(void) { return new saf_fuse_session; }
+
+static bool session_overlap(saf_fuse_session* ss, WinOverlap* ov) {
+  if (!ss->pr && !(ss->pr = pipe_acquire())) return false;
+  PipeRes* pr = ss->pr;
+  ov->aux = pr->aux; ov->fork = pr->fork; ov->join = pr->join;
+  ov->cls_done[0] = pr->fused[0]; ov->cls_done[1] = pr->fused[1]; ov->fuse_done[0] = pr->fused[2]; ov->fuse_done[1] = pr->fused[3];
+  ov->tiles = pr->tiles;
+  return true;
 }
 
-static int session_run(saf_fuse_session* ss, const KVol& kv, const saf_frame* frames, int32_t n_frames, bool hold, hipStream_t s) {
-  if (!ss->pr && !(ss->pr = pipe_acquire())) return fail(SAF_E_HIP, "could not create the classification stream / events of a session");
-  PipeRes* pr = ss->pr;
-  WinOverlap ov;
-  ov.aux = pr->aux; ov.fork = pr->fork; ov.join = pr->join;
-  ov.cls_done[0] = pr->fused[0]; ov.cls_done[1] = pr->fused[1]; ov.fuse_done[0] = pr->fused[2]; ov.fuse_done[1] = pr->fused[3];
-  ov.tiles = pr->tiles;
-  ss->carry.hold = hold;
-  return fuse_many_windowed(kv, frames, n_frames, ss->workspace, ss->workspace_bytes, ss->stats, nullptr, s, &ov, nullptr, false, &ss->carry);
+int saf_fuse_session_ok(const saf_volume* vol, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
+  KVol kv;
+  if (make_kvol(vol, &kv) || n_frames <= 0 || !frames) return -1;
+  if (getenv("SAF_WIN_OVERLAP") && getenv("SAF_WIN_OVERLAP")[0] == '0') return 0;
+  return stream_ok(kv, frames, n_frames, workspace_bytes) ? 1 : 0;
 }
 
 int saf_fuse_session_push(saf_fuse_session* ss, const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,
-                          size_t workspace_bytes, uint64_t* stats, void* stream) {
+                          size_t workspace_bytes, uint64_t* stats, void* stream, void* ready_event, void* tile_stream) {
   if (!ss) return fail(SAF_E_INVALID, "session is NULL");
   KVol kv;
   int rc = make_kvol(vol, &kv);
   if (rc) return rc;
   if (n_frames <= 0 || !frames) return fail(SAF_E_INVALID, "bad frame array");
   if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
-  if (!window_ok(kv, frames, n_frames, workspace_bytes) || (getenv("SAF_WIN_OVERLAP") && getenv("SAF_WIN_OVERLAP")[0] == '0'))
-    return fail(SAF_E_UNSUPPORTED, "a streaming session takes what the windowed two-stream path takes (saf_fuse_path == 1, SAF_WIN_OVERLAP != 0)");
-  if (ss->carry.pending && (ss->feat != kv.feat || ss->workspace != workspace || ss->workspace_bytes != workspace_bytes || ss->stats != stats))
-    return fail(SAF_E_INVALID, "a session with a pending window continues on the same volume, workspace and counters: finish it first");
+  if (!stream_ok(kv, frames, n_frames, workspace_bytes) || (getenv("SAF_WIN_OVERLAP") && getenv("SAF_WIN_OVERLAP")[0] == '0'))
+    return fail(SAF_E_UNSUPPORTED, "a streaming session takes what the windowed row forms take on two streams (saf_fuse_session_ok)");
+  if (ss->st.have_shape && (ss->feat != kv.feat || ss->workspace != workspace || ss->workspace_bytes != workspace_bytes || ss->stats != stats))
+    return fail(SAF_E_INVALID, "a session continues on the same volume, workspace and counters: finish it first");
   if ((rc = poll_latch())) return rc;
   ensure_latch();
+  WinOverlap ov;
+  if (!session_overlap(ss, &ov)) return fail(SAF_E_HIP, "could not create the classification stream / events of a session");
   ss->feat = kv.feat; ss->workspace = workspace; ss->workspace_bytes = workspace_bytes; ss->stats = stats;
-  return session_run(ss, kv, frames, n_frames, true, static_cast<hipStream_t>(stream));
+  return stream_push(kv, frames, n_frames, workspace, workspace_bytes, stats, static_cast<hipStream_t>(stream),
+                     static_cast<hipEvent_t>(ready_event), static_cast<hipStream_t>(tile_stream), &ov, &ss->st);
 }
 
 int saf_fuse_session_finish(saf_fuse_session* ss, void* stream) {
   if (!ss) return fail(SAF_E_INVALID, "session is NULL");
   int rc = SAF_OK;
-  if (ss->carry.pending) rc = session_run(ss, ss->carry.kv, nullptr, 0, false, static_cast<hipStream_t>(stream));
-  // the next push starts a new pipeline (its first classification alone): counts and tile slots start over
-  ss->carry.pending = false;
-  ss->carry.n_units = 0;
-  ss->carry.n_windows = 0;
-  for (int k = 0; k < 8; ++k) ss->carry.tile_window[k] = -1;
+  WinOverlap ov;
+  if (ss->st.open && ss->st.filled > 0) {
+    if (!session_overlap(ss, &ov)) return fail(SAF_E_HIP, "could not create the classification stream / events of a session");
+    rc = stream_close(ss->workspace, ss->workspace_bytes, ss->stats, static_cast<hipStream_t>(stream), &ov, &ss->st);
+  }
+  ss->st = WinStream();  // the next push starts a new pipeline (its first window's classification alone on the chip)
   return rc;
 }
 
 int saf_fuse_session_abandon(saf_fuse_session* ss) {
   if (!ss) return fail(SAF_E_INVALID, "session is NULL");
-  ss->carry.pending = false;  // (its classification ran -- TSDF and masks of a volume that is being discarded; no row kernel follows)
-  ss->carry.n_units = 0;
-  ss->carry.n_windows = 0;
-  for (int k = 0; k < 8; ++k) ss->carry.tile_window[k] = -1;
+  ss->st = WinStream();  // (the open window's classification ran -- TSDF and masks of a volume that is being discarded; no row kernel follows)
   return SAF_OK;
 }
 
-int saf_fuse_session_pending(const saf_fuse_session* ss) { return ss && ss->carry.pending ? ss->carry.F : 0; }
+int saf_fuse_session_pending(const saf_fuse_session* ss) { return ss && ss->st.open ? ss->st.filled : 0; }
 
 void saf_fuse_session_destroy(saf_fuse_session* ss) {
   if (!ss) return;

@@ -303,27 +303,24 @@ struct WinSlabs {
   const int32_t *x0, *nx;
   void* const* done;
 };
-// A streaming SESSION (saf_fuse_session_*, round 6): consecutive calls continue one unit pipeline -- a call leaves its LAST unit
-// classified but without its row kernel (`hold`), so that the next call's first classification runs beside that row kernel
-// instead of alone (every separate saf_fuse_frames call exposes its first window's classification, 3.7 ms at 256^3; the
-// one-frame-per-integrate() queue flushes a window at a time).  What survives between the calls: unit parity (headers and mask
-// planes are double-buffered by it), the tile slots, and what the pending unit's row kernel needs (it reads the frames through
-// the header's frame table on the device: no host descriptors).
-struct WinCarry {
-  int n_units = 0;      // units classified so far (parity, "first unit of the session")
-  int n_windows = 0;    // windows so far (tile slots)
-  bool pending = false; // the last classified unit has no row kernel yet
-  bool hold = false;    // this call leaves its last unit pending
-  KVol kv;              // the pending unit's (sub-)volume
-  int F = 0, window = -1;
-  KFrame kf0;           // image / map shape of the session's frames
-  int tile_window[8];
+// A streaming session (saf_fuse_session_*; saf_window.hip): the open window's state between two pushes.
+struct WinStream {
+  bool open = false;        // a window is open: `filled` of its frames are classified, its row kernel is not launched
+  int filled = 0;
+  int n_windows = 0;        // windows closed so far (parity of headers / mask planes, tile slots, "first window")
+  bool have_shape = false;  // kv / kf0 are those of the session's frames
+  KVol kv;
+  KFrame kf0;
 };
+bool stream_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes);
+int stream_push(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes, uint64_t* stats,
+                hipStream_t s, hipEvent_t ready, hipStream_t tile_stream, const WinOverlap* ov, WinStream* st);
+int stream_close(void* workspace, size_t workspace_bytes, uint64_t* stats, hipStream_t s, const WinOverlap* ov, WinStream* st);
 // recycled: the volume's feature rows were not cleared when its scalars were (saf_fuse_frames_recycled) -- the rows of voxels
 // whose weight is still 0 when the call is over are zeroed by it, beside the last window's row kernel where the schedule allows.
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
                        uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs = nullptr,
-                       bool recycled = false, WinCarry* carry = nullptr);
+                       bool recycled = false);
 // saf_misc.hip (clear_rows): zero the feature rows of the voxels n in [0, kv.N) with weight[n] == 0 and -- masks may be NULL -- no
 // bit set in masks[p * mask_plane + n] for p < n_planes (the hit masks of a window whose row kernel may be running: it writes exactly
 // the rows with a bit set, this kernel only the others).

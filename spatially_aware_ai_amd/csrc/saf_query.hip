@@ -231,7 +231,8 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
                                                                 int64_t fstride, int D, const float* __restrict__ text,
                                                                 int L, int64_t tstride, float scale, int normalize,
                                                                 const float* __restrict__ wts, float* __restrict__ out,
-                                                                float* __restrict__ out_last) {
+                                                                float* __restrict__ out_last, int64_t out_stride, int out_col0) {
+  // (out_stride / out_col0: where this launch's L columns lie in the output row -- L and 0, or one 64-label block of a wider row)
   extern __shared__ __attribute__((aligned(16))) float s_text[];  // [TILES*32][D + 4], rows >= L are zero
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tstr = D + 4;
@@ -357,13 +358,13 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
         for (int t = 0; t < TILES; ++t) val[t] -= mean;
       } else {
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) val[t] *= scale;
+        for (int t = 0; t < TILES; ++t) val[t] = wts && ok[t] ? val[t] * scale * wts[m + 32 * t] : val[t] * scale;  // (wts: a block of a wide surgery scan)
       }
       if (r < n_rows) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           if (ok[t]) {
-            if (out) out[r * L + m + 32 * t] = val[t];
+            if (out) out[r * out_stride + out_col0 + m + 32 * t] = val[t];
             if (out_last && m + 32 * t == L - 1) out_last[r] = val[t];
           }
         }
@@ -374,7 +375,8 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
 
 template <int EPI, int FT, int TILES, int TH>
 int launch_mfma_th(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
-                   float scale, int normalize, const float* wts, float* out, float* out_last, int per_cu, size_t shmem, hipStream_t s) {
+                   float scale, int normalize, const float* wts, float* out, float* out_last, int per_cu, size_t shmem, hipStream_t s,
+                   int64_t out_stride, int out_col0) {
   auto fn = query_mfma_kernel<EPI, FT, TILES, TH>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -387,26 +389,26 @@ int launch_mfma_th(const void* feats, int64_t n_rows, int64_t fstride, int D, co
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(TH), shmem, s, feats, n_rows, fstride, D, text, L,
-                     tstride, scale, normalize, wts, out, out_last);
+                     tstride, scale, normalize, wts, out, out_last, out_stride > 0 ? out_stride : (int64_t)L, out_col0);
   return check_launch("query_mfma_kernel");
 }
 
 template <int EPI, int FT, int TILES>
 int launch_mfma_t(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
-                  float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s) {
+                  float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s, int64_t out_stride, int out_col0) {
   const size_t shmem = (size_t)TILES * 32 * (D + 4) * sizeof(float);
   const int per_cu = (int)((160 * 1024) / (shmem + 256)) > 2 ? 2 : (int)((160 * 1024) / (shmem + 256));
   // SAF_Q_THREADS (read per call; development): 256 or 512 threads per workgroup whatever the tiles leave room for
   const char* th_env = getenv("SAF_Q_THREADS");
   const bool wide = th_env ? atoi(th_env) == 512 : per_cu <= 1;
-  return wide ? launch_mfma_th<EPI, FT, TILES, 512>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s)
-              : launch_mfma_th<EPI, FT, TILES, 256>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s);
+  return wide ? launch_mfma_th<EPI, FT, TILES, 512>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s, out_stride, out_col0)
+              : launch_mfma_th<EPI, FT, TILES, 256>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s, out_stride, out_col0);
 }
 
 // true if the MFMA scan can take this shape
 inline bool mfma_ok(int ft, int64_t fstride, int D, int L, const void* feats) {
   const int esz = ft == SAF_F32 ? 4 : 2;
-  if (D % 8 != 0 || L > 64) return false;
+  if (D % 8 != 0 || L > 64) return false;  // (L > 64 with an [N, L] output: launch_mfma_blocks, 64 labels at a time)
   if (((uintptr_t)feats & 15) || (fstride * esz) % (4 * esz) != 0 || (fstride % 4) != 0) return false;
   const size_t shmem = (size_t)(L > 32 ? 2 : 1) * 32 * (D + 4) * sizeof(float);
   return shmem <= 150 * 1024;
@@ -414,25 +416,81 @@ inline bool mfma_ok(int ft, int64_t fstride, int D, int L, const void* feats) {
 
 template <int EPI, int FT>
 int launch_mfma_f(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
-                  float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s) {
+                  float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s, int64_t out_stride, int out_col0) {
   return L > 32 ? launch_mfma_t<EPI, FT, 2>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out,
-                                            out_last, s)
+                                            out_last, s, out_stride, out_col0)
                 : launch_mfma_t<EPI, FT, 1>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out,
-                                            out_last, s);
+                                            out_last, s, out_stride, out_col0);
 }
 
 template <int EPI>
 int launch_mfma(int ft, const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L,
                 int64_t tstride, float scale, int normalize, const float* wts, float* out, float* out_last,
-                hipStream_t s) {
+                hipStream_t s, int64_t out_stride = 0, int out_col0 = 0) {
   switch (ft) {
     case SAF_BF16:
-      return launch_mfma_f<EPI, SAF_BF16>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+      return launch_mfma_f<EPI, SAF_BF16>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s, out_stride, out_col0);
     case SAF_F16:
-      return launch_mfma_f<EPI, SAF_F16>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+      return launch_mfma_f<EPI, SAF_F16>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s, out_stride, out_col0);
     default:
-      return launch_mfma_f<EPI, SAF_F32>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s);
+      return launch_mfma_f<EPI, SAF_F32>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, s, out_stride, out_col0);
   }
+}
+
+// More than 64 labels (round 6; the reference's control set grows by one label per new query text, clip_seem_fusion.py:496-505):
+// the MFMA scan once per block of 64 labels, each writing its block of the row's scaled (surgery: weighted) scores, then one pass
+// over the [N, L] scores for what needs the whole row -- softmax's maximum and denominator, surgery's mean.  (Rounds 1-5 fell
+// back to the one-wave-per-row kernel.)
+template <int EPI>
+__global__ __launch_bounds__(256) void finish_rows_kernel(float* __restrict__ out, int64_t n_rows, int L, float* __restrict__ out_last) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  for (int64_t r = wave; r < n_rows; r += n_waves) {
+    float* row = out + r * L;
+    if (EPI == SAF_Q_SOFTMAX) {
+      float mx = -INFINITY;
+      for (int c = lane; c < L; c += 64) mx = fmaxf(mx, row[c]);
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sum = 0.0f;
+      for (int c = lane; c < L; c += 64) sum += expf(row[c] - mx);
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      for (int c = lane; c < L; c += 64) {
+        const float v = expf(row[c] - mx) / sum;
+        row[c] = v;
+        if (out_last && c == L - 1) out_last[r] = v;
+      }
+    } else {  // surgery: minus the row's mean over the labels
+      float sum = 0.0f;
+      for (int c = lane; c < L; c += 64) sum += row[c];
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float mean = sum / (float)L;
+      for (int c = lane; c < L; c += 64) {
+        const float v = row[c] - mean;
+        row[c] = v;
+        if (out_last && c == L - 1) out_last[r] = v;
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_mfma_blocks(int ft, const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
+                       float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s) {
+  for (int c0 = 0; c0 < L; c0 += 64) {
+    const int lb = L - c0 < 64 ? L - c0 : 64;
+    int rc = launch_mfma<SAF_Q_SCORES>(ft, feats, n_rows, fstride, D, text + (int64_t)c0 * tstride, lb, tstride, scale, normalize,
+                                       wts ? wts + c0 : nullptr, out, nullptr, s, (int64_t)L, c0);
+    if (rc) return rc;
+  }
+  if (EPI == SAF_Q_SCORES) {
+    if (out_last) return fail(SAF_E_UNSUPPORTED, "query scan: out_last of a raw-score scan over more than 64 labels");
+    return SAF_OK;
+  }
+  int64_t blocks = (n_rows + 3) / 4;
+  const int64_t cap = (int64_t)device_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(finish_rows_kernel<EPI>, dim3((unsigned)blocks), dim3(256), 0, s, out, n_rows, L, out_last);
+  return check_launch("finish_rows_kernel");
 }
 
 template <int EPI>
@@ -473,14 +531,23 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
   const void* f = feats;
   const int ft = feat_dtype;
   const bool mfma = mfma_ok(ft, feat_stride, feat_dim, n_text, feats);
+  // more than 64 labels: block by block on the MFMA scan where it takes a 64-label block of this shape and the caller wants the
+  // whole [N, L] matrix (the blocks' scores need somewhere to meet)
+  const bool blocks = !mfma && n_text > 64 && out != nullptr && mfma_ok(ft, feat_stride, feat_dim, 64, feats);
   switch (epilogue) {
     case SAF_Q_SCORES:
+      if (blocks)
+        return launch_mfma_blocks<SAF_Q_SCORES>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
+                                                nullptr, out, out_last, s);
       if (mfma)
         return launch_mfma<SAF_Q_SCORES>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale,
                                          normalize, nullptr, out, out_last, s);
       return launch<SAF_Q_SCORES>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
                                   nullptr, out, out_last, s);
     case SAF_Q_SOFTMAX:
+      if (blocks)
+        return launch_mfma_blocks<SAF_Q_SOFTMAX>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
+                                                 nullptr, out, out_last, s);
       if (mfma)
         return launch_mfma<SAF_Q_SOFTMAX>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale,
                                           normalize, nullptr, out, out_last, s);
@@ -494,6 +561,9 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
       int rc = launch<EPI_WEIGHTS>(ft, f, 1, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize, wts,
                                    nullptr, nullptr, s);
       if (rc) return rc;
+      if (blocks)
+        return launch_mfma_blocks<SAF_Q_SURGERY>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize,
+                                                 wts, out, out_last, s);
       if (mfma)
         return launch_mfma<SAF_Q_SURGERY>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, 1.0f,
                                           normalize, wts, out, out_last, s);

@@ -137,6 +137,9 @@ __device__ unsigned long long g_win_t[16];
 #ifndef SAF_CLS_BOX
 #define SAF_CLS_BOX 1  // the brick's frame cull tests the box's extents (0: its bounding sphere, rounds 2-3)
 #endif
+#ifndef SAF_CLS_SKIPDEAD
+#define SAF_CLS_SKIPDEAD 1  // depth gathers of voxel slots without a single pixel in the wave are not issued (0: always four per frame)
+#endif
 #ifndef SAF_CLS_FU
 #define SAF_CLS_FU 1   // frames classified together: with the frame cull, occupancy hides the depth gathers better than batching does (1: 1.13 ms, 2: 1.17, 4: 1.29, 8: 2.08 per launch)
 #endif
@@ -342,8 +345,16 @@ __device__ __forceinline__ void classify_voxels(const KVol& v, const ClsArgs& wa
       const __amdgpu_buffer_rsrc_t dimg = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(wa.depth[fr[u] >= 0 ? fr[u] : 0]), 0, wa.depth_bytes, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+#if SAF_CLS_SKIPDEAD
+        // a voxel slot no lane of the wave has a pixel for (a brick at the edge of the view, z <= 0) issues no gather: an
+        // instruction whose 64 offsets all lie beyond the image makes no memory request but still takes its turn in the
+        // texture-address unit, the path the classification shares with the row kernel beside it
+        depth[u][j] = 0.0f;
+        if (__builtin_amdgcn_ballot_w64(pix[u][j] >= 0) != 0ull)
+#endif
         depth[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dimg, pix[u][j] * 4, 0, 0));
+      }
 #if SAF_CLS_ABL & 1
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1663,24 +1674,14 @@ struct WinUnit {
 };
 
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,
-                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs, bool recycled,
-                       WinCarry* carry) {
+                       uint64_t* stats, saf_profiler* prof, hipStream_t s, const WinOverlap* ov, const WinSlabs* slabs, bool recycled) {
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   int rc = SAF_OK;
   KFrame kf0;
-  if (carry && (!ov || (slabs && slabs->n > 0) || recycled)) return fail(SAF_E_INVALID, "a streaming session needs the two-stream schedule, whole volumes and no deferred clear");
-  if (n_frames > 0) {
-    if ((rc = make_kframe(&frames[0], &kf0))) return rc;
-    for (int32_t i = 1; i < n_frames; ++i) {
-      KFrame t;
-      if ((rc = make_kframe(&frames[i], &t))) return rc;
-    }
-    if (carry && carry->pending && (kf0.H != carry->kf0.H || kf0.W != carry->kf0.W || kf0.npy != carry->kf0.npy || kf0.npx != carry->kf0.npx ||
-                                    kf0.rgb_bilinear != carry->kf0.rgb_bilinear || (kf0.label_map == nullptr) != (carry->kf0.label_map == nullptr)))
-      return fail(SAF_E_INVALID, "the frames of a streaming session must share their shapes: finish the session first");
-  } else {  // (a session's finish: only the pending unit's row kernel)
-    if (!carry || !carry->pending) return SAF_OK;
-    kf0 = carry->kf0;
+  if ((rc = make_kframe(&frames[0], &kf0))) return rc;
+  for (int32_t i = 1; i < n_frames; ++i) {
+    KFrame t;
+    if ((rc = make_kframe(&frames[i], &t))) return rc;
   }
   const int P = kf0.npy * kf0.npx;
   // Two layouts of the workspace: with room for the window's depth images re-laid-out in tiles (a workspace sized by
@@ -1733,21 +1734,14 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   int ts_log2 = 4;
   while (((kf0.W + (1 << ts_log2) - 1) >> ts_log2) * ((kf0.H + (1 << ts_log2) - 1) >> ts_log2) > kMaxDepthTiles) ++ts_log2;
   const int tiles_x = (kf0.W + (1 << ts_log2) - 1) >> ts_log2, n_tiles = tiles_x * ((kf0.H + (1 << ts_log2) - 1) >> ts_log2);
-  static_assert(kTileWindows <= 8, "WinCarry::tile_window");
-  int tile_window_local[kTileWindows];  // which window's tile maxima a slot of the tile region holds (-1: none)
-  for (int k = 0; k < kTileWindows; ++k) tile_window_local[k] = -1;
-  int* tile_window = carry ? carry->tile_window : tile_window_local;
-  // a session: this call's units continue the session's count (parity of headers and mask planes, tile slots); a pending unit
-  // of the previous call comes first -- it is classified already, only its row kernel is still owed
-  const int first_new = carry && carry->pending ? 1 : 0;
-  const int ubase = carry ? carry->n_units - first_new : 0, wbase = carry ? carry->n_windows : 0;
+  int tile_window[kTileWindows];  // which window's tile maxima a slot of the tile region holds (-1: none)
+  for (int k = 0; k < kTileWindows; ++k) tile_window[k] = -1;
   const int wlen = window_frames();
   const int n_win = (n_frames + wlen - 1) / wlen;
   auto win_frames = [&](int w) { return n_frames - w * wlen < wlen ? n_frames - w * wlen : wlen; };
 
   // ---- the units of this call
   std::vector<WinUnit> units;
-  if (first_new) units.push_back(WinUnit{carry->kv, 0, carry->F, 0, -1, carry->window});
   if (slabs && slabs->n > 0) {
     for (int k = 0; k < slabs->n; ++k) {
       if (slabs->x0[k] < 0 || slabs->nx[k] <= 0 || slabs->x0[k] + slabs->nx[k] > kv.nx) return fail(SAF_E_INVALID, "slab %d outside the volume", k);
@@ -1770,7 +1764,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     for (int w = 0; w < n_win; ++w) {
       const int n = w == 0 ? n0 : ns;
       for (int k = 0; k < n; ++k)
-        units.push_back(WinUnit{n == 1 ? kv : slab_kvol(kv, k * (kv.nx / n), kv.nx / n), w * wlen, win_frames(w), k == 0, -1, wbase + w});
+        units.push_back(WinUnit{n == 1 ? kv : slab_kvol(kv, k * (kv.nx / n), kv.nx / n), w * wlen, win_frames(w), k == 0, -1, w});
     }
   }
   const int n_units = (int)units.size();
@@ -1832,7 +1826,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   // The later windows' tiles AHEAD of time, on the caller's stream: it is idle until the first window has been classified, and
   // every such pair of small launches inside the classification chain (16 per 512-frame job, ~70 us each beside a row kernel)
   // lengthens the chain that a job's time follows.  Window 0's stay in front of its classification.
-  const bool pre_tiles = ov && ov->tiles && !carry && !(slabs && slabs->n > 0) && n_units == n_win && n_win >= 2 &&
+  const bool pre_tiles = ov && ov->tiles && !(slabs && slabs->n > 0) && n_units == n_win && n_win >= 2 &&
                          !(getenv("SAF_WIN_PRETILES") && getenv("SAF_WIN_PRETILES")[0] == '0');
   if (pre_tiles) {
     for (int w = 1; w < n_win && w < kTileWindows; ++w) {
@@ -1844,11 +1838,11 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   auto classify = [&](int ui) -> int {
     const WinUnit& u = units[ui];
     const Geom g = geom(u.kv);
-    const int F = u.F, f0 = u.f0, gi = ubase + ui, par = gi & 1;  // gi: the unit's index in the session (= ui without one)
+    const int F = u.F, f0 = u.f0, par = ui & 1;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
     // the window's depth tile maxima: computed when a unit of the window first needs them
-    const int widx = wbase + f0 / wlen, tslot = widx % kTileWindows;
+    const int widx = f0 / wlen, tslot = widx % kTileWindows;
     float* dmax_w = reinterpret_cast<float*>(ws + wl.tile_off + (size_t)tslot * wl.tile_win);  // [kWin] largest, [kWin] smallest
     float* tmax_w = dmax_w + 1024;
     float* tdepth_w = tmax_w + (size_t)kWin * kMaxDepthTiles;  // (tiled layout only) the window's depth images in tiles
@@ -1857,7 +1851,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
     WinTable* tab = reinterpret_cast<WinTable*>(hdr + kTableOff);
     mark("classify: begin", ui);
-    if (ov && gi >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
+    if (ov && ui >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
     if (pre_tiles && ui == 1 && hipStreamWaitEvent(cs, ov->tiles, 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent(tiles)");
     // header: unit counters, dmax, the classification launches' counter shards, the frame table
     if (hipMemsetAsync(hdr, 0, kHdrBytes, cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
@@ -1874,7 +1868,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       // (unit 0 has the chip to itself -- everything the caller queued before is done, nothing of this call runs yet --, where the
       //  classification is bound by its vector instructions and the tile offset costs 5 % (0.92 vs 0.97 ms per launch): it reads the
       //  frames' own images; the tiled copies pay where the address path is shared, i.e. for every later unit)
-      const bool use_tiled = tiled && (gi > 0 || (til_env && til_env[0] == '2'));
+      const bool use_tiled = tiled && (ui > 0 || (til_env && til_env[0] == '2'));
       ca.depth_bytes = use_tiled ? (int)(dpx * sizeof(float)) : kf0.H * kf0.W * 4;
       for (int k = 0; k < kClsFrames; ++k) {
         const saf_frame& fr = frames[f0 + fb + (k < ca.n ? k : 0)];
@@ -1914,7 +1908,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (ov && hipEventRecord(ov->cls_done[par], cs) != hipSuccess) return fail(SAF_E_HIP, "hipEventRecord");
     return SAF_OK;
   };
-  if (n_units > first_new && (rc = classify(first_new))) return rc;
+  if ((rc = classify(0))) return rc;
   // A recycled volume (saf_fuse_frames_recycled): the rows of the voxels that are still unwritten when the call is over have to be
   // zeroed -- on a coherent scene five sixths of the volume, 28 GB of stores at 256^3 x 512 and a tenth of the job when they follow
   // it.  When every unit covers the whole volume they are written on the classification stream BESIDE the last unit's row kernel
@@ -1928,22 +1922,13 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   for (int ui = 0; ui < n_units && rc == SAF_OK; ++ui) {
     const WinUnit& u = units[ui];
     const Geom g = geom(u.kv);
-    const int F = u.F, f0 = u.f0, par = (ubase + ui) & 1;
-    if (carry && carry->hold && ui + 1 == n_units && ui >= first_new) {
-      // a session's last unit stays pending: classified (queued on the classification stream, its event recorded), its row
-      // kernel launched by the next call of the session -- beside that call's first classification
-      carry->pending = true;
-      carry->kv = u.kv; carry->F = F; carry->window = u.window; carry->kf0 = kf0;
-      break;
-    }
-    if (carry && ui == 0 && first_new) carry->pending = false;
+    const int F = u.F, f0 = u.f0, par = ui & 1;
     WinArgs wa;
     wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     const WinTable* tab = reinterpret_cast<const WinTable*>(hdr + kTableOff);
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
-    // queued now: it runs beside this unit's row kernel (unit `first_new` was classified ahead of the loop)
-    if (ov && ui + 1 < n_units && ui + 1 > first_new && (rc = classify(ui + 1))) break;
+    if (ov && ui + 1 < n_units && (rc = classify(ui + 1))) break;  // queued now: it runs beside this unit's row kernel
     if (ov && hipStreamWaitEvent(s, ov->cls_done[par], 0) != hipSuccess) { rc = fail(SAF_E_HIP, "hipStreamWaitEvent"); break; }
     if (clear_beside && ui + 1 == n_units) {
       // (queued behind this unit's classification; the row kernel of the unit before must have stored its weights)
@@ -1979,10 +1964,6 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (ov && hipEventRecord(ov->fuse_done[par], s) != hipSuccess) { rc = fail(SAF_E_HIP, "hipEventRecord"); break; }
     if (!ov && ui + 1 < n_units) rc = classify(ui + 1);
   }
-  if (carry) {
-    carry->n_units = ubase + n_units;
-    carry->n_windows = wbase + (n_frames > 0 ? n_win : 0);
-  }
   if (ov) {  // whatever was queued on the classification stream is ordered before later work of the caller (error paths too)
     if (hipEventRecord(ov->join, cs) == hipSuccess) (void)hipStreamWaitEvent(s, ov->join, 0);
   }
@@ -2003,6 +1984,215 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     }
   }
 #endif
+  return rc;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Streaming sessions (saf_fuse_session_*, round 6): the one-frame-per-integrate() queue hands its frames over 32 at a time.
+//
+// A separate saf_fuse_frames call per flushed window exposes, every time, the window's whole classification (3.7 ms at 256^3:
+// nothing of the call runs beside it) -- and the queue cannot flush before the window's 128th frame has been staged (3 ms).  A
+// session keeps ONE pipeline over its calls and classifies as the frames arrive: every push of 32 frames is one classification
+// launch (one mask plane) on the classification stream; when a window's last plane is queued its row kernel follows on the
+// caller's stream, and the next window's launches -- pushed while it runs -- run beside it, as units u and u + 1 of one
+// fuse_many_windowed call do.  Same kernels, same arguments per launch, same window cuts: results are bit for bit those of one
+// saf_fuse_frames call over the same frames.  (The row forms only: the brick form builds its segments per window.)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct StreamPlan {  // what fuse_many_windowed derives at its top, for one (volume, frame shape, workspace)
+  WinLayout wl;
+  bool tiled, sum, maps16;
+  size_t dpx, img_bytes16, win_lds;
+  int P, img_vecs, prep_blocks, ts_log2, tiles_x, n_tiles, wlen;
+  WinFn fn;
+};
+int stream_plan(const KVol& kv, const KFrame& kf0, size_t workspace_bytes, StreamPlan* pl) {
+  pl->P = kf0.npy * kf0.npx;
+  pl->dpx = depth_px_padded(kf0.H, kf0.W);
+  const WinLayout wl_lin = win_layout(kv.N, kv.D, pl->P), wl_til = win_layout(kv.N, kv.D, pl->P, false, pl->dpx);
+  const char* til_env = getenv("SAF_CLS_TILED");
+  pl->tiled = !(til_env && til_env[0] == '0') && pl->dpx * sizeof(float) < (size_t)1 << 31 && workspace_bytes >= wl_til.cmax_off;
+  pl->wl = pl->tiled ? wl_til : wl_lin;
+  if (workspace_bytes < pl->wl.cmax_off) return fail(SAF_E_WORKSPACE, "session: workspace too small");
+  pl->sum = kv.accum == SAF_SUM;
+  pl->img_vecs = (int)(pl->wl.img_bytes / sizeof(float4));
+  pl->prep_blocks = (kv.D * (pl->P + 1) + 255) / 256;
+  const char* m16 = getenv("SAF_WIN_MAPS16");
+  const bool of = window_form_sums() && !(kv.bf16 != 0 && m16 && m16[0] == '0');
+  switch (kv.D / 256) {
+    case 1: pl->fn = pick_win<1>(pl->sum, kv.bf16 != 0, of, &pl->win_lds); break;
+    case 2: pl->fn = pick_win<2>(pl->sum, kv.bf16 != 0, of, &pl->win_lds); break;
+    case 3: pl->fn = pick_win<3>(pl->sum, kv.bf16 != 0, of, &pl->win_lds); break;
+    default: pl->fn = pick_win<4>(pl->sum, kv.bf16 != 0, of, &pl->win_lds); break;
+  }
+  if (!pl->fn) return fail(SAF_E_UNSUPPORTED, "session: no row kernel for this width");
+  pl->maps16 = of && kv.bf16 != 0 && SAF_WIN_MAPS16_BUILD;
+  pl->img_bytes16 = ((size_t)kv.D * (pl->P + 1) * 2 + 255) & ~(size_t)255;
+  if (pl->maps16) pl->img_vecs = (int)(pl->img_bytes16 / sizeof(float4));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pl->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->win_lds);
+  if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", pl->win_lds, hipGetErrorString(e));
+  pl->ts_log2 = 4;
+  while (((kf0.W + (1 << pl->ts_log2) - 1) >> pl->ts_log2) * ((kf0.H + (1 << pl->ts_log2) - 1) >> pl->ts_log2) > kMaxDepthTiles) ++pl->ts_log2;
+  pl->tiles_x = (kf0.W + (1 << pl->ts_log2) - 1) >> pl->ts_log2;
+  pl->n_tiles = pl->tiles_x * ((kf0.H + (1 << pl->ts_log2) - 1) >> pl->ts_log2);
+  pl->wlen = window_frames();
+  return SAF_OK;
+}
+}  // namespace
+
+bool stream_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes) {
+  // what the windowed ROW forms take (window_ok's shape rules without its minimum of 16 frames per call: a push may be short)
+  if (brick_form_ok(kv)) return false;
+  if (getenv("SAF_WINDOW") && getenv("SAF_WINDOW")[0] == '0') return false;
+  if (kv.bf16 && getenv("SAF_WINDOW_BF16") && getenv("SAF_WINDOW_BF16")[0] == '0') return false;
+  if (kv.D % 256 != 0 || kv.D > 1024 || (kv.bf16 && kv.D % 512 != 0) || n_frames < 1) return false;
+  const saf_frame& f0 = frames[0];
+  for (int32_t i = 1; i < n_frames; ++i) {
+    const saf_frame& f = frames[i];
+    if (f.height != f0.height || f.width != f0.width || f.npy != f0.npy || f.npx != f0.npx || f.rgb_bilinear != f0.rgb_bilinear ||
+        (f.label_map == nullptr) != (f0.label_map == nullptr))
+      return false;
+  }
+  if (f0.npx + 3 > 255 || f0.npy + 3 > 255) return false;
+  const WinLayout wl = win_layout(kv.N, kv.D, f0.npy * f0.npx);
+  return wl.maps_bytes < (size_t)kTapOutside && workspace_bytes >= wl.cmax_off;
+}
+
+// the open window's row kernel: behind its last classification launch
+int stream_close(void* workspace, size_t workspace_bytes, uint64_t* stats, hipStream_t s, const WinOverlap* ov, WinStream* st) {
+  if (!st->open || st->filled == 0) return SAF_OK;
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  StreamPlan pl;
+  int rc = stream_plan(st->kv, st->kf0, workspace_bytes, &pl);
+  if (rc) return rc;
+  const KVol& kv = st->kv;
+  const int par = st->n_windows & 1, F = st->filled;
+  if (hipEventRecord(ov->cls_done[par], ov->aux) != hipSuccess || hipStreamWaitEvent(s, ov->cls_done[par], 0) != hipSuccess)
+    return fail(SAF_E_HIP, "session: could not order the row kernel behind its classification");
+  unsigned char* hdr = ws + (size_t)par * kHdrBytes;
+  const WinTable* tab = reinterpret_cast<const WinTable*>(hdr + kTableOff);
+  uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + pl.wl.maps_bytes + (size_t)par * pl.wl.mask_bytes);
+  float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
+  WinArgs wa;
+  wa.F = F; wa.H = st->kf0.H; wa.W = st->kf0.W; wa.npy = st->kf0.npy; wa.npx = st->kf0.npx; wa.rgb_bilinear = st->kf0.rgb_bilinear;
+  hipLaunchKernelGGL(prep_rows_kernel, dim3(pl.prep_blocks, F), dim3(256), 0, s, tab, static_cast<void*>(maps),
+                     pl.maps16 ? (int)(pl.img_bytes16 / 2) : (int)(pl.wl.img_bytes / sizeof(float)), kv.D, pl.P, pl.maps16 ? 1 : 0);
+  if ((rc = check_launch("prep_rows_kernel"))) return rc;
+  // (the row kernel's grid and unit order: as fuse_many_windowed's geom())
+  const bool of = window_form_sums() && !(kv.bf16 != 0 && getenv("SAF_WIN_MAPS16") && getenv("SAF_WIN_MAPS16")[0] == '0');
+  const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
+  const char* xcd_env = getenv("SAF_WIN_XCD");
+  const uint32_t n_pieces = (uint32_t)(((int64_t)kv.N + kPiece - 1) / kPiece), row_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
+  uint32_t grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : (of ? SAF_WIN_OF_WPE : 2));
+  if (grid > row_wgs) grid = row_wgs;
+  const int xcd_order = !(xcd_env && xcd_env[0] == '0') && kv.nx % 16 == 0 && kv.ny % 16 == 0 && kv.nz % kUnitVox == 0 && kv.N % kPiece == 0 ? 1 : 0;
+  hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(kWinThreads), pl.win_lds, s, kv, wa, tab, maps, pl.img_vecs,
+                     reinterpret_cast<unsigned long long*>(stats), reinterpret_cast<unsigned int*>(hdr), masks, pl.wl.mask_plane,
+                     reinterpret_cast<const unsigned long long*>(hdr + kClsAccOff), xcd_order);
+  if ((rc = check_launch("fuse_window_kernel"))) return rc;
+  if (hipEventRecord(ov->fuse_done[par], s) != hipSuccess) return fail(SAF_E_HIP, "hipEventRecord");
+  st->n_windows += 1;
+  st->filled = 0;
+  st->open = false;
+  return SAF_OK;
+}
+
+int stream_push(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes, uint64_t* stats,
+                hipStream_t s, hipEvent_t ready, hipStream_t tile_stream, const WinOverlap* ov, WinStream* st) {
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  int rc = SAF_OK;
+  KFrame kf0;
+  if ((rc = make_kframe(&frames[0], &kf0))) return rc;
+  for (int32_t i = 1; i < n_frames; ++i) {
+    KFrame t;
+    if ((rc = make_kframe(&frames[i], &t))) return rc;
+  }
+  if (st->have_shape && (kf0.H != st->kf0.H || kf0.W != st->kf0.W || kf0.npy != st->kf0.npy || kf0.npx != st->kf0.npx ||
+                         kf0.rgb_bilinear != st->kf0.rgb_bilinear || (kf0.label_map == nullptr) != (st->kf0.label_map == nullptr)))
+    return fail(SAF_E_INVALID, "the frames of a streaming session share their shapes: finish the session first");
+  if (st->open && st->filled % kClsFrames != 0)
+    return fail(SAF_E_INVALID, "the open window holds %d frames: only a window's LAST push may be short of a multiple of %d (finish the session)", st->filled, kClsFrames);
+  StreamPlan pl;
+  if ((rc = stream_plan(kv, kf0, workspace_bytes, &pl))) return rc;
+  st->kv = kv; st->kf0 = kf0; st->have_shape = true;
+  hipStream_t cs = ov->aux;
+  // What the classification of these frames waits for: their staging.  With `ready` (an event the caller recorded behind it) ONLY
+  // that -- forking from `s` would also wait for the row kernel queued there, the very kernel these launches are to run beside
+  // (the first version did: every window's classification started when the previous row kernel ended; api_b1 0.895 of bulk).
+  // A session's first push forks from `s` as well: whatever the caller queued there before the session comes first.
+  if (!ready || (st->n_windows == 0 && !st->open)) {
+    if (hipEventRecord(ov->fork, s) != hipSuccess || hipStreamWaitEvent(cs, ov->fork, 0) != hipSuccess)
+      return fail(SAF_E_HIP, "session: could not fork the classification stream");
+  }
+  if (ready && hipStreamWaitEvent(cs, ready, 0) != hipSuccess) return fail(SAF_E_HIP, "session: hipStreamWaitEvent(ready)");
+  // `tile_stream` (the stream the frames were staged on, idle otherwise): the launches' depth tile maxima and tiled copies are
+  // computed THERE, behind the staging, and the classification waits for them -- two small launches per 32 frames (0.1 ms beside a
+  // row kernel) that would otherwise sit in the classification chain, which a window's time follows
+  hipStream_t ts = tile_stream ? tile_stream : cs;
+  const char* til_env = getenv("SAF_CLS_TILED");
+  const bool verify = getenv("SAF_CLS_VERIFY") && getenv("SAF_CLS_VERIFY")[0] == '1' && stats;
+  int done = 0;
+  while (done < n_frames) {
+    if (st->open && st->filled >= pl.wlen && (rc = stream_close(workspace, workspace_bytes, stats, s, ov, st))) return rc;
+    const int par = st->n_windows & 1, widx = st->n_windows, tslot = widx % kTileWindows;
+    unsigned char* hdr = ws + (size_t)par * kHdrBytes;
+    uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + pl.wl.maps_bytes + (size_t)par * pl.wl.mask_bytes);
+    float* dmax_w = reinterpret_cast<float*>(ws + pl.wl.tile_off + (size_t)tslot * pl.wl.tile_win);
+    float* tmax_w = dmax_w + 1024;
+    float* tdepth_w = tmax_w + (size_t)kWin * kMaxDepthTiles;
+    unsigned long long* cls_acc = reinterpret_cast<unsigned long long*>(hdr + kClsAccOff);
+    WinTable* tab = reinterpret_cast<WinTable*>(hdr + kTableOff);
+    if (!st->open) {  // a window starts: its header (counters, frame table) and mask planes were the window's two before
+      if (st->n_windows >= 2 && hipStreamWaitEvent(cs, ov->fuse_done[par], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
+      if (hipMemsetAsync(hdr, 0, kHdrBytes, cs) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
+      st->open = true;
+      st->filled = 0;
+    }
+    const int fb = st->filled;  // a multiple of 32 (checked above / by the loop)
+    ClsArgs ca;
+    ca.n = n_frames - done < kClsFrames ? n_frames - done : kClsFrames;
+    if (fb + ca.n > pl.wlen) ca.n = pl.wlen - fb;
+    ca.H = kf0.H; ca.W = kf0.W; ca.slot = fb; ca.count = 1;
+    ca.guard_x = kf0.W <= 8192 ? (float)kf0.W * SAF_CLS_GUARD_EPS : 2.0f;
+    ca.guard_y = kf0.H <= 8192 ? (float)kf0.H * SAF_CLS_GUARD_EPS : 2.0f;
+    ca.mid_x = (float)(kf0.W - 1) * 0.5f; ca.mid_y = (float)(kf0.H - 1) * 0.5f;
+    ca.verify = stats ? reinterpret_cast<unsigned long long*>(stats) + 7 : nullptr;
+    ca.tiles_x8 = (kf0.W + (1 << SAF_CLS_TILE_WL2) - 1) >> SAF_CLS_TILE_WL2;
+    // (the session's first window has the chip to itself: it reads the frames' own images, as a call's first unit does)
+    const bool use_tiled = pl.tiled && (widx > 0 || (til_env && til_env[0] == '2'));
+    ca.depth_bytes = use_tiled ? (int)(pl.dpx * sizeof(float)) : kf0.H * kf0.W * 4;
+    for (int k = 0; k < kClsFrames; ++k) {
+      const saf_frame& fr = frames[done + (k < ca.n ? k : 0)];
+      ca.depth[k] = fr.depth; ca.rgb[k] = fr.rgb; ca.pose[k] = fr.pose; ca.K[k] = fr.K; ca.label_map[k] = fr.label_map;
+      ca.feat_map[k] = fr.feat_map;
+    }
+    float* dmax = dmax_w + fb;
+    float* tmax = tmax_w + (size_t)fb * kMaxDepthTiles;
+    float* tdepth = tdepth_w + (size_t)fb * pl.dpx;
+    // this launch's depth tile maxima (and tiled copies), from the frames' own images
+    hipLaunchKernelGGL(depth_max_kernel, dim3((pl.n_tiles + 3) / 4, ca.n), dim3(256), 0, ts, ca, pl.ts_log2, pl.tiles_x, pl.n_tiles, tmax,
+                       pl.tiled ? tdepth : nullptr, ca.tiles_x8, (int)pl.dpx);
+    hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, ts, tmax, pl.n_tiles, dmax);
+    if (tile_stream && (hipEventRecord(ov->tiles, ts) != hipSuccess || hipStreamWaitEvent(cs, ov->tiles, 0) != hipSuccess))
+      return fail(SAF_E_HIP, "session: could not order the classification behind its depth tiles");
+    if (use_tiled)
+      for (int k = 0; k < kClsFrames; ++k) ca.depth[k] = tdepth + (size_t)(k < ca.n ? k : 0) * pl.dpx;
+    uint32_t* plane = masks + (size_t)(fb / kClsFrames) * pl.wl.mask_plane;
+    const uint32_t tx = ((uint32_t)kv.nx + 8 * kBrickX - 1) / (8 * kBrickX), ty = ((uint32_t)kv.ny + 8 * kBrickY - 1) / (8 * kBrickY);
+    const uint32_t nbz = ((uint32_t)kv.nz + kBrickZ - 1) / kBrickZ, cls_wgs = (tx * ty * 64u * nbz + 3u) / 4u;
+    auto kfn = use_tiled ? (verify ? (pl.sum ? classify_bricks_kernel<true, true, true> : classify_bricks_kernel<false, true, true>)
+                                   : (pl.sum ? classify_bricks_kernel<true, false, true> : classify_bricks_kernel<false, false, true>))
+                         : (verify ? (pl.sum ? classify_bricks_kernel<true, true, false> : classify_bricks_kernel<false, true, false>)
+                                   : (pl.sum ? classify_bricks_kernel<true, false, false> : classify_bricks_kernel<false, false, false>));
+    hipLaunchKernelGGL(kfn, dim3(cls_wgs), dim3(256), 0, cs, kv, ca, dmax, tmax, pl.ts_log2, pl.tiles_x, plane,
+                       reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
+    if ((rc = check_launch("classify_bricks_kernel"))) return rc;
+    st->filled += ca.n;
+    done += ca.n;
+  }
+  // a full window's row kernel follows at once: the launches of the next pushes run beside it
+  if (st->open && st->filled >= pl.wlen) rc = stream_close(workspace, workspace_bytes, stats, s, ov, st);
   return rc;
 }
 

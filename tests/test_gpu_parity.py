@@ -717,6 +717,27 @@ def test_query_golden(golden_dir):
     np.testing.assert_allclose(sur_r.cpu().numpy(), g["surgery_redundant"], rtol=1e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("nl,fdt", [(100, torch.float32), (65, torch.float32), (129, torch.float16)])
+def test_query_scan_over_more_than_64_labels(oracle, nl, fdt):
+    """The reference's control set grows by one label per new query text (clip_seem_fusion.py:496-505): beyond 64 labels the scan
+    runs the exact-fp32 MFMA kernel once per block of 64 labels and a finishing pass over the [N, L] scores (softmax's
+    maximum and denominator, surgery's mean over ALL labels) -- against the oracle's one-pass scan."""
+    from spatially_aware_ai_amd.clipfusion import _query_scan
+
+    n, d = 3001, 512
+    g = torch.Generator().manual_seed(nl)
+    feats = torch.randn((n, d), generator=g)
+    feats[7] = 0.0  # an all-zero row: nan_to_num gives zeros
+    text = torch.nn.functional.normalize(torch.randn((nl, d), generator=g), dim=-1)
+    fd = feats.to(fdt).cuda()
+    fo = fd.float().cpu()
+    for epi, scale in ((_abi.SAF_Q_SURGERY, 1.0), (_abi.SAF_Q_SOFTMAX, 100.0), (_abi.SAF_Q_SCORES, 3.0)):
+        want = oracle.query_scan(fo, text, epi, scale=scale, normalize=True)
+        got = _query_scan(fd, text.cuda(), epi, scale=scale, normalize=True)
+        assert got.shape == (n, nl)
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"epilogue {epi}, {nl} labels")
+
+
 def test_text_query_engine_postprocessing(golden_dir):
     """clip_text_query end to end on captured features: relevance and RGBA (clip_seem_fusion.py:507-559)."""
     from spatially_aware_ai_amd.clip_seem_fusion import TextQueryEngine
