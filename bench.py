@@ -881,12 +881,14 @@ def measure_traffic(a, timeout_s=150, overrides=None):
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="saf_pmc_", dir="/tmp")
-        o = dict(grid=str(a.grid), depth_kind=a.depth_kind, feat_dtype=a.feat_dtype, labels=a.labels, label_kind=a.label_kind)
+        o = dict(grid=str(a.grid), depth_kind=a.depth_kind, feat_dtype=a.feat_dtype, labels=a.labels, label_kind=a.label_kind,
+                 pose_kind=a.pose_kind)
         o.update(overrides or {})
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
                os.path.abspath(__file__), "--cpu-frames", "0", "--steps", "1", "--warmup", "0", "--no-profile-events", "--no-side",
                "--end-to-end", "0", "--no-pmc", "--frames", str(a.frames), "--grid", o["grid"], "--dim", str(a.dim),
-               "--depth-kind", o["depth_kind"], "--feat-dtype", o["feat_dtype"], "--label-kind", o["label_kind"]] + (
+               "--depth-kind", o["depth_kind"], "--feat-dtype", o["feat_dtype"], "--label-kind", o["label_kind"],
+               "--pose-kind", o["pose_kind"], "--api-b1", "0"] + (
                    ["--labels"] if o["labels"] else [])
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s, check=True,
@@ -915,12 +917,13 @@ SIDE_TRAFFIC_CASES = {  # side workload -> the main-path flags of the same job (
     "config3_256cube_bf16_labels": dict(feat_dtype="bf16", labels=True, label_kind="iid"),
     "config3_256cube_bf16_labels_consistent": dict(feat_dtype="bf16", labels=True, label_kind="world"),
     "coherent_scene_depth_B": dict(depth_kind="B"),
+    "coherent_scene_free_poses": dict(depth_kind="B", pose_kind="free"),
 }
 
 
 def side_traffic(a, path):
     """`bench.py --side-traffic`: the counter traffic (HBM bytes per window of the row kernel) of every side workload's job, two
-    profiler passes each, written to `path` (committed as profiles/r05/side_traffic.json: the default run, which must stay
+    profiler passes each, written to `path` (committed as profiles/r06/side_traffic.json: the default run, which must stay
     within minutes, quotes it instead of running eight more child processes)."""
     out = {}
     for name, ov in SIDE_TRAFFIC_CASES.items():
@@ -1026,10 +1029,10 @@ def side_workloads(a, device, L, frames_A, npy, npx):
                          "avg_launch_us": round(kern * 1e6, 1), "launches": int(n.value), "windows": int(n_win),
                          "algorithmic_bytes_per_launch": int(fuse_bytes)}}
         try:  # counter traffic of the same job: measured this round with `bench.py --side-traffic` (two profiler passes per workload)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r05", "side_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r06", "side_traffic.json")))
             if tj.get(name) and a.dim == 512 and a.width == 640 and a.height == 480:
                 out[name]["roofline"]["traffic"] = tj[name]["hbm_bytes_per_window"]
-                out[name]["roofline"]["traffic_source"] = "profiles/r05/side_traffic.json (this round, another box): " + tj["method"]
+                out[name]["roofline"]["traffic_source"] = "profiles/r06/side_traffic.json (this round, another box): " + tj["method"]
         except Exception:  # noqa: BLE001
             pass
         del fz, ws, keep

@@ -124,7 +124,10 @@ size_t saf_fuse_workspace_bytes_for(const saf_volume* vol, int32_t npy, int32_t 
 /* The same, with room for the frames' depth images (height x width) re-laid-out in 4 x 8-pixel tiles, four windows of 128
  * frames of them (0.63 GB at 640 x 480): with such a workspace the windowed path's classification gathers depth from the
  * tiled copies -- half the cache lines per brick and frame --, with a smaller one from the frames'
- * own row-major images; results are identical either way.  New in round 5; nothing to mirror in the reference. */
+ * own row-major images; results are identical either way.  New in round 5; nothing to mirror in the reference.
+ * Round 6: for a volume that counts labels (ClipSeemFusion) it also holds ONE window of the frames' rgb and label images packed as
+ * {r, g, b, label} pixels in 4 x 2-pixel tiles (0.63 GB at 640 x 480): the row kernel then takes a hit's bilinear colour and its
+ * class from four 16-byte gathers instead of thirteen 4-byte ones (clip_seem_fusion.py:786-798); identical results either way. */
 size_t saf_fuse_workspace_bytes_for_frames(const saf_volume* vol, int32_t npy, int32_t npx, int32_t height, int32_t width);
 
 /*
@@ -187,9 +190,9 @@ int saf_fuse_path(const saf_volume* vol, const saf_frame* frames, int32_t n_fram
  *                            frames (their staging), on any stream, and behind the previous finish of this session; the
  *                            classification waits for it INSTEAD of for everything queued on `stream` -- where the previous
  *                            window's row kernel sits, the kernel it is meant to run beside.  NULL: it waits for `stream`.
- *                            `tile_stream` (a hipStream_t, may be NULL): the stream the frames were staged on; the launches'
- *                            depth tile maxima (two small kernels per 32 frames) run there instead of in the classification
- *                            chain.  That stream must be ordered behind the row kernel of the window four windows back (the
+ *                            `tile_stream` (a hipStream_t, may be NULL): the stream the frames were staged on (the one `ready_event`
+ *                            was recorded on: with it the event itself is not waited for); the launches' depth tile maxima (two
+ *                            small kernels per 32 frames) run there, behind the staging, instead of in the classification chain.  That stream must be ordered behind the row kernel of the window four windows back (the
  *                            tile region holds four windows: the host queue's staging ring has the same period).
  *   saf_fuse_session_finish  launches the row kernel of the window that is still open; behind it (in stream order) the volume
  *                            holds every pushed frame, bit for bit as one saf_fuse_frames call over them leaves it.

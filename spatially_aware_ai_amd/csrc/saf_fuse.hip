@@ -1052,7 +1052,7 @@ size_t saf_fuse_workspace_bytes_for_frames(const saf_volume* vol, int32_t npy, i
   KVol kv;
   if (!vol || npy <= 0 || npx <= 0 || height <= 0 || width <= 0 || make_kvol(vol, &kv)) return 0;
   const size_t a = ws_layout(kv.N, kv.D, npy * npx).total;
-  const size_t b = window_workspace_bytes(kv.N, kv.D, npy * npx, brick_form_ok(kv), height, width);
+  const size_t b = window_workspace_bytes(kv.N, kv.D, npy * npx, brick_form_ok(kv), height, width, kv.labels != nullptr);
   return a > b ? a : b;
 }
 

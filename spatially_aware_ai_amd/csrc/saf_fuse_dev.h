@@ -286,7 +286,7 @@ struct ScopedPair {
 }  // namespace
 
 // the windowed path (saf_window.hip), called by saf_fuse_frames
-size_t window_workspace_bytes(int64_t n_vox, int D, int P, bool bricks, int H = 0, int W = 0);
+size_t window_workspace_bytes(int64_t n_vox, int D, int P, bool bricks, int H = 0, int W = 0, bool labels = false);
 int window_frames();  // frames per window of this call (SAF_WINDOW_FRAMES, or 64 with SAF_WIN_FRAMES=64)
 bool window_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes);
 // Streams / events for running the classification of window w + 1 beside the row kernel of window w (may be NULL:

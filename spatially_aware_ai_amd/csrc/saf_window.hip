@@ -100,6 +100,20 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const WinTable* __restri
 }
 
 
+// ClipSeemFusion's image side (round 6): a hit's bilinear rgb sample is four 12-byte taps in two image rows
+// and its class one 4-byte tap of a third image -- 13 gather instructions per 64 hits and 3.3 distinct lines per hit from images
+// no cache holds (128 x 4.9 MB per window): +50 M line fetches per window.  One packed image per frame of {r, g, b, label} pixels
+// in 4 x 2-pixel tiles of a line: four 16-byte gathers and 1.9 lines.  A thread per pixel; the ragged last tile column / row is padding.
+__global__ __launch_bounds__(256) void prep_rgbl_kernel(const WinTable* __restrict__ tab, float4* __restrict__ out, int H, int W,
+                                                        int tiles_x, int px_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * W) return;
+  const int f = blockIdx.y, y = i / W, x = i - y * W;
+  const float* __restrict__ rgb = tab->rgb[f] + (size_t)i * 3;
+  const float* __restrict__ lab = tab->label_map[f];
+  out[(size_t)f * px_pad + rgbl_offset(x, y, tiles_x)] = make_float4(rgb[0], rgb[1], rgb[2], lab ? lab[i] : 0.0f);
+}
+
 #ifdef SAF_WIN_TIMING  // development aid: per-phase wave cycles of the window kernel, printed by the host
 __device__ unsigned long long g_win_t[16];
 #define WT_DECL unsigned long long wt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last_ = __builtin_readcyclecounter(), wt_c0_ = wt_last_, wt_r0_ = __builtin_amdgcn_s_memrealtime()
@@ -138,7 +152,9 @@ __device__ unsigned long long g_win_t[16];
 #define SAF_CLS_BOX 1  // the brick's frame cull tests the box's extents (0: its bounding sphere, rounds 2-3)
 #endif
 #ifndef SAF_CLS_SKIPDEAD
-#define SAF_CLS_SKIPDEAD 1  // depth gathers of voxel slots without a single pixel in the wave are not issued (0: always four per frame)
+#define SAF_CLS_SKIPDEAD 0  // 1: depth gathers of voxel slots without a single pixel in the wave are not issued.  Measured SLOWER (round 6, same box,
+                            // profiles/r06/classification_skipdead_ab.txt: job 75.26 -> 75.7 ms, config 3 69.5 -> 70.0): the ballot and branch per slot cost
+                            // the vector-bound kernel more than the skipped requests save the texture-address path
 #endif
 #ifndef SAF_CLS_FU
 #define SAF_CLS_FU 1   // frames classified together: with the frame cull, occupancy hides the depth gathers better than batching does (1: 1.13 ms, 2: 1.17, 4: 1.29, 8: 2.08 per launch)
@@ -187,9 +203,14 @@ __device__ unsigned long long g_win_t[16];
 constexpr int kUnitVox = kPiece >> SAF_WIN_SPLIT_LOG2;  // voxels of a unit of work (a quarter piece)
 // OF = the order-free form of the row kernel: a row's samples of the window are summed in
 // REGISTERS and the row is blended once, (w0 old + sum) / (w0 + k); no row lives in LDS.
-template <int CPL, bool OF = false>
+#ifndef SAF_WIN_OF_SR2_BF16
+#define SAF_WIN_OF_SR2_BF16 5  // ... of a bf16 volume: 5 rows -- 168 registers instead of 178: two row waves (registers come in blocks of eight) then leave a
+                               // SIMD room for TWO classification waves of 80, with six (184 each) for one; config 3's job 66.0 -> 65.2 ms, the f32 kernel
+                               // (168 registers with six rows) loses with five: 75.1 -> 75.8 (profiles/r06/config3_rgbl_ab.txt)
+#endif
+template <int CPL, bool OF = false, bool BF16 = false>
 struct WinCfg {
-  static constexpr int SR = OF ? (CPL == 1 ? 8 : (CPL == 2 ? SAF_WIN_OF_SR2 : (CPL == 3 ? 3 : 2)))
+  static constexpr int SR = OF ? (CPL == 1 ? 8 : (CPL == 2 ? (BF16 ? SAF_WIN_OF_SR2_BF16 : SAF_WIN_OF_SR2) : (CPL == 3 ? 3 : 2)))
                                : (CPL == 1 ? 8 : (CPL == 2 ? SAF_WIN_SR2 : 3));  // rows of a sub-chunk (LDS resident / register sums)
   static constexpr int P = OF ? (CPL == 1 ? 4 : (CPL == 2 ? SAF_WIN_OF_P2 : 1))
                               : (CPL == 1 ? 6 : (CPL == 2 ? SAF_WIN_P2 : 2));  // tap groups in flight
@@ -946,13 +967,12 @@ __device__ __forceinline__ void win_batch_of(const WinCtx<CPL>& cx, const int (&
 
 
 template <int CPL, bool SUM, bool BF16, bool OF>
-__global__ __launch_bounds__(kWinThreads)
-__attribute__((amdgpu_waves_per_eu(OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE, OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE))) void
-fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, int img_vecs,
-                   unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
-                   const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc,
-                   int xcd_order) {
-  using Cfg = WinCfg<CPL, OF>;
+__device__ __forceinline__ void
+fuse_window_body(const KVol& v, const WinArgs& wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, int img_vecs,
+                 unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
+                 const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc,
+                 int xcd_order) {
+  using Cfg = WinCfg<CPL, OF, BF16>;
   constexpr int SR = Cfg::SR;
   // (s_setprio 1 / 3 here, ahead of the classification waves that share the SIMDs, changes nothing: 105.4 / 105.7 / 105.8 ms)
   // a bf16 sub-chunk also holds its raw rows in registers until they are widened: one tap group fewer in flight
@@ -1160,8 +1180,10 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
           s_hf[j] = hf | ((uint32_t)((cy << 8) | cx) << 6);
           kf.rgb = s_rgb[fb];
           kf.label_map = s_lab[fb];
-          float s0, s1, s2;
-          const int pix = sample_rgb_lane(kf, cam, p.gx, p.gy, s0, s1, s2);
+          float s0, s1, s2, lpk = 0.0f;
+          // (wa.rgbl: ClipSeemFusion's bilinear rgb and the pixel's class from the window's packed images -- four 16-byte gathers)
+          const int pix = wa.rgbl ? sample_rgbl_lane(wa.rgbl + (size_t)fb * wa.rgbl_px, wa.rgbl_tiles_x, kf, cam, p.gx, p.gy, s0, s1, s2, lpk)
+                                  : sample_rgb_lane(kf, cam, p.gx, p.gy, s0, s1, s2);
           s_ha[j] = s0;
           s_hb[j] = s1;
           s_hs2[j] = s2;
@@ -1170,7 +1192,7 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
 #endif
           // the hit's class (clip_seem_fusion.py:786-791: nearest sample of the panoptic map, .long())
           if (SAF_WIN_LABEL_RUNS && v.labels && kf.label_map) {
-            const float lraw = kf.label_map[pix >= 0 ? pix : 0];
+            const float lraw = wa.rgbl ? lpk : kf.label_map[pix >= 0 ? pix : 0];
             const long long l = (long long)(pix >= 0 ? lraw : 0.f);
             const bool ok = l >= 0 && l < v.n_classes;
             lbl = ok ? (int)l : -1;
@@ -1553,16 +1575,43 @@ fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const f
   }
 }
 
+// The kernels proper.  Registers are handed out in blocks of eight and a SIMD has 512: two row waves of up to 176 leave room for TWO
+// classification waves of 80 beside them, two of 177 (= 184) for one.  The order-free D = 512 kernels -- the benchmark's -- are
+// therefore capped at 176 (amdgpu_num_vgpr takes no template-dependent value: hence two wrappers around one body); the bf16 one
+// had crept to 177 in round 5, and config 3's classification beside it lost its second wave per SIMD.
+#ifndef SAF_WIN_OF_VGPRS
+#define SAF_WIN_OF_VGPRS 176
+#endif
+template <int CPL, bool SUM, bool BF16, bool OF>
+__global__ __launch_bounds__(kWinThreads)
+__attribute__((amdgpu_waves_per_eu(OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE, OF ? SAF_WIN_OF_WPE : SAF_WIN_WPE))) void
+fuse_window_kernel(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, int img_vecs,
+                   unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
+                   const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc,
+                   int xcd_order) {
+  fuse_window_body<CPL, SUM, BF16, OF>(v, wa, tab, map_imgs, img_vecs, stats, piece_ctr, hitmask, mask_plane, cls_acc, xcd_order);
+}
+template <int CPL, bool SUM, bool BF16>
+__global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_num_vgpr(SAF_WIN_OF_VGPRS))) void
+fuse_window_kernel_of176(KVol v, WinArgs wa, const WinTable* __restrict__ tab, const float* __restrict__ map_imgs, int img_vecs,
+                         unsigned long long* __restrict__ stats, unsigned int* __restrict__ piece_ctr,
+                         const uint32_t* __restrict__ hitmask, uint32_t mask_plane, const unsigned long long* __restrict__ cls_acc,
+                         int xcd_order) {
+  fuse_window_body<CPL, SUM, BF16, true>(v, wa, tab, map_imgs, img_vecs, stats, piece_ctr, hitmask, mask_plane, cls_acc, xcd_order);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Windowed (voxel-major) path of saf_fuse_frames: see fuse_window_kernel.
 // Workspace: the common header (piece counter), the kWin pixel-major map images of one window, and the
 // window's frame bitmasks (kMaskWords words per voxel).
 // ---------------------------------------------------------------------------------------------
 struct WinLayout {
-  size_t img_bytes, maps_bytes, mask_bytes, tile_off, tile_win, cmax_off, total;
+  size_t img_bytes, maps_bytes, mask_bytes, tile_off, tile_win, rgbl_off, cmax_off, total;
   uint32_t mask_plane;
 };
-WinLayout win_layout(int64_t n_vox, int D, int P, bool bricks = false, size_t depth_px_pad = 0) {
+// rgbl_px_pad > 0 (with depth_px_pad: the layout of saf_fuse_workspace_bytes_for_frames for a volume that counts labels): room for
+// ONE window's packed {r, g, b, label} images behind the tile region
+WinLayout win_layout(int64_t n_vox, int D, int P, bool bricks = false, size_t depth_px_pad = 0, size_t rgbl_px_pad = 0) {
   WinLayout w;
   w.img_bytes = ((size_t)D * (P + 1) * sizeof(float) + 255) & ~(size_t)255;
   w.maps_bytes = (size_t)kWin * w.img_bytes;
@@ -1570,7 +1619,8 @@ WinLayout win_layout(int64_t n_vox, int D, int P, bool bricks = false, size_t de
   w.mask_bytes = ((size_t)w.mask_plane * sizeof(uint32_t) * kMaskWords + 255) & ~(size_t)255;
   w.tile_off = kHdrTotal + w.maps_bytes + 2 * w.mask_bytes;  // the classification's depth tile maxima (one launch's)
   w.tile_win = (tile_win_bytes(depth_px_pad) + 255) & ~(size_t)255;
-  w.cmax_off = w.tile_off + kTileWindows * w.tile_win;  // the brick form's channel maxima and camera table
+  w.rgbl_off = w.tile_off + kTileWindows * w.tile_win;
+  w.cmax_off = w.rgbl_off + (((size_t)kWin * rgbl_px_pad * sizeof(float4) + 255) & ~(size_t)255);  // the brick form's channel maxima and camera table
   // the brick form's segment pools (6.5 GB at 256^3) only where that form can run: the row forms end at cmax_off
   w.total = w.cmax_off + (bricks ? brick_aux_bytes_est(n_vox, D) : 0);
   return w;
@@ -1580,6 +1630,10 @@ using WinFn = void (*)(KVol, WinArgs, const WinTable*, const float*, int, unsign
                        uint32_t, const unsigned long long*, int);
 template <int CPL, bool OF>
 WinFn pick_win(bool sum, bool bf16) {
+  if (OF && CPL == 2 && SAF_WIN_OF_VGPRS > 0) {  // the benchmark's kernels: within 176 registers (see fuse_window_kernel_of176)
+    if (bf16) return sum ? fuse_window_kernel_of176<2, true, true> : fuse_window_kernel_of176<2, false, true>;
+    return sum ? fuse_window_kernel_of176<2, true, false> : fuse_window_kernel_of176<2, false, false>;
+  }
   if (bf16) {
     if (CPL % 2 != 0) return nullptr;
     constexpr int C2 = CPL % 2 == 0 ? CPL : 2;
@@ -1596,8 +1650,9 @@ WinFn pick_win(bool sum, bool bf16, bool of, size_t* lds) {
 // Shapes the windowed path takes; everything else runs the per-frame pipeline.
 }  // namespace
 
-size_t window_workspace_bytes(int64_t n_vox, int D, int P, bool bricks, int H, int W) {
-  return win_layout(n_vox, D, P, bricks, H > 0 && W > 0 ? depth_px_padded(H, W) : 0).total;
+size_t window_workspace_bytes(int64_t n_vox, int D, int P, bool bricks, int H, int W, bool labels) {
+  const bool fr = H > 0 && W > 0;
+  return win_layout(n_vox, D, P, bricks, fr ? depth_px_padded(H, W) : 0, fr && labels ? rgbl_px_padded(H, W) : 0).total;
 }
 
 // SAF_WIN_FORM (read per call): "rows" = the frame-ordered row kernel (bit-identical to fusing frame after frame), "sums" =
@@ -1688,7 +1743,9 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
   // saf_fuse_workspace_bytes_for_frames) or without (the classification then reads the frames' own row-major images).
   // SAF_CLS_TILED=0 (read per call): never tiled; 2: the first unit of a call reads the tiled copies too (tests: a single-window call).
   const size_t dpx = depth_px_padded(kf0.H, kf0.W);
-  const WinLayout wl_lin = win_layout(kv.N, kv.D, P), wl_til = win_layout(kv.N, kv.D, P, false, dpx);
+  // (a volume that counts labels: the frames-sized layout also holds one window of packed {r, g, b, label} images)
+  const size_t rpx = kv.labels ? rgbl_px_padded(kf0.H, kf0.W) : 0;
+  const WinLayout wl_lin = win_layout(kv.N, kv.D, P), wl_til = win_layout(kv.N, kv.D, P, false, dpx, rpx);
   const char* til_env = getenv("SAF_CLS_TILED");
   bool tiled = !(til_env && til_env[0] == '0') && dpx * sizeof(float) < (size_t)1 << 31 && workspace_bytes >= wl_til.cmax_off;
   if (tiled && brick_form_ok(kv)) {  // the brick form's pools follow the tile region: both must fit, or neither moves
@@ -1697,6 +1754,8 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (a_lin > 0 && brick_aux_fits(kv, a_lin) && !(a_til > 0 && brick_aux_fits(kv, a_til))) tiled = false;
   }
   const WinLayout wl = tiled ? wl_til : wl_lin;
+  // ClipSeemFusion's image side from packed images (SAF_WIN_RGBL=0, read per call: from the frames' own images -- the A/B)
+  const bool rgbl_on = wl.cmax_off > wl.rgbl_off && kf0.rgb_bilinear && kf0.label_map && !(getenv("SAF_WIN_RGBL") && getenv("SAF_WIN_RGBL")[0] == '0');
   const bool sum = kv.accum == SAF_SUM;
   int img_vecs = (int)(wl.img_bytes / sizeof(float4));
   const int prep_blocks = (kv.D * (P + 1) + 255) / 256;
@@ -1899,6 +1958,7 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     if (split) {  // the brick form's build kernel: the window's hit records, sorted groups and scalar side, into the segment pool
       WinArgs wa;
       wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
+      wa.rgbl = nullptr; wa.rgbl_px = 0; wa.rgbl_tiles_x = 0;
       ScopedPair t(prof, 3, f0, cs);
       if ((r = launch_brick_build(u.kv, wa, tab, wl.img_bytes, reinterpret_cast<unsigned long long*>(stats), masks, wl.mask_plane,
                                   ws + wl.cmax_off, aux_bytes, par, cs)))
@@ -1925,6 +1985,8 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     const int F = u.F, f0 = u.f0, par = ui & 1;
     WinArgs wa;
     wa.F = F; wa.H = kf0.H; wa.W = kf0.W; wa.npy = kf0.npy; wa.npx = kf0.npx; wa.rgb_bilinear = kf0.rgb_bilinear;
+    wa.rgbl = rgbl_on && !brick_form ? reinterpret_cast<const float4*>(ws + wl.rgbl_off) : nullptr;
+    wa.rgbl_px = (int)rgbl_px_padded(kf0.H, kf0.W); wa.rgbl_tiles_x = (kf0.W + 3) >> 2;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     const WinTable* tab = reinterpret_cast<const WinTable*>(hdr + kTableOff);
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + wl.maps_bytes + (size_t)par * wl.mask_bytes);
@@ -1940,6 +2002,11 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
       hipLaunchKernelGGL(prep_rows_kernel, dim3(prep_blocks, F), dim3(256), 0, s, tab, static_cast<void*>(maps),
                          maps16 ? (int)(img_bytes16 / 2) : (int)(wl.img_bytes / sizeof(float)), kv.D, P, maps16 ? 1 : 0);
       if ((rc = check_launch("prep_rows_kernel"))) break;
+      if (wa.rgbl) {
+        hipLaunchKernelGGL(prep_rgbl_kernel, dim3((kf0.H * kf0.W + 255) / 256, F), dim3(256), 0, s, tab, const_cast<float4*>(wa.rgbl), kf0.H, kf0.W,
+                           wa.rgbl_tiles_x, wa.rgbl_px);
+        if ((rc = check_launch("prep_rgbl_kernel"))) break;
+      }
       maps_of = u.window;
     }
     if (brick_form) {
@@ -2010,7 +2077,8 @@ struct StreamPlan {  // what fuse_many_windowed derives at its top, for one (vol
 int stream_plan(const KVol& kv, const KFrame& kf0, size_t workspace_bytes, StreamPlan* pl) {
   pl->P = kf0.npy * kf0.npx;
   pl->dpx = depth_px_padded(kf0.H, kf0.W);
-  const WinLayout wl_lin = win_layout(kv.N, kv.D, pl->P), wl_til = win_layout(kv.N, kv.D, pl->P, false, pl->dpx);
+  const WinLayout wl_lin = win_layout(kv.N, kv.D, pl->P),
+                  wl_til = win_layout(kv.N, kv.D, pl->P, false, pl->dpx, kv.labels ? rgbl_px_padded(kf0.H, kf0.W) : 0);
   const char* til_env = getenv("SAF_CLS_TILED");
   pl->tiled = !(til_env && til_env[0] == '0') && pl->dpx * sizeof(float) < (size_t)1 << 31 && workspace_bytes >= wl_til.cmax_off;
   pl->wl = pl->tiled ? wl_til : wl_lin;
@@ -2076,9 +2144,18 @@ int stream_close(void* workspace, size_t workspace_bytes, uint64_t* stats, hipSt
   float* maps = reinterpret_cast<float*>(ws + kHdrTotal);
   WinArgs wa;
   wa.F = F; wa.H = st->kf0.H; wa.W = st->kf0.W; wa.npy = st->kf0.npy; wa.npx = st->kf0.npx; wa.rgb_bilinear = st->kf0.rgb_bilinear;
+  const bool rgbl_on = pl.wl.cmax_off > pl.wl.rgbl_off && st->kf0.rgb_bilinear && st->kf0.label_map &&
+                       !(getenv("SAF_WIN_RGBL") && getenv("SAF_WIN_RGBL")[0] == '0');
+  wa.rgbl = rgbl_on ? reinterpret_cast<const float4*>(ws + pl.wl.rgbl_off) : nullptr;
+  wa.rgbl_px = (int)rgbl_px_padded(st->kf0.H, st->kf0.W); wa.rgbl_tiles_x = (st->kf0.W + 3) >> 2;
   hipLaunchKernelGGL(prep_rows_kernel, dim3(pl.prep_blocks, F), dim3(256), 0, s, tab, static_cast<void*>(maps),
                      pl.maps16 ? (int)(pl.img_bytes16 / 2) : (int)(pl.wl.img_bytes / sizeof(float)), kv.D, pl.P, pl.maps16 ? 1 : 0);
   if ((rc = check_launch("prep_rows_kernel"))) return rc;
+  if (wa.rgbl) {
+    hipLaunchKernelGGL(prep_rgbl_kernel, dim3((wa.H * wa.W + 255) / 256, F), dim3(256), 0, s, tab, const_cast<float4*>(wa.rgbl), wa.H, wa.W,
+                       wa.rgbl_tiles_x, wa.rgbl_px);
+    if ((rc = check_launch("prep_rgbl_kernel"))) return rc;
+  }
   // (the row kernel's grid and unit order: as fuse_many_windowed's geom())
   const bool of = window_form_sums() && !(kv.bf16 != 0 && getenv("SAF_WIN_MAPS16") && getenv("SAF_WIN_MAPS16")[0] == '0');
   const int wgs_env = getenv("SAF_WIN_WGS") ? atoi(getenv("SAF_WIN_WGS")) : 0;
@@ -2121,11 +2198,13 @@ int stream_push(const KVol& kv, const saf_frame* frames, int32_t n_frames, void*
   // that -- forking from `s` would also wait for the row kernel queued there, the very kernel these launches are to run beside
   // (the first version did: every window's classification started when the previous row kernel ended; api_b1 0.895 of bulk).
   // A session's first push forks from `s` as well: whatever the caller queued there before the session comes first.
-  if (!ready || (st->n_windows == 0 && !st->open)) {
+  if ((!ready && !tile_stream) || (st->n_windows == 0 && !st->open)) {
     if (hipEventRecord(ov->fork, s) != hipSuccess || hipStreamWaitEvent(cs, ov->fork, 0) != hipSuccess)
       return fail(SAF_E_HIP, "session: could not fork the classification stream");
   }
-  if (ready && hipStreamWaitEvent(cs, ready, 0) != hipSuccess) return fail(SAF_E_HIP, "session: hipStreamWaitEvent(ready)");
+  // (with a tile stream the classification waits for the tiles' event, recorded THERE behind the frames' staging: one barrier per
+  //  launch instead of two -- every cross-stream wait is ~0.05 ms of gap in the classification chain)
+  if (ready && !tile_stream && hipStreamWaitEvent(cs, ready, 0) != hipSuccess) return fail(SAF_E_HIP, "session: hipStreamWaitEvent(ready)");
   // `tile_stream` (the stream the frames were staged on, idle otherwise): the launches' depth tile maxima and tiled copies are
   // computed THERE, behind the staging, and the classification waits for them -- two small launches per 32 frames (0.1 ms beside a
   // row kernel) that would otherwise sit in the classification chain, which a window's time follows

@@ -23,7 +23,43 @@ struct WinTable {
 };
 struct WinArgs {  // what is common to a window's frames
   int F, H, W, npy, npx, rgb_bilinear;
+  // (round 6) ClipSeemFusion's image side: the window's rgb and label images re-laid-out as ONE image per frame of 16-byte
+  // {r, g, b, label} pixels in 4 x 2-pixel tiles of one cache line (prep_rgbl_kernel); NULL: the frames' own images
+  const float4* rgbl;
+  int rgbl_px, rgbl_tiles_x;  // padded pixels per frame, tiles per image row
 };
+// where pixel (x, y) lies in a frame's packed image
+__device__ __forceinline__ int rgbl_offset(int x, int y, int tiles_x) { return (((y >> 1) * tiles_x + (x >> 2)) << 3) + ((y & 1) << 2) + (x & 3); }
+inline size_t rgbl_px_padded(int H, int W) { return (size_t)((H + 1) >> 1) * (size_t)((W + 3) >> 2) * 8; }
+// The same sample from a frame's PACKED image ({r, g, b, label} pixels, tiled: saf_window_dev.h rgbl_offset) -- ClipSeemFusion's
+// bilinear rgb (clip_seem_fusion.py:793-798) as four 16-byte gathers instead of twelve 4-byte ones, and the panoptic class of the
+// nearest pixel (:786-791) from the `.w` of the tap it coincides with (rint(x) is floor(x) or floor(x) + 1) instead of a
+// thirteenth gather from a third image.  Same taps, same weights, same arithmetic: bit for bit sample_rgb_lane + the label lookup.
+__device__ __forceinline__ int sample_rgbl_lane(const float4* __restrict__ img, int tiles_x, const KFrame& f, const Cam& cam, float gx,
+                                                float gy, float& s0, float& s1, float& s2, float& lraw) {
+  const float xn = __builtin_rintf(unnormalize(gx, cam.sfx)), yn = __builtin_rintf(unnormalize(gy, cam.sfy));
+  const bool inb = (xn > -1.0f) && (xn < cam.fw) && (yn > -1.0f) && (yn < cam.fh);
+  const int pix = inb ? (int)yn * f.W + (int)xn : -1;
+  const Bilin bi = bilinear_setup(gx, gy, cam.sfx, cam.sfy);
+  const bool x0ok = bi.x0 >= 0 && bi.x0 < f.W, x1ok = bi.x0 + 1 >= 0 && bi.x0 + 1 < f.W;
+  const bool y0ok = bi.y0 >= 0 && bi.y0 < f.H, y1ok = bi.y0 + 1 >= 0 && bi.y0 + 1 < f.H;
+  const bool knw = x0ok && y0ok, kne = x1ok && y0ok, ksw = x0ok && y1ok, kse = x1ok && y1ok;
+  float4 nw = img[knw ? rgbl_offset(bi.x0, bi.y0, tiles_x) : 0], ne = img[kne ? rgbl_offset(bi.x0 + 1, bi.y0, tiles_x) : 0];
+  float4 sw = img[ksw ? rgbl_offset(bi.x0, bi.y0 + 1, tiles_x) : 0], se = img[kse ? rgbl_offset(bi.x0 + 1, bi.y0 + 1, tiles_x) : 0];
+  // the nearest pixel's class: the tap at (xn - x0, yn - y0)
+  const bool east = inb && (int)xn != bi.x0, south = inb && (int)yn != bi.y0;
+  lraw = south ? (east ? se.w : sw.w) : (east ? ne.w : nw.w);
+  // out-of-image taps: value forced to +0 (x * 0 would keep NaN/inf of pixel 0 alive)
+  if (!knw) nw = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!kne) ne = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!ksw) sw = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!kse) se = make_float4(0.f, 0.f, 0.f, 0.f);
+  s0 = lerp_taps(nw.x, ne.x, sw.x, se.x, bi);
+  s1 = lerp_taps(nw.y, ne.y, sw.y, se.y, bi);
+  s2 = lerp_taps(nw.z, ne.z, sw.z, se.z, bi);
+  return pix;
+}
+
 constexpr size_t kTableOff = 2048;  // WinTable in the workspace header
 static_assert(kTableOff + sizeof(WinTable) <= kHdrBytes, "workspace header layout");
 
