@@ -1836,7 +1836,10 @@ int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames
     Geom g;
     const uint32_t n_pieces = (uint32_t)(((int64_t)u.N + kPiece - 1) / kPiece);
     const uint32_t row_wgs = (n_pieces + kWinWaves - 1) / kWinWaves;
-    g.grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : (of ? SAF_WIN_OF_WPE : 2));
+    // (the frame-ordered form keeps its rows in LDS: with 512-hit chunks 115 KB per workgroup at D = 512 -- ONE fits a CU, and a grid
+    //  of two per CU would leave half of the persistent workgroups waiting for the others to finish)
+    const int fit = win_lds > 0 ? (int)((160 * 1024) / win_lds) : 2;
+    g.grid = (uint32_t)device_cus() * (wgs_env > 0 ? wgs_env : (of ? SAF_WIN_OF_WPE : (fit < 1 ? 1 : (fit > 2 ? 2 : fit))));
     if (g.grid > row_wgs) g.grid = row_wgs;
     // the classification's bricks: the brick grid padded to whole 8 x 8 tiles of brick columns
     const uint32_t tx = ((uint32_t)u.nx + 8 * kBrickX - 1) / (8 * kBrickX), ty = ((uint32_t)u.ny + 8 * kBrickY - 1) / (8 * kBrickY);
