@@ -907,6 +907,13 @@ query_wide2_kernel(Wide2Args wa) {
 // 16-byte stores after v_permlane16_swap (the odd 16-lane rows of one operand against the even rows of the other).
 // ------------------------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifndef SAF_W3_PAIR
+#define SAF_W3_PAIR 0  // 1: heat maps (VS_BACKGROUND, 16-bit out): a row's two 64-byte halves of one output line -- two consecutive tiles -- meet in the
+                       // LDS and leave as ONE full-line store (0: a 64-byte store per row and tile: 46.5 GB written for 33.6 GB of scores).  Built and
+                       // measured in round 6, results identical, SLOWER: 21.2 / 21.5 -> 22.7 / 22.95 ms on one box (profiles/r06/
+                       // wide_scan_paired_stores_ab.txt) -- the epilogue sits at the issue port's limit: a ds_write, two ds_read
+                       // and their wait per row block and pair of tiles cost more than the 13 GB of half-line write traffic they remove
+#endif
 #ifndef SAF_W3_PREFETCH
 #define SAF_W3_PREFETCH 1  // the next row block's first pieces through the LDS (query_wide3_kernel, kPref); 0: every row from HBM at the block change
 #endif
@@ -929,6 +936,8 @@ struct W3State {
                      // block the fp32-output instantiations kept the whole struct in scratch memory)
   int best_q[2];
   const float* inv_lds;  // QUERY_MAX: the wave's 32 (scale / norm) values in LDS, by row of the wave
+  unsigned char* pair_lds;  // SAF_W3_PAIR: the wave's 4 KiB of output lines in LDS ([row block][row][128 bytes]), or nullptr
+  int pair;                 // this step's epilogue tile: 0 = stores its half lines itself, 1 = low half, staged only, 2 = high half: stage, then full lines
 };
 
 template <int OT, int EPI>
@@ -1118,8 +1127,27 @@ __device__ __forceinline__ void w3_piece(int k, const Wide2Args& wa, const f32x4
         auto ry = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
         typedef unsigned int w3_u4 __attribute__((ext_vector_type(4)));
         const w3_u4 w = {rx[0], ry[0], rx[1], ry[1]};
-        uint16_t* o = static_cast<uint16_t*>(wa.out) + t.row[rb] * wa.ostride + colt + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
-        *reinterpret_cast<w3_u4*>(o) = w;
+        const int col0 = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;  // the lane's 8 consecutive columns of the tile
+        if (SAF_W3_PAIR && EPI == SAF_QW_VS_BACKGROUND && st.pair != 0) {
+          // the row's line in LDS: this tile's 64 bytes in its half; the high half then reads whole lines back -- lane l takes
+          // 16 bytes (l & 7) of row (l >> 3) + 8 h -- and a wave's store instruction writes eight full 128-byte lines
+          unsigned char* line = st.pair_lds + (rb * 16 + c) * 128 + (st.pair == 2 ? 64 : 0) + col0 * 2;
+          *reinterpret_cast<w3_u4*>(line) = w;
+          if (st.pair == 2) {
+            const int lane = 16 * g + c;
+            const int64_t row0 = t.row[rb] - c;  // the row block's first row
+            uint16_t* ob = static_cast<uint16_t*>(wa.out) + (colt - kWTile) + 8 * (lane & 7);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int r = (lane >> 3) + 8 * h;
+              const w3_u4 full = *reinterpret_cast<const w3_u4*>(st.pair_lds + (rb * 16 + r) * 128 + (lane & 7) * 16);
+              *reinterpret_cast<w3_u4*>(ob + (row0 + r) * wa.ostride) = full;
+            }
+          }
+        } else {
+          uint16_t* o = static_cast<uint16_t*>(wa.out) + t.row[rb] * wa.ostride + colt + col0;
+          *reinterpret_cast<w3_u4*>(o) = w;
+        }
       }
     }
   } else if (EPI == SAF_QW_ROW_ARGMAX) {
@@ -1211,6 +1239,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   st.lse0 = st.lse1 = 0.f;
   float* s_inv = reinterpret_cast<float*>(s_tiles + 2 * kWTile * ROWB) + wave * kRows;  // QUERY_MAX only
   st.inv_lds = s_inv;
+  // SAF_W3_PAIR: 4 KiB of output lines per wave behind the tiles (the heat maps use no row prefetch region); lines must be lines:
+  // output rows 128-byte aligned
+  constexpr bool kPair = SAF_W3_PAIR && EPI == SAF_QW_VS_BACKGROUND && OT != SAF_F32;
+  const bool pair_ok = kPair && vec_ok && (((uintptr_t)wa.out & 127) == 0) && ((wa.ostride * 2) % 128 == 0);
+  st.pair_lds = kPair ? s_tiles + 2 * kWTile * ROWB + 1024 + wave * 4096 : nullptr;
+  st.pair = 0;
+  bool pair_staged = false;  // the previous tile's halves wait in the LDS (wave-uniform)
   cur.qt = 0;
   prev = cur;
   f32x4_t acc[2][2][2];  // [step parity][row block][query block]
@@ -1348,6 +1383,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifdef SAF_W3_NO_FAST
     fast = false;
 #endif
+    if (kPair) {
+      // low half (an even output tile): staged only -- if the NEXT tile's epilogue takes this path too (same block, a whole tile,
+      // and not the workgroup's very last one, whose epilogue runs behind the loop); high half: completes what was staged
+      st.pair = 0;
+      if (fast && pair_ok) {
+        const int ot = prev.qt - 1;
+        if ((ot & 1) == 0) st.pair = (prev.qt + 1 < n_qt && (prev.qt + 2) * kWTile <= wa.Q && step + 1 < n_steps) ? 1 : 0;
+        else st.pair = pair_staged ? 2 : 0;
+      }
+      pair_staged = st.pair == 1;
+    }
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
     if (!fast) {
 #ifndef SAF_W3_NO_EPI  // (development: the scan without its epilogues -- wrong results, the matrix core's time)
@@ -1381,6 +1427,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // -- every one of them by all lanes of a group that always exists
 #ifndef SAF_W3_NO_EPI
       tail_ops = EPI == SAF_QW_ROW_ARGMAX ? 0 : EPI == SAF_QW_QUERY_MAX ? 1 : (OT == SAF_F32 ? 4 : 2);
+      if (kPair && st.pair == 1) tail_ops = 0;  // (staged: no store this step; a completed pair: four)
+      if (kPair && st.pair == 2) tail_ops = 4;
 #else
       tail_ops = 0;
 #endif
@@ -1496,7 +1544,8 @@ template <int FT, int OT, int KS, int EPI>
 int launch_wide3(const Wide2Args& wa, hipStream_t s) {
   // two text tiles, 1 KiB of 1/norms (QUERY_MAX), and at D = 512 eleven 1 KiB pieces per wave of the next block's rows (kPref)
   constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16) + 1024 +
-                           ((KS == 32 && SAF_W3_PREFETCH && (EPI == SAF_QW_SCORES || EPI == SAF_QW_QUERY_MAX)) ? 8 * 11 * 1024 : 0);
+                           ((KS == 32 && SAF_W3_PREFETCH && (EPI == SAF_QW_SCORES || EPI == SAF_QW_QUERY_MAX)) ? 8 * 11 * 1024 : 0) +
+                           ((SAF_W3_PAIR && EPI == SAF_QW_VS_BACKGROUND && OT != SAF_F32) ? 8 * 4096 : 0);
   auto fn = query_wide3_kernel<FT, OT, KS, EPI>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
