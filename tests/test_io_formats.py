@@ -112,3 +112,43 @@ def test_device_arrays_stream_to_npy(tmp_path):
     vc = np.load(paths["voxel_clip_feats"])
     assert vc.shape == (6, 5, 4, 8) and np.array_equal(vc.reshape(-1, 8), fz.clip_feat.cpu().numpy())
     assert np.load(paths["voxel_rgb"]).shape == (6, 5, 4, 3)
+
+
+def test_array_list_reads_like_the_reference_lists_and_its_json_parses_the_same():
+    """`io.ArrayList` stands in for the nested Python lists the reference's `scene_knowledge` holds (an object's `voxels`: a list of
+    tuples, handy_utils.py:430-452; its mesh: `.tolist()` of three arrays, clip_seem_fusion.py:393-417): same reads, and
+    `dumps_scene_knowledge` renders it natively into text that parses to what `json.dumps(..., default=str)` of the lists gives."""
+    import json
+
+    from spatially_aware_ai_amd.io import ArrayList, array_to_json, dumps_scene_knowledge
+
+    rng = np.random.default_rng(5)
+    vox = rng.integers(0, 300, (2000, 3))
+    verts = (rng.standard_normal((700, 3)) * 1e-3).astype(np.float32)
+    verts[0] = [1e20, -1e-7, 100000.0]
+    verts[1] = [np.float32(0.1), 2.5, -0.0]
+    faces = rng.integers(0, 700, (400, 3)).astype(np.int32)
+    cols = rng.random((700, 3))  # float64, as matplotlib hands colours over
+    vl = ArrayList(vox, tuples=True)
+    assert len(vl) == 2000 and vl[17] == tuple(vox[17].tolist()) and isinstance(vl[17][0], int)
+    assert vl == list(map(tuple, vox.tolist())) and list(vl)[:3] == [tuple(r) for r in vox[:3].tolist()]
+    assert np.array_equal(np.asarray(vl), vox) and vl[5:9] == [tuple(r) for r in vox[5:9].tolist()]
+    assert ArrayList(verts).tolist() == verts.tolist() and ArrayList(verts)[3] == verts[3].tolist()
+    sk = {"unique_objects": {"chair:1": {"class_id": 56, "voxels": vl, "color": [1, 2, 3], "removed": False, "gt": None,
+                                         "mesh": {"vertices": ArrayList(verts), "faces": ArrayList(faces), "colors": ArrayList(cols)}},
+                             "wall:1": {"voxels": ArrayList(np.zeros((0, 3), np.int64), tuples=True), "mesh": None, "odd": np.float32(2.5)}},
+          "object_counts": {"chair": 1}, "scan_version": 0}
+
+    def plain(o):
+        if isinstance(o, ArrayList):
+            return o.array.tolist()
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        return o
+
+    want = json.loads(json.dumps(plain(sk), default=str))
+    assert json.loads(dumps_scene_knowledge(sk)) == want
+    assert json.loads(array_to_json(np.arange(5))) == [0, 1, 2, 3, 4] and json.loads(array_to_json(np.zeros((3, 0)))) == [[], [], []]
+    assert json.loads(dumps_scene_knowledge({"a": [1, 2], "b": "x"})) == {"a": [1, 2], "b": "x"}  # nothing bulky: the standard encoder's text
