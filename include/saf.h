@@ -194,6 +194,9 @@ int saf_fuse_path(const saf_volume* vol, const saf_frame* frames, int32_t n_fram
  *                            was recorded on: with it the event itself is not waited for); the launches' depth tile maxima (two
  *                            small kernels per 32 frames) run there, behind the staging, instead of in the classification chain.  That stream must be ordered behind the row kernel of the window four windows back (the
  *                            tile region holds four windows: the host queue's staging ring has the same period).
+ *   saf_fuse_session_prepare (optional) the depth tile maxima of frames that will be pushed NEXT, in order, computed on `stream` (the one
+ *                            they were staged on) a call ahead of their push: a `ready_event` recorded behind it has completed by the
+ *                            time the frames are pushed, and the push then queues its launch with no cross-stream wait in front.
  *   saf_fuse_session_finish  launches the row kernel of the window that is still open; behind it (in stream order) the volume
  *                            holds every pushed frame, bit for bit as one saf_fuse_frames call over them leaves it.
  *   saf_fuse_session_abandon drops the open window without fusing its rows (the volume is being reset: its classification has
@@ -208,6 +211,8 @@ int saf_fuse_session_ok(const saf_volume* vol, const saf_frame* frames, int32_t 
 int saf_fuse_session_push(saf_fuse_session* session, const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
                           void* workspace, size_t workspace_bytes, uint64_t* stats, void* stream, void* ready_event,
                           void* tile_stream);
+int saf_fuse_session_prepare(saf_fuse_session* session, const saf_volume* vol, const saf_frame* frames, int32_t n_frames,
+                             void* workspace, size_t workspace_bytes, void* stream);
 int saf_fuse_session_finish(saf_fuse_session* session, void* stream);
 int saf_fuse_session_abandon(saf_fuse_session* session);
 int saf_fuse_session_pending(const saf_fuse_session* session);

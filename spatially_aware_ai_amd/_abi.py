@@ -89,6 +89,7 @@ PROTOTYPES = {
     "saf_fuse_session_create": (C.c_void_p, []),
     "saf_fuse_session_ok": (C.c_int, [C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, C.c_size_t]),
     "saf_fuse_session_push": (C.c_int, [C.c_void_p, C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp, _fp, _fp, _fp]),
+    "saf_fuse_session_prepare": (C.c_int, [C.c_void_p, C.POINTER(SafVolume), C.POINTER(SafFrame), C.c_int32, _fp, C.c_size_t, _fp]),
     "saf_fuse_session_finish": (C.c_int, [C.c_void_p, _fp]),
     "saf_fuse_session_abandon": (C.c_int, [C.c_void_p]),
     "saf_fuse_session_pending": (C.c_int, [C.c_void_p]),

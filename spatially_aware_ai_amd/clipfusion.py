@@ -350,8 +350,17 @@ class _FusionVolumeMixin:
                     if label_maps is not None:
                         st["labels"][slot].copy_(label_maps[i], non_blocking=True)
                 self.__dict__["_pending_n"] = k + 1
-                if (slot + 1) % self._PUSH_FRAMES == 0:  # one classification launch's worth of frames: hand them over
-                    self._flush_pending()
+                if (slot + 1) % self._PUSH_FRAMES == 0:
+                    # one classification launch's worth of frames is staged: their depth tiles are computed now, behind the staging
+                    # on this stream, and the chunk BEFORE them is handed over -- its staging and tiles have completed meanwhile
+                    # (the host needs 0.7 ms to stage 32 frames), so its launch is queued with no cross-stream wait in front
+                    # (a session's FIRST window is pushed chunk by chunk at once, each launch waiting for its frames: nothing runs
+                    #  beside it yet, a barrier in front of a launch costs nothing there, and the scan starts 0.7 ms earlier)
+                    self._prepare_chunk(st, slot + 1 - self._PUSH_FRAMES, self._PUSH_FRAMES, stream)
+                    if st["sess_frames"] < win:
+                        self._flush_pending()
+                    elif self.__dict__["_pending_n"] > self._PUSH_FRAMES:
+                        self._flush_pending(keep=self._PUSH_FRAMES)
             if fast:  # the sources are read asynchronously on this stream
                 for t in (depth_imgs, rgb_imgs, poses, K) + (() if lazy is not None else (clip_feat_img,)) + tuple(label_maps or ()):
                     t.record_stream(stream)
@@ -403,17 +412,37 @@ class _FusionVolumeMixin:
             if st is not None:  # the open window's frames (and, conservatively, everybody's) are free behind `ev`
                 st["free_ev"] = [ev] * len(st["free_ev"])
                 st["sess_frames"] = 0
+                st["chunk_ready"] = {}
             if rc != 0:  # its windows are classified and partly fused: nothing to retry
                 self.__dict__["_poisoned"] = "the queue's session could not launch its last row kernel; the volume is incomplete: reset() it"
             check(rc, "saf_fuse_session_finish")
             torch.cuda.current_stream(dev).wait_event(ev)
 
-    def _flush_pending(self, final=False):
+    def _prepare_chunk(self, st, lo, n, stream):
+        """``saf_fuse_session_prepare`` for the staged frames in ring slots [lo, lo + n): their depth tiles, on ``stream`` behind
+        their staging, and the event a later push looks at (``hipEventQuery``).  A shape no session takes: nothing to do."""
+        if self.__dict__.get("_poisoned") or getattr(self, "_shard_stripes", None) is not None:
+            return
+        sl = slice(lo, lo + n)
+        labs = None if st["labels"] is None else st["labels"][sl]
+        arr, _keep, npy, npx = self._make_frames(st["depth"][sl], st["rgb"][sl], st["pose"][sl], st["K"][sl], st["feat"][sl], labs, st["key"][4])
+        vol = self._c_volume(for_fuse=True)
+        ws = self._get_workspace(npy, npx, (int(st["depth"].shape[1]), int(st["depth"].shape[2])))
+        L = lib()
+        if L.saf_fuse_session_ok(C.byref(vol), arr, n, ws.numel()) != 1:
+            return
+        if self.__dict__.get("_session") is None:
+            self.__dict__["_session"] = L.saf_fuse_session_create()
+        if L.saf_fuse_session_prepare(self.__dict__["_session"], C.byref(vol), arr, n, ws.data_ptr(), ws.numel(), stream.cuda_stream) == 0:
+            st.setdefault("chunk_ready", {})[lo + n] = stream.record_event()  # keyed by the slot behind the chunk
+
+    def _flush_pending(self, final=False, keep=0):
         """Hand the staged frames to the library.  ``final``: somebody is about to look -- the session is finished behind them
-        (its last window's rows launched, the current stream waits); else (a window just completed) the window is pushed and
-        its row kernel stays owed until the next push."""
-        n = self.__dict__.get("_pending_n", 0)
-        if not n:
+        (its last window's rows launched, the current stream waits); else the frames but the newest ``keep`` are pushed into
+        the session (the newest chunk's staging and depth tiles are still running: it follows one chunk later, wait-free)."""
+        n = self.__dict__.get("_pending_n", 0) - (0 if final else keep)
+        keep = self.__dict__.get("_pending_n", 0) - n
+        if n <= 0:
             if final:
                 self._finish_session()
             return
@@ -442,12 +471,13 @@ class _FusionVolumeMixin:
                 # the backbone, the descriptors or the argument checks at the entry of the fuse call failed (out of
                 # memory, an unsupported tiling) BEFORE any kernel touched the volume: the frames stay queued -- the next
                 # access raises again instead of reading a volume that silently lacks them
-                self.__dict__["_pending_n"] = n
+                self.__dict__["_pending_n"] = n + keep
             else:
                 # the call failed after launching some of its windows: fusing the same frames again would count them
                 # twice, dropping them would lose them silently.  Neither: the volume is unusable until reset().
                 self.__dict__["_poisoned"] = f"a flush of {n} queued frames failed part-way ({exc!r}); the volume is incomplete: reset() it"
             raise
+        self.__dict__["_pending_n"] = keep
         if final:
             self._finish_session()
             st["ring0"] = 0  # (every quarter now carries the event of the finish, or of the call on the current stream)
@@ -559,7 +589,13 @@ class _FusionVolumeMixin:
                 # the staging kernels (and a deferred backbone's maps) of these frames: what their classification waits for -- NOT
                 # the queue's stream, where the previous window's row kernel sits (the launches are to run beside it).  The
                 # session's first push also orders the queue's stream behind the caller's (reset()'s zeroing, an earlier finish)
-                ready = stream.record_event()
+                # (a chunk whose tiles were prepared a chunk ago brings the event recorded behind them -- completed by now, the
+                #  library finds, and waits for nothing; anything else: an event behind what this stream holds now)
+                ready = (st.get("chunk_ready") or {}).pop(lo + n, None)
+                if ready is None or st.get("lazy") is not None:  # (a deferred backbone has just written these frames' maps: behind THAT)
+                    ready = stream.record_event()
+                for k in [k for k in (st.get("chunk_ready") or {}) if k <= lo + n]:
+                    del st["chunk_ready"][k]
                 if not self.__dict__.get("_session_open"):
                     fs.wait_event(ready)
                 if self.__dict__.get("_session") is None:
@@ -636,6 +672,7 @@ class _FusionVolumeMixin:
             if st is not None:
                 st["sess_frames"], st["ring0"] = 0, 0
                 st["free_ev"] = [ev] * len(st["free_ev"])
+                st["chunk_ready"] = {}
         lazy = bool(lazy) and b["clip_feat"].is_cuda
         for name in ("rgb", "tsdf", "weight", "tsdf_weight", "labels_one_hot") + (() if lazy else ("clip_feat",)):
             t = b.get(name)

@@ -1166,13 +1166,25 @@ int saf_fuse_session_push(saf_fuse_session* ss, const saf_volume* vol, const saf
                      static_cast<hipEvent_t>(ready_event), static_cast<hipStream_t>(tile_stream), &ov, &ss->st);
 }
 
+int saf_fuse_session_prepare(saf_fuse_session* ss, const saf_volume* vol, const saf_frame* frames, int32_t n_frames, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!ss) return fail(SAF_E_INVALID, "session is NULL");
+  KVol kv;
+  int rc = make_kvol(vol, &kv);
+  if (rc) return rc;
+  if (n_frames <= 0 || !frames) return fail(SAF_E_INVALID, "bad frame array");
+  if (!workspace || ((uintptr_t)workspace & 255)) return fail(SAF_E_INVALID, "workspace must be 256-byte aligned");
+  if (!stream_ok(kv, frames, n_frames, workspace_bytes)) return fail(SAF_E_UNSUPPORTED, "saf_fuse_session_prepare: not a shape a session takes");
+  return stream_prepare(kv, frames, n_frames, workspace, workspace_bytes, static_cast<hipStream_t>(stream), &ss->st);
+}
+
 int saf_fuse_session_finish(saf_fuse_session* ss, void* stream) {
   if (!ss) return fail(SAF_E_INVALID, "session is NULL");
   int rc = SAF_OK;
   WinOverlap ov;
   if (ss->st.open && ss->st.filled > 0) {
     if (!session_overlap(ss, &ov)) return fail(SAF_E_HIP, "could not create the classification stream / events of a session");
-    rc = stream_close(ss->workspace, ss->workspace_bytes, ss->stats, static_cast<hipStream_t>(stream), &ov, &ss->st);
+    rc = stream_close(ss->workspace, ss->workspace_bytes, ss->stats, static_cast<hipStream_t>(stream), &ov, &ss->st, false);
   }
   ss->st = WinStream();  // the next push starts a new pipeline (its first window's classification alone on the chip)
   return rc;

@@ -311,11 +311,15 @@ struct WinStream {
   bool have_shape = false;  // kv / kf0 are those of the session's frames
   KVol kv;
   KFrame kf0;
+  long long pushed = 0;     // frames classified so far in this session
+  long long prepared = 0;   // frames whose depth tiles are computed (stream_prepare runs ahead of stream_push: >= pushed, or behind it when unused)
 };
+int stream_prepare(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes, hipStream_t ts,
+                   WinStream* st);
 bool stream_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t workspace_bytes);
 int stream_push(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes, uint64_t* stats,
                 hipStream_t s, hipEvent_t ready, hipStream_t tile_stream, const WinOverlap* ov, WinStream* st);
-int stream_close(void* workspace, size_t workspace_bytes, uint64_t* stats, hipStream_t s, const WinOverlap* ov, WinStream* st);
+int stream_close(void* workspace, size_t workspace_bytes, uint64_t* stats, hipStream_t s, const WinOverlap* ov, WinStream* st, bool preopen);
 // recycled: the volume's feature rows were not cleared when its scalars were (saf_fuse_frames_recycled) -- the rows of voxels
 // whose weight is still 0 when the call is over are zeroed by it, beside the last window's row kernel where the schedule allows.
 int fuse_many_windowed(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes,

@@ -2131,7 +2131,7 @@ bool stream_ok(const KVol& kv, const saf_frame* frames, int32_t n_frames, size_t
 }
 
 // the open window's row kernel: behind its last classification launch
-int stream_close(void* workspace, size_t workspace_bytes, uint64_t* stats, hipStream_t s, const WinOverlap* ov, WinStream* st) {
+int stream_close(void* workspace, size_t workspace_bytes, uint64_t* stats, hipStream_t s, const WinOverlap* ov, WinStream* st, bool preopen) {
   if (!st->open || st->filled == 0) return SAF_OK;
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   StreamPlan pl;
@@ -2175,6 +2175,55 @@ int stream_close(void* workspace, size_t workspace_bytes, uint64_t* stats, hipSt
   st->n_windows += 1;
   st->filled = 0;
   st->open = false;
+  if (preopen) {
+    // The NEXT window is opened here, on the classification stream, right behind this window's last launch: its header's wait
+    // (the row kernel of two windows ago) and its memset are then out of the way when the next frames arrive, and the first
+    // classification launch of window w + 1 reaches the chip a few microseconds BEFORE the row kernel of window w (which still has a
+    // cross-stream wait and prep_rows_kernel in front of it) -- as in one saf_fuse_frames call, where that launch runs at its
+    // alone speed while the row kernel's workgroups find their places (profiles/r06/api_b1_timeline.txt: 1.05 ms against 8.4).
+    const int parn = st->n_windows & 1;
+    unsigned char* hdrn = ws + (size_t)parn * kHdrBytes;
+    if (st->n_windows >= 2 && hipStreamWaitEvent(ov->aux, ov->fuse_done[parn], 0) != hipSuccess) return fail(SAF_E_HIP, "hipStreamWaitEvent");
+    if (hipMemsetAsync(hdrn, 0, kHdrBytes, ov->aux) != hipSuccess) return fail(SAF_E_HIP, "hipMemsetAsync(workspace header)");
+    st->open = true;
+  }
+  return SAF_OK;
+}
+
+// The depth tiles (maxima, tiled copies) of frames that WILL be pushed next, in order, computed on the stream they were staged on --
+// a call ahead of their push: by the time the host pushes them (after staging the next 32), an event recorded behind this call has
+// long completed, the push finds that out with hipEventQuery and queues its classification launch with NO cross-stream wait in front
+// (a barrier packet between two launches of the classification chain is 0.12 ms of idle chain: profiles/r06/api_b1_timeline.txt).
+int stream_prepare(const KVol& kv, const saf_frame* frames, int32_t n_frames, void* workspace, size_t workspace_bytes, hipStream_t ts,
+                   WinStream* st) {
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  int rc = SAF_OK;
+  KFrame kf0;
+  if ((rc = make_kframe(&frames[0], &kf0))) return rc;
+  StreamPlan pl;
+  if ((rc = stream_plan(kv, kf0, workspace_bytes, &pl))) return rc;
+  if (st->prepared < st->pushed) st->prepared = st->pushed;
+  int done = 0;
+  while (done < n_frames) {
+    // where frame number `prepared` of the session will lie: window = closed windows + what is still to be pushed ahead of it
+    const long long ahead = st->prepared - st->pushed + (st->open ? st->filled : 0);
+    const int widx = st->n_windows + (int)(ahead / pl.wlen), fb = (int)(ahead % pl.wlen), tslot = widx % kTileWindows;
+    float* dmax_w = reinterpret_cast<float*>(ws + pl.wl.tile_off + (size_t)tslot * pl.wl.tile_win);
+    float* tmax_w = dmax_w + 1024;
+    float* tdepth_w = tmax_w + (size_t)kWin * kMaxDepthTiles;
+    ClsArgs ca;
+    ca.n = n_frames - done < kClsFrames ? n_frames - done : kClsFrames;
+    if (fb + ca.n > pl.wlen) ca.n = pl.wlen - fb;
+    ca.H = kf0.H; ca.W = kf0.W;
+    for (int k = 0; k < kClsFrames; ++k) ca.depth[k] = frames[done + (k < ca.n ? k : 0)].depth;
+    float* tmax = tmax_w + (size_t)fb * kMaxDepthTiles;
+    hipLaunchKernelGGL(depth_max_kernel, dim3((pl.n_tiles + 3) / 4, ca.n), dim3(256), 0, ts, ca, pl.ts_log2, pl.tiles_x, pl.n_tiles, tmax,
+                       pl.tiled ? tdepth_w + (size_t)fb * pl.dpx : nullptr, (kf0.W + (1 << SAF_CLS_TILE_WL2) - 1) >> SAF_CLS_TILE_WL2, (int)pl.dpx);
+    hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, ts, tmax, pl.n_tiles, dmax_w + fb);
+    if ((rc = check_launch("depth tiles"))) return rc;
+    st->prepared += ca.n;
+    done += ca.n;
+  }
   return SAF_OK;
 }
 
@@ -2201,13 +2250,17 @@ int stream_push(const KVol& kv, const saf_frame* frames, int32_t n_frames, void*
   // that -- forking from `s` would also wait for the row kernel queued there, the very kernel these launches are to run beside
   // (the first version did: every window's classification started when the previous row kernel ended; api_b1 0.895 of bulk).
   // A session's first push forks from `s` as well: whatever the caller queued there before the session comes first.
-  if ((!ready && !tile_stream) || (st->n_windows == 0 && !st->open)) {
+  // (frames whose depth tiles stream_prepare has computed: if `ready` -- recorded behind that -- has COMPLETED, nothing is waited for)
+  const bool prepared = st->prepared >= st->pushed + n_frames;
+  const bool ready_done = prepared && ready && hipEventQuery(ready) == hipSuccess;
+  if (prepared) tile_stream = nullptr;
+  if ((!ready && !tile_stream) || (st->n_windows == 0 && !st->open && st->pushed == 0)) {
     if (hipEventRecord(ov->fork, s) != hipSuccess || hipStreamWaitEvent(cs, ov->fork, 0) != hipSuccess)
       return fail(SAF_E_HIP, "session: could not fork the classification stream");
   }
   // (with a tile stream the classification waits for the tiles' event, recorded THERE behind the frames' staging: one barrier per
   //  launch instead of two -- every cross-stream wait is ~0.05 ms of gap in the classification chain)
-  if (ready && !tile_stream && hipStreamWaitEvent(cs, ready, 0) != hipSuccess) return fail(SAF_E_HIP, "session: hipStreamWaitEvent(ready)");
+  if (ready && !tile_stream && !ready_done && hipStreamWaitEvent(cs, ready, 0) != hipSuccess) return fail(SAF_E_HIP, "session: hipStreamWaitEvent(ready)");
   // `tile_stream` (the stream the frames were staged on, idle otherwise): the launches' depth tile maxima and tiled copies are
   // computed THERE, behind the staging, and the classification waits for them -- two small launches per 32 frames (0.1 ms beside a
   // row kernel) that would otherwise sit in the classification chain, which a window's time follows
@@ -2216,7 +2269,7 @@ int stream_push(const KVol& kv, const saf_frame* frames, int32_t n_frames, void*
   const bool verify = getenv("SAF_CLS_VERIFY") && getenv("SAF_CLS_VERIFY")[0] == '1' && stats;
   int done = 0;
   while (done < n_frames) {
-    if (st->open && st->filled >= pl.wlen && (rc = stream_close(workspace, workspace_bytes, stats, s, ov, st))) return rc;
+    if (st->open && st->filled >= pl.wlen && (rc = stream_close(workspace, workspace_bytes, stats, s, ov, st, true))) return rc;
     const int par = st->n_windows & 1, widx = st->n_windows, tslot = widx % kTileWindows;
     unsigned char* hdr = ws + (size_t)par * kHdrBytes;
     uint32_t* masks = reinterpret_cast<uint32_t*>(ws + kHdrTotal + pl.wl.maps_bytes + (size_t)par * pl.wl.mask_bytes);
@@ -2253,11 +2306,13 @@ int stream_push(const KVol& kv, const saf_frame* frames, int32_t n_frames, void*
     float* tmax = tmax_w + (size_t)fb * kMaxDepthTiles;
     float* tdepth = tdepth_w + (size_t)fb * pl.dpx;
     // this launch's depth tile maxima (and tiled copies), from the frames' own images
-    hipLaunchKernelGGL(depth_max_kernel, dim3((pl.n_tiles + 3) / 4, ca.n), dim3(256), 0, ts, ca, pl.ts_log2, pl.tiles_x, pl.n_tiles, tmax,
-                       pl.tiled ? tdepth : nullptr, ca.tiles_x8, (int)pl.dpx);
-    hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, ts, tmax, pl.n_tiles, dmax);
-    if (tile_stream && (hipEventRecord(ov->tiles, ts) != hipSuccess || hipStreamWaitEvent(cs, ov->tiles, 0) != hipSuccess))
-      return fail(SAF_E_HIP, "session: could not order the classification behind its depth tiles");
+    if (!prepared) {
+      hipLaunchKernelGGL(depth_max_kernel, dim3((pl.n_tiles + 3) / 4, ca.n), dim3(256), 0, ts, ca, pl.ts_log2, pl.tiles_x, pl.n_tiles, tmax,
+                         pl.tiled ? tdepth : nullptr, ca.tiles_x8, (int)pl.dpx);
+      hipLaunchKernelGGL(depth_reduce_kernel, dim3(ca.n), dim3(256), 0, ts, tmax, pl.n_tiles, dmax);
+      if (tile_stream && (hipEventRecord(ov->tiles, ts) != hipSuccess || hipStreamWaitEvent(cs, ov->tiles, 0) != hipSuccess))
+        return fail(SAF_E_HIP, "session: could not order the classification behind its depth tiles");
+    }
     if (use_tiled)
       for (int k = 0; k < kClsFrames; ++k) ca.depth[k] = tdepth + (size_t)(k < ca.n ? k : 0) * pl.dpx;
     uint32_t* plane = masks + (size_t)(fb / kClsFrames) * pl.wl.mask_plane;
@@ -2271,10 +2326,11 @@ int stream_push(const KVol& kv, const saf_frame* frames, int32_t n_frames, void*
                        reinterpret_cast<unsigned long long*>(stats), cls_acc, tab);
     if ((rc = check_launch("classify_bricks_kernel"))) return rc;
     st->filled += ca.n;
+    st->pushed += ca.n;
     done += ca.n;
   }
   // a full window's row kernel follows at once: the launches of the next pushes run beside it
-  if (st->open && st->filled >= pl.wlen) rc = stream_close(workspace, workspace_bytes, stats, s, ov, st);
+  if (st->open && st->filled >= pl.wlen) rc = stream_close(workspace, workspace_bytes, stats, s, ov, st, true);
   return rc;
 }
 
