@@ -222,6 +222,92 @@ __device__ __forceinline__ float half_sum(float x) {
 }
 
 
+// ---- epilogue on the MFMA accumulator layout: this lane holds column n = m (+32 t) of 16 rows.  `inv`: the factor of row m
+// (1 / norm); CS (the split scan): the row's and the columns' power-of-two scales 2^rexp, 2^cexp undone by one v_ldexp_f32,
+// which cannot leave fp32's range half-way the way two multiplications can.
+__device__ __forceinline__ float row_inverse(float ss, int normalize) {
+  // clip_feat /= norm ; nan_to_num: an all-zero row gives zeros       clip_seem_fusion.py:508-511
+  // SAF_NORM_L2_CLAMP: norm.clamp_min(0.1)                            eval_scannet_segmentation.py:549-551
+  return normalize == SAF_NORM_L2_CLAMP ? 1.0f / fmaxf(sqrtf(ss), 0.1f) : (normalize ? (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f) : 1.0f);
+}
+
+template <int EPI, int TILES, bool CS>
+__device__ __forceinline__ void scan_epilogue(const f32x16 (&acc)[TILES], float inv, int rexp, const int (&cexp)[TILES], int64_t tile,
+                                              int64_t n_rows, int L, float scale, const float (&wl)[TILES],
+                                              float* __restrict__ out, float* __restrict__ out_last, int64_t out_stride,
+                                              int out_col0, float* __restrict__ stage = nullptr) {
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  // `stage` (this wave's 8 x L floats of LDS, or null): the [N, L] matrix leaves as whole 16-byte pieces of 8 rows at a time --
+  // registers 4j .. 4j + 3 hold rows 8j .. 8j + 7 of the tile, 32 L contiguous bytes of the output -- instead of a row's 32
+  // columns per store, which for L = 63 begin at every 4-byte phase of a line (raw scores, L = 63: 4.21 -> 4.02 ms per 2^23 rows;
+  // softmax / surgery: no change, their stores hide in the epilogue).  Full tiles only.
+  const bool staged = stage != nullptr && (tile + 1) * 32 <= n_rows;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int mi = (i & 3) + 8 * (i >> 2) + 4 * h;  // row of accumulator register i in this half
+    const float inv_i = __shfl(inv, mi);
+    const int rexp_i = CS ? __shfl(rexp, mi) : 0;
+    const int64_t r = tile * 32 + mi;
+    float val[TILES];
+    bool ok[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      ok[t] = (m + 32 * t) < L;
+      val[t] = acc[t][i] * inv_i;  // cosine score S[r][n]
+      if (CS) val[t] = ldexpf(val[t], -(rexp_i + cexp[t]));
+    }
+    if (EPI == SAF_Q_SOFTMAX) {
+      // relevance = (100 * img_feats @ text.T).softmax(-1)            clipfusion.py:902-903
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) mx = fmaxf(mx, ok[t] ? scale * val[t] : -INFINITY);
+      mx = half_max(mx);
+      float e[TILES], sum = 0.0f;
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        e[t] = ok[t] ? expf(scale * val[t] - mx) : 0.0f;
+        sum += e[t];
+      }
+      sum = half_sum(sum);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) val[t] = e[t] / sum;
+    } else if (EPI == SAF_Q_SURGERY) {
+      // similarity = S*w - mean_t(S*w)                                 clipfusion.py:924-932
+      float part = 0.0f;
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        val[t] = ok[t] ? val[t] * wl[t] : 0.0f;
+        part += val[t];
+      }
+      const float mean = half_sum(part) / (float)L;
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) val[t] -= mean;
+    } else {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) val[t] = val[t] * scale * wl[t];  // (weights: a block of a wide surgery scan; else 1)
+    }
+    if (r < n_rows) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        if (ok[t]) {
+          if (staged) stage[((i & 3) + 4 * h) * L + m + 32 * t] = val[t];
+          else if (out) out[r * out_stride + out_col0 + m + 32 * t] = val[t];
+          if (out_last && m + 32 * t == L - 1) out_last[r] = val[t];
+        }
+      }
+    }
+    if (staged && (i & 3) == 3) {  // (wave-uniform)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float4* dst = reinterpret_cast<float4*>(out + (tile * 32 + 8 * (i >> 2)) * (int64_t)L);
+      for (int q = lane; q < 2 * L; q += 64) dst[q] = reinterpret_cast<const float4*>(stage)[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
 
 // TH threads per workgroup: 256, or 512 where the text tiles leave room for only ONE workgroup per CU (two 32-row tiles at D = 512:
 // 132 KB) -- four waves would be one per SIMD, each alone with its loads, LDS reads and MFMA chain: the L = 63 surgery scan over
@@ -231,7 +317,8 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
                                                                 int64_t fstride, int D, const float* __restrict__ text,
                                                                 int L, int64_t tstride, float scale, int normalize,
                                                                 const float* __restrict__ wts, float* __restrict__ out,
-                                                                float* __restrict__ out_last, int64_t out_stride, int out_col0) {
+                                                                float* __restrict__ out_last, int64_t out_stride, int out_col0,
+                                                                int /*stage_on: the split scan's*/) {
   // (out_stride / out_col0: where this launch's L columns lie in the output row -- L and 0, or one 64-label block of a wider row)
   extern __shared__ __attribute__((aligned(16))) float s_text[];  // [TILES*32][D + 4], rows >= L are zero
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -242,6 +329,9 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
   }
   __syncthreads();
   const int m = lane & 31, h = lane >> 5;
+  float wl[TILES];  // this lane's columns' weights (surgery; 1 without): read once, not per row (a load in the epilogue waits for
+#pragma unroll      // every row load in flight before it)
+  for (int t = 0; t < TILES; ++t) wl[t] = wts && m + 32 * t < L ? wts[m + 32 * t] : 1.0f;
   const int n_groups = D / (8 * kQGroup);  // full prefetch groups; the remainder is handled chunk by chunk
   const int64_t n_tiles = (n_rows + 31) / 32;
   for (int64_t tile = (int64_t)blockIdx.x * (TH / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (TH / 64)) {
@@ -312,97 +402,267 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
       }
     }
-    // ---- epilogue on the accumulator layout: this lane holds column n = m (+32 t) of 16 rows
     ss += __shfl_xor(ss, 32);  // both halves of row m
-    // clip_feat /= norm ; nan_to_num: an all-zero row gives zeros       clip_seem_fusion.py:508-511
-    // SAF_NORM_L2_CLAMP: norm.clamp_min(0.1)                            eval_scannet_segmentation.py:549-551
-    const float inv = normalize == SAF_NORM_L2_CLAMP ? 1.0f / fmaxf(sqrtf(ss), 0.1f)
-                                                     : (normalize ? (ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f) : 1.0f);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int mi = (i & 3) + 8 * (i >> 2) + 4 * h;  // row of accumulator register i in this half
-      const float inv_i = __shfl(inv, mi);
-      const int64_t r = tile * 32 + mi;
-      float val[TILES];
-      bool ok[TILES];
-#pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        ok[t] = (m + 32 * t) < L;
-        val[t] = acc[t][i] * inv_i;  // cosine score S[r][n]
-      }
-      if (EPI == SAF_Q_SOFTMAX) {
-        // relevance = (100 * img_feats @ text.T).softmax(-1)            clipfusion.py:902-903
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) mx = fmaxf(mx, ok[t] ? scale * val[t] : -INFINITY);
-        mx = half_max(mx);
-        float e[TILES], sum = 0.0f;
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-          e[t] = ok[t] ? expf(scale * val[t] - mx) : 0.0f;
-          sum += e[t];
-        }
-        sum = half_sum(sum);
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) val[t] = e[t] / sum;
-      } else if (EPI == SAF_Q_SURGERY) {
-        // similarity = S*w - mean_t(S*w)                                 clipfusion.py:924-932
-        float part = 0.0f;
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-          val[t] = ok[t] ? val[t] * wts[m + 32 * t] : 0.0f;
-          part += val[t];
-        }
-        const float mean = half_sum(part) / (float)L;
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) val[t] -= mean;
-      } else {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) val[t] = wts && ok[t] ? val[t] * scale * wts[m + 32 * t] : val[t] * scale;  // (wts: a block of a wide surgery scan)
-      }
-      if (r < n_rows) {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-          if (ok[t]) {
-            if (out) out[r * out_stride + out_col0 + m + 32 * t] = val[t];
-            if (out_last && m + 32 * t == L - 1) out_last[r] = val[t];
-          }
-        }
-      }
-    }
+    const int none[TILES] = {};
+    scan_epilogue<EPI, TILES, false>(acc, row_inverse(ss, normalize), 0, none, tile, n_rows, L, scale, wl, out, out_last, out_stride, out_col0);
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split scan (round 6; feat_dim % 16 == 0, n_text <= 64): the same scan with every fp32 operand cut into two fp16 pieces,
+// x * 2^e = hi + lo (hi = fp16(x 2^e), lo = fp16(x 2^e - hi): 22 significant bits between them), and the dot products taken as
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 3 x 32 cycles per 16 k and 32 x 32 outputs where
+// v_mfma_f32_32x32x2_f32 takes 8 x 64: the L = 63 scan over an fp32 volume stops being bound by the fp32 matrix rate (9.65 ms of
+// MFMAs at 256^3 x 512) and becomes what it should be, a stream of the volume.  What is dropped is lo.lo and the
+// pieces' rounding: <= 3 x 2^-22 of sum_k |a_k b_k| per score -- the size of the differences between two fp32 summation orders
+// of 512 terms -- against the 1e-4 the scores are held to.
+//   * Text rows: scaled per label by the power of two that brings the label's largest magnitude into [2^13, 2^14), cut once into
+//     LDS in the order the lanes read them (a lane's 8 + 8 halfs of a k-step are 32 contiguous bytes), the scale undone per
+//     column in the epilogue.
+//   * Feature rows: a row's scale follows its running maximum like the running maximum of an online softmax: it is set from the
+//     first 64 features that are not all zero (largest magnitude into [2^13, 2^14)) and, should a later group of 64 exceed 2^15
+//     under it, lowered, the row's accumulators multiplied by the same power of two (exact).  No value overflows fp16, none
+//     that matters falls below its normal range (a feature 2^-16 of the row's largest still has its hi piece whole), and a row
+//     of any magnitude fp32 holds is scanned like any other.  Row norms come from the unscaled fp32 values as before.
+// Same loads, same register ring, same epilogue as the fp32 MFMA scan above (SAF_Q_SPLIT=0 selects that one).  Measured at
+// 256^3 x 512 fp32 (profiles/r06/split_scan_ab.txt): L = 63 surgery 10.95 -> 7.6 ms (round 5: 12.2), L = 5 softmax 6.9 -> 6.3.
+// ------------------------------------------------------------------------------------------
+#ifndef SAF_QS_ABL
+#define SAF_QS_ABL 0
+#endif
+#ifndef SAF_QS_STAGE
+#define SAF_QS_STAGE 1  // 0: the score matrix stored a row's 32 columns at a time (A/B)
+#endif
+#ifndef SAF_QS_CHAIN
+#define SAF_QS_CHAIN 0  // 1: the ring runs on from tile to tile (measured: no gain, profiles/r06/split_scan_ab.txt)
+#endif
+typedef _Float16 h8x __attribute__((ext_vector_type(8)));
+typedef _Float16 h2x __attribute__((ext_vector_type(2)));
+
+// the exponent e that brings a largest magnitude `mx` (finite, > 0; denormals too) into [2^13, 2^14) as mx * 2^e
+__device__ __forceinline__ int split_exponent(float mx) {
+  int ex;
+  (void)frexpf(mx, &ex);  // mx = f * 2^ex, 0.5 <= f < 1
+  return 14 - ex;
+}
+__device__ __forceinline__ void split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
+  const h2x hv = {(_Float16)y0, (_Float16)y1};
+  const h2x lv = {(_Float16)(y0 - (float)hv.x), (_Float16)(y1 - (float)hv.y)};
+  hi = __builtin_bit_cast(uint32_t, hv);
+  lo = __builtin_bit_cast(uint32_t, lv);
+}
+
 template <int EPI, int FT, int TILES, int TH>
+__global__ __launch_bounds__(TH) void query_split_kernel(const void* __restrict__ feats, int64_t n_rows, int64_t fstride, int D,
+                                                         const float* __restrict__ text, int L, int64_t tstride, float scale,
+                                                         int normalize, const float* __restrict__ wts, float* __restrict__ out,
+                                                         float* __restrict__ out_last, int64_t out_stride, int out_col0,
+                                                         int stage_on) {
+  // [TILES*32] label rows of D/16 k-steps x {half 0, half 1} x {hi, lo} x 8 halfs (+16 bytes: the rows' reads fall on different
+  // banks), then the labels' scale exponents
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_split[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rs_bytes = 4 * D + 16;
+  int* s_ce = reinterpret_cast<int*>(s_split + (size_t)TILES * 32 * rs_bytes);
+  float* stage = stage_on ? reinterpret_cast<float*>(s_ce + TILES * 32) + (size_t)wave * (TILES * 256) : nullptr;  // 8 rows x <= 32 TILES floats
+  for (int n = wave; n < TILES * 32; n += TH / 64) {
+    float mx = 0.0f;
+    if (n < L)
+      for (int k = lane; k < D; k += 64) mx = fmaxf(mx, fabsf(text[(int64_t)n * tstride + k]));
+    mx = wave_max(mx);
+    const int be = mx > 0.0f && mx < INFINITY ? split_exponent(mx) : 0;
+    if (lane == 0) s_ce[n] = be;
+    for (int k = lane; k < D; k += 64) {
+      const float y = n < L ? ldexpf(text[(int64_t)n * tstride + k], be) : 0.0f;
+      const _Float16 hi = (_Float16)y, lo = (_Float16)(y - (float)hi);
+      const int p = k >> 4, u = (k >> 3) & 1, hh = (k >> 2) & 1, j = k & 3;
+      _Float16* dst = reinterpret_cast<_Float16*>(s_split + (size_t)n * rs_bytes + p * 64 + hh * 32) + 4 * u + j;
+      dst[0] = hi;
+      dst[8] = lo;
+    }
+  }
+  __syncthreads();
+  const int m = lane & 31, h = lane >> 5;
+  float wl[TILES];  // this lane's columns' weights (surgery; 1 without): read once, not per row (a load in the epilogue waits for
+#pragma unroll      // every row load in flight before it)
+  for (int t = 0; t < TILES; ++t) wl[t] = wts && m + 32 * t < L ? wts[m + 32 * t] : 1.0f;
+  int ce[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) ce[t] = s_ce[m + 32 * t];
+  const int n_groups = D / (8 * kQGroup);  // full prefetch groups; the remainder is handled pair by pair
+  const int64_t n_tiles = (n_rows + 31) / 32;
+  const unsigned char* tb = s_split + (size_t)m * rs_bytes + h * 32;
+  // SAF_QS_CHAIN=1 (off: measured, no gain -- the CU's other seven waves cover a tile's first latency): where the groups of a row
+  // fill the ring a whole number of times the ring runs on from tile to tile, a tile's last groups and its epilogue with the
+  // first groups of the wave's NEXT tile in flight.
+  const bool chain = SAF_QS_CHAIN && n_groups >= kQSlots && n_groups % kQSlots == 0;
+  const int64_t tile0 = (int64_t)blockIdx.x * (TH / 64) + wave, tile_step = (int64_t)gridDim.x * (TH / 64);
+  auto row_base = [&](int64_t tile) {
+    int64_t row = tile * 32 + m;
+    if (row >= n_rows) row = n_rows - 1;  // padded lanes recompute the last row, never stored
+    return row * fstride + 4 * h;
+  };
+  float4 ring[kQSlots][kQGroup];
+  if (chain && tile0 < n_tiles) {
+    const int64_t base = row_base(tile0);
+#pragma unroll
+    for (int sl = 0; sl + 1 < kQSlots; ++sl)
+#pragma unroll
+      for (int q = 0; q < kQGroup; ++q) ring[sl][q] = load_row4<FT>(feats, base + 8 * (sl * kQGroup + q));
+  }
+  for (int64_t tile = tile0; tile < n_tiles; tile += tile_step) {
+    const int64_t base = row_base(tile);
+    const int64_t base_next = row_base(tile + tile_step < n_tiles ? tile + tile_step : tile);  // (behind the last tile: loads nobody uses)
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    float ss = 0.0f;
+    int re = 0;         // the row's scale is 2^re (applied by v_ldexp_f32: any exponent, denormal features included)
+    bool seen = false;  // a feature of the row was not zero
+    // a group's largest magnitude `gm` (this half's part) against the row's scale, before the group is cut
+    auto fit = [&](float gm) {
+      gm = fmaxf(gm, __shfl_xor(gm, 32));
+      const bool need = ldexpf(gm, re) >= 32768.0f || (!seen && gm > 0.0f);
+      if (__builtin_amdgcn_ballot_w64(need)) {
+        const int ne = need ? (gm < INFINITY ? split_exponent(gm) : 0) : re;
+        const float fac = need && seen ? ldexpf(1.0f, ne - re) : 1.0f;  // (0 once the row has grown by more than fp32's range)
+        re = ne;
+        seen = seen || gm > 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float f = __shfl(fac, (i & 3) + 8 * (i >> 2) + 4 * h);
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) acc[t][i] *= f;
+        }
+      }
+    };
+    // one k-step: chunks 2p and 2p + 1 of the lane's row (k = 16p + 8u + 4h + j)
+    auto step = [&](const float4& a0, const float4& a1, int p) {
+      ss = __builtin_fmaf(a0.x, a0.x, ss);
+      ss = __builtin_fmaf(a0.y, a0.y, ss);
+      ss = __builtin_fmaf(a0.z, a0.z, ss);
+      ss = __builtin_fmaf(a0.w, a0.w, ss);
+      ss = __builtin_fmaf(a1.x, a1.x, ss);
+      ss = __builtin_fmaf(a1.y, a1.y, ss);
+      ss = __builtin_fmaf(a1.z, a1.z, ss);
+      ss = __builtin_fmaf(a1.w, a1.w, ss);
+      uint4 hi, lo;
+#if SAF_QS_ABL & 2  // (development, WRONG results: the features' bits as they are)
+      hi = make_uint4(__builtin_bit_cast(uint32_t, a0.x), __builtin_bit_cast(uint32_t, a0.y), __builtin_bit_cast(uint32_t, a0.z), __builtin_bit_cast(uint32_t, a0.w));
+      lo = make_uint4(__builtin_bit_cast(uint32_t, a1.x), __builtin_bit_cast(uint32_t, a1.y), __builtin_bit_cast(uint32_t, a1.z), __builtin_bit_cast(uint32_t, a1.w));
+#else
+      split2(ldexpf(a0.x, re), ldexpf(a0.y, re), hi.x, lo.x);
+      split2(ldexpf(a0.z, re), ldexpf(a0.w, re), hi.y, lo.y);
+      split2(ldexpf(a1.x, re), ldexpf(a1.y, re), hi.z, lo.z);
+      split2(ldexpf(a1.z, re), ldexpf(a1.w, re), hi.w, lo.w);
+#endif
+      const h8x ah = __builtin_bit_cast(h8x, hi), al = __builtin_bit_cast(h8x, lo);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        const uint4* bp = reinterpret_cast<const uint4*>(tb + (size_t)t * 32 * rs_bytes + p * 64);
+        const uint4 bc[2] = {bp[0], bp[1]};
+        const h8x bh = __builtin_bit_cast(h8x, bc[0]), bl = __builtin_bit_cast(h8x, bc[1]);
+#if SAF_QS_ABL & 1  // (development, WRONG results: no MFMAs, the pieces kept alive by four integer operations)
+        acc[t][0] += __builtin_bit_cast(float, (hi.x ^ lo.y ^ bc[0].x) & 0x3fffffffu);
+        acc[t][1] += __builtin_bit_cast(float, (hi.z ^ lo.w ^ bc[1].x) & 0x3fffffffu);
+        acc[t][2] += __builtin_bit_cast(float, (hi.y ^ lo.x ^ hi.w ^ lo.z) & 0x3fffffffu);
+#else
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+#endif
+      }
+    };
+    if (!chain) {
+#pragma unroll
+      for (int sl = 0; sl + 1 < kQSlots; ++sl) {
+        if (sl < n_groups) {
+#pragma unroll
+          for (int q = 0; q < kQGroup; ++q) ring[sl][q] = load_row4<FT>(feats, base + 8 * (sl * kQGroup + q));
+        }
+      }
+    }
+    for (int g0 = 0; g0 < n_groups; g0 += kQSlots) {
+#pragma unroll
+      for (int sl = 0; sl < kQSlots; ++sl) {
+        const int g = g0 + sl;
+        if (g >= n_groups) break;
+        const int gl = g + kQSlots - 1;
+        if (gl < n_groups || chain) {
+          const int64_t from = gl < n_groups ? base + 8 * (gl * kQGroup) : base_next + 8 * ((gl - n_groups) * kQGroup);
+#pragma unroll
+          for (int q = 0; q < kQGroup; ++q) ring[(sl + kQSlots - 1) % kQSlots][q] = load_row4<FT>(feats, from + 8 * q);
+        }
+        float gm = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kQGroup; ++q) {
+          const float4 a = ring[sl][q];
+          gm = fmaxf(fmaxf(gm, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+        }
+        fit(gm);
+#pragma unroll
+        for (int q = 0; q < kQGroup; q += 2) step(ring[sl][q], ring[sl][q + 1], (g * kQGroup + q) >> 1);
+      }
+    }
+    for (int k0 = 8 * kQGroup * n_groups; k0 < D; k0 += 16) {  // D not a multiple of 64
+      const float4 a0 = load_feat4<FT>(feats, base + k0), a1 = load_feat4<FT>(feats, base + k0 + 8);
+      fit(fmaxf(fmaxf(fmaxf(fabsf(a0.x), fabsf(a0.y)), fmaxf(fabsf(a0.z), fabsf(a0.w))),
+               fmaxf(fmaxf(fabsf(a1.x), fabsf(a1.y)), fmaxf(fabsf(a1.z), fabsf(a1.w)))));
+      step(a0, a1, k0 >> 4);
+    }
+    ss += __shfl_xor(ss, 32);  // both halves of row m
+    scan_epilogue<EPI, TILES, true>(acc, row_inverse(ss, normalize), re, ce, tile, n_rows, L, scale, wl, out, out_last,
+                                    out_stride, out_col0, stage);
+  }
+}
+
+template <int EPI, int FT, int TILES, int TH, bool SPLIT>
 int launch_mfma_th(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
                    float scale, int normalize, const float* wts, float* out, float* out_last, int per_cu, size_t shmem, hipStream_t s,
                    int64_t out_stride, int out_col0) {
-  auto fn = query_mfma_kernel<EPI, FT, TILES, TH>;
-  if (shmem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)shmem);
-    if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  }
+  auto fn = SPLIT ? query_split_kernel<EPI, FT, TILES, TH> : query_mfma_kernel<EPI, FT, TILES, TH>;
   constexpr int kWavesTh = TH / 64;
   int64_t blocks = ((n_rows + 31) / 32 + kWavesTh - 1) / kWavesTh;
   const int64_t cap = (int64_t)device_cus() * (per_cu < 1 ? 1 : per_cu);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+  // the split scan's staged stores: a whole [N, L] matrix on a 16-byte boundary, and 8 x 32 TILES floats of LDS per wave to spare
+  const size_t stage_bytes = (size_t)kWavesTh * TILES * 256 * sizeof(float);
+  const bool stage = SPLIT && SAF_QS_STAGE && out && (out_stride <= 0 || out_stride == L) && out_col0 == 0 && ((uintptr_t)out & 15) == 0 &&
+                     shmem + stage_bytes <= 159 * 1024 && (160 * 1024) / (shmem + stage_bytes + 256) >= (size_t)(per_cu < 1 ? 1 : per_cu);
+  if (stage) shmem += stage_bytes;
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)shmem);
+    if (e != hipSuccess) return fail(SAF_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(TH), shmem, s, feats, n_rows, fstride, D, text, L,
-                     tstride, scale, normalize, wts, out, out_last, out_stride > 0 ? out_stride : (int64_t)L, out_col0);
-  return check_launch("query_mfma_kernel");
+                     tstride, scale, normalize, wts, out, out_last, out_stride > 0 ? out_stride : (int64_t)L, out_col0, stage ? 1 : 0);
+  return check_launch(SPLIT ? "query_split_kernel" : "query_mfma_kernel");
+}
+
+// SAF_Q_SPLIT (read per call): 0 = the fp32 MFMA scan for every shape (development / A-B); default: the split scan where it applies
+inline bool split_wanted(int D) {
+  const char* e = getenv("SAF_Q_SPLIT");
+  return D % 16 == 0 && !(e && atoi(e) == 0);
 }
 
 template <int EPI, int FT, int TILES>
 int launch_mfma_t(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
                   float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s, int64_t out_stride, int out_col0) {
-  const size_t shmem = (size_t)TILES * 32 * (D + 4) * sizeof(float);
+  const bool split = split_wanted(D);
+  // (the split scan's label rows take the bytes of the fp32 rows -- two fp16 pieces per value -- plus a scale per label)
+  const size_t shmem = (size_t)TILES * 32 * (D + 4) * sizeof(float) + (split ? (size_t)TILES * 32 * sizeof(float) : 0);
   const int per_cu = (int)((160 * 1024) / (shmem + 256)) > 2 ? 2 : (int)((160 * 1024) / (shmem + 256));
   // SAF_Q_THREADS (read per call; development): 256 or 512 threads per workgroup whatever the tiles leave room for
   const char* th_env = getenv("SAF_Q_THREADS");
   const bool wide = th_env ? atoi(th_env) == 512 : per_cu <= 1;
-  return wide ? launch_mfma_th<EPI, FT, TILES, 512>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s, out_stride, out_col0)
-              : launch_mfma_th<EPI, FT, TILES, 256>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s, out_stride, out_col0);
+#define SAF_Q_GO(TH, SP) launch_mfma_th<EPI, FT, TILES, TH, SP>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s, out_stride, out_col0)
+  if (split) return wide ? SAF_Q_GO(512, true) : SAF_Q_GO(256, true);
+  return wide ? SAF_Q_GO(512, false) : SAF_Q_GO(256, false);
+#undef SAF_Q_GO
 }
 
 // true if the MFMA scan can take this shape
@@ -410,7 +670,7 @@ inline bool mfma_ok(int ft, int64_t fstride, int D, int L, const void* feats) {
   const int esz = ft == SAF_F32 ? 4 : 2;
   if (D % 8 != 0 || L > 64) return false;  // (L > 64 with an [N, L] output: launch_mfma_blocks, 64 labels at a time)
   if (((uintptr_t)feats & 15) || (fstride * esz) % (4 * esz) != 0 || (fstride % 4) != 0) return false;
-  const size_t shmem = (size_t)(L > 32 ? 2 : 1) * 32 * (D + 4) * sizeof(float);
+  const size_t shmem = (size_t)(L > 32 ? 2 : 1) * 32 * (D + 5) * sizeof(float);  // (+ the split scan's scale per label)
   return shmem <= 150 * 1024;
 }
 

@@ -1,0 +1,160 @@
+"""The split scan (saf_query.hip, query_split_kernel): fp32 text-query scores out of fp16 matrix instructions.
+
+Every fp32 operand is cut into two fp16 pieces under a power-of-two scale (the rows' scale follows their running maximum), the dot
+products are hi.hi + hi.lo + lo.hi with fp32 accumulation.  What the cut drops is bounded by 3 x 2^-22 of sum_k |a_k b_k| per
+score; these tests hold it to 4 x 2^-22 of that sum (+ the fp32 accumulation's own rounding) against a float64 scan -- on ordinary
+CLIP-like rows and on rows built to break a fixed scale: magnitudes from 1e-30 to 1e30, late spikes, leading zeros, denormals.
+Reference semantics: clipfusion.py:899-934, clip_seem_fusion.py:507-511 (the oracle's query_scan restates them)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from spatially_aware_ai_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+CUT = 4.0 * 2.0 ** -22   # the pieces' rounding + the dropped lo.lo term, relative to sum |a b|
+ACC = 3.0e-7              # fp32 accumulation over <= 512 terms on ordinary rows (what the exact-fp32 chain shows against float64)
+ACC_WORST = 96 * 2.0 ** -24  # its worst case: one term dominates and each of a row's 96 matrix instructions rounds the running
+                             # sum once (the fp32 chain this replaces rounds it 512 times: 512 x 2^-24)
+
+
+def _scan(feats, text, epi=_abi.SAF_Q_SCORES, scale=1.0, normalize=False):
+    from spatially_aware_ai_amd.clipfusion import _query_scan
+    return _query_scan(feats, text, epi, scale=scale, normalize=normalize)
+
+
+def _raw_bound(f64, t64):
+    """per (row, label): sum_k |a_k b_k| in float64"""
+    return np.abs(f64) @ np.abs(t64).T
+
+
+def _check_raw(feats, text, what, acc=ACC):
+    """raw scores (no normalisation): the split scan against float64, error relative to sum |a b|"""
+    got = _scan(feats.cuda(), text.cuda()).double().cpu().numpy()
+    f64, t64 = feats.float().double().numpy(), text.double().numpy()
+    want = f64 @ t64.T
+    mag = _raw_bound(f64, t64)
+    bound = mag * (CUT + acc)
+    err = np.abs(got - want)
+    bad = (err > bound + 1e-44) & (mag < 1e37)   # (beyond: the score itself may leave fp32's range)
+    if bad.any():
+        r, c = np.argwhere(bad)[0]
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.size} scores off by more than the cut allows; first at row {r}, "
+                             f"label {c}: got {got[r, c]!r}, float64 {want[r, c]!r}, sum |a b| {mag[r, c]!r}")
+    ok = (mag < 1e37) & (mag > 1e-30)
+    return float((err[ok] / mag[ok]).max())
+
+
+@pytest.mark.parametrize("nl", [5, 33, 63, 64])
+def test_split_scan_is_fp32_faithful(nl):
+    n, d = 6007, 512
+    g = torch.Generator().manual_seed(100 + nl)
+    feats = torch.nn.functional.normalize(torch.randn((n, d), generator=g), dim=-1) * (0.2 + torch.rand((n, 1), generator=g))
+    text = torch.nn.functional.normalize(torch.randn((nl, d), generator=g), dim=-1)
+    worst = _check_raw(feats, text, f"{nl} labels")
+    # and not worse than twice the fp32 matrix instructions' own distance from float64 + the cut
+    os.environ["SAF_Q_SPLIT"] = "0"
+    try:
+        exact = _scan(feats.cuda(), text.cuda()).double().cpu().numpy()
+    finally:
+        del os.environ["SAF_Q_SPLIT"]
+    f64, t64 = feats.double().numpy(), text.double().numpy()
+    exact_err = float((np.abs(exact - f64 @ t64.T) / _raw_bound(f64, t64)).max())
+    assert worst <= 2.0 * exact_err + CUT, (worst, exact_err)
+
+
+@pytest.mark.parametrize("fdt", [torch.float32, torch.float16, torch.bfloat16])
+def test_split_scan_epilogues_against_oracle(oracle, fdt):
+    """softmax / surgery / scores with the fused normalisation, the three volume dtypes, against the oracle at BASELINE's tolerance"""
+    n, d = 4003, 512
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn((n, d), generator=g)
+    feats[11] = 0.0
+    fd = feats.to(fdt).cuda()
+    fo = fd.float().cpu()
+    for nl in (5, 63):
+        text = torch.nn.functional.normalize(torch.randn((nl, d), generator=g), dim=-1)
+        for epi, scale, norm in ((_abi.SAF_Q_SURGERY, 1.0, True), (_abi.SAF_Q_SOFTMAX, 100.0, True), (_abi.SAF_Q_SCORES, 3.0, True),
+                                 (_abi.SAF_Q_SCORES, 1.0, False)):
+            want = oracle.query_scan(fo, text, epi, scale=scale, normalize=norm)
+            got = _scan(fd, text.cuda(), epi, scale=scale, normalize=norm)
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"epilogue {epi}, {nl} labels, {fdt}")
+
+
+def test_split_scan_rows_of_any_magnitude():
+    """rows and labels that a fixed fp16 scale would overflow or flush: the row scale follows the running maximum"""
+    d, nl = 512, 63
+    g = torch.Generator().manual_seed(9)
+    base = torch.randn((64 * 14, d), generator=g)
+    rows = base.clone().view(14, 64, d)
+    rows[0] *= 1e30
+    rows[1] *= 1e-30
+    rows[2] *= 1e-40                                   # denormal features
+    rows[3, :, 64:] *= 1e5                             # everything behind the first group far larger: one re-scale
+    rows[4] *= torch.logspace(-6, 9, d)[None]          # a steady climb over 15 decades: re-scale after re-scale
+    rows[5, :, :64] = 0.0                              # the scale cannot come from the first group
+    rows[6] = 0.0
+    rows[6, :, -1] = 3.0                               # one feature, the last
+    rows[7] *= torch.logspace(9, -6, d)[None]          # a steady fall: late features far below the scale
+    rows[8, :, 100] = 6.0e4                            # a spike above fp16's largest finite value x the scale
+    rows[9] *= (10.0 ** torch.randint(-20, 20, (64, 1), generator=g).float())  # every row of a tile at another magnitude
+    rows[10, :, ::2] = 0.0
+    rows[11] = rows[11].abs() * 1e-3 + 1.0             # no cancellation, tiny variation around a constant
+    rows[12, :, 448:] *= 1e12                          # the last group only
+    rows[13] *= 65504.0
+    feats = rows.view(-1, d)
+    text = torch.randn((nl, d), generator=g)
+    text[0] *= 1e20
+    text[1] *= 1e-20
+    text[2] = 0.0
+    text[3, 5:] = 0.0
+    text[4] *= 1e-40
+    finite = _check_raw(feats, text, "magnitudes", acc=ACC_WORST)
+    assert np.isfinite(finite)
+    # normalised scores of the same rows: cosine values, so the bound is relative to |a| |b|-sized sums again
+    keep = torch.ones(14, dtype=torch.bool)
+    keep[[0, 1, 2, 9]] = False                         # (their sums of squares leave fp32's range, in the reference too)
+    f = rows[keep].view(-1, d)
+    t = torch.nn.functional.normalize(torch.randn((nl, d), generator=g), dim=-1)
+    got = _scan(f.cuda(), t.cuda(), normalize=True).double().cpu().numpy()
+    f64 = f.double().numpy()
+    norm = np.sqrt((f64 * f64).sum(-1, keepdims=True))
+    want = (f64 / norm) @ t.double().numpy().T
+    bound = (np.abs(f64) / norm) @ np.abs(t.double().numpy()).T * (CUT + ACC_WORST)
+    assert (np.abs(got - want) <= bound).all(), float((np.abs(got - want) / bound).max())
+
+
+@pytest.mark.parametrize("d", [16, 48, 80, 528, 1024])
+def test_split_scan_other_widths(d):
+    """feat_dim a multiple of 16 but not of 64: the pairs behind the last full group; no full group at all"""
+    n, nl = 1000, 37
+    g = torch.Generator().manual_seed(d)
+    feats = torch.randn((n, d), generator=g)
+    feats[:, d // 2:] *= 300.0
+    text = torch.randn((nl, d), generator=g)
+    _check_raw(feats, text, f"D = {d}")
+
+
+def test_split_scan_strided_rows_and_non_finite():
+    """a row stride wider than feat_dim (a view of a wider volume), and non-finite features: the row's scores are non-finite, its
+    neighbours' are untouched"""
+    n, d, nl = 777, 512, 20
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn((n, d + 64), generator=g).cuda()
+    text = torch.randn((nl, d), generator=g)
+    view = wide[:, :d]
+    assert not view.is_contiguous()
+    got = _scan(view, text.cuda()).double().cpu().numpy()
+    f64, t64 = view.double().cpu().numpy(), text.double().numpy()
+    assert (np.abs(got - f64 @ t64.T) <= _raw_bound(f64, t64) * (CUT + ACC)).all()
+    bad = view.clone().contiguous()
+    bad[5, 17] = float("inf")
+    bad[40, 300] = float("nan")
+    got_b = _scan(bad, text.cuda()).cpu().numpy()
+    assert not np.isfinite(got_b[5]).any() and not np.isfinite(got_b[40]).any()
+    ok = np.ones(n, dtype=bool)
+    ok[[5, 40]] = False
+    np.testing.assert_array_equal(got_b[ok], got.astype(np.float32)[ok])
