@@ -1355,8 +1355,17 @@ def bench_query(a, world, rank, local_rank):
             mf = {"achieved": round(flop_issued / kern / 1e12, 1), "peak": mpeak, "unit": "TFLOP/s",
                   "frac": round(flop_issued / kern / 1e12 / mpeak, 4)}
             bound = "mfma" if t_mfma > t_hbm else "hbm"  # the larger of the two floors names the bound
+            traffic, traffic_source = None, None
+            try:  # counter traffic of the same scan at the full size: tools/r06_split_traffic.sh (two profiler passes)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r06", "split_scan_traffic.json")))
+                if split and n == 1 << 24 and d == 512:
+                    traffic = tj["L5_softmax_last" if nl == 5 else "L63_surgery"]["hbm_bytes_per_launch"]
+                    traffic_source = "profiles/r06/split_scan_traffic.json (this round, another box): " + tj["method"]
+            except (OSError, KeyError, ValueError):
+                pass
             cases.append({"case": name, "ms": round(wall * 1e3, 3), "rows_this_rank": n, "queries": nl,
-                          "roofline": dict(mf if bound == "mfma" else hbm, bound=bound, traffic=None, avg_launch_us=round(kern * 1e6, 1),
+                          "roofline": dict(mf if bound == "mfma" else hbm, bound=bound, traffic=traffic, traffic_source=traffic_source,
+                                           avg_launch_us=round(kern * 1e6, 1),
                                            kernel="query_split_kernel" if split else "query_mfma_kernel",
                                            algorithmic_bytes_per_launch=int(nbytes), issued_mfma_flop_per_launch=int(flop_issued),
                                            floors_ms={"hbm": round(t_hbm * 1e3, 2), ("fp16_mfma_x3" if split else "fp32_mfma"): round(t_mfma * 1e3, 2)},

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The reference's own scans over the fp32 volume (query_mfma_kernel: L = 5 softmax, query_mesh.py:36-39; L = 63 surgery,
+"""The reference's own scans over the fp32 volume (query_split_kernel, or query_mfma_kernel under SAF_Q_SPLIT=0: L = 5 softmax, query_mesh.py:36-39; L = 63 surgery,
 :52-83) alone, over `rows` x 512 fp32 rows: ms per scan, HBM GB/s of the algorithmic bytes, exact-fp32 TFLOP/s.  For same-box
 A/Bs of library builds through SAF_LIB_PATH (tools/build_variant.sh).  python tools/probe_qmfma.py [rows = 2^23] [L ...]"""
 import sys
