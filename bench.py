@@ -1073,6 +1073,53 @@ def side_workloads(a, device, L, frames_A, npy, npx):
         feats16[s0:s0 + (1 << 20)] = torch.randn((min(1 << 20, n - s0), d), generator=g, device=device).half()
     text = torch.randn((n_bg + q, d), generator=torch.Generator().manual_seed(9))
     text = (text / text.norm(dim=-1, keepdim=True)).to(device)
+    # ---- the reference's own online scans over the fp32 volume (clip_text_query: L = 5 softmax to the last column,
+    #      query_mesh.py:36-39; L = 63 surgery, :52-83): the split scan (round 6) -- fp32 scores from fp16 matrix instructions
+    if d % 16 == 0:
+        from spatially_aware_ai_amd.clipfusion import _query_scan
+        f32 = torch.empty((n, d), dtype=torch.float32, device=device)
+        for s0 in range(0, n, 1 << 20):
+            f32[s0:s0 + (1 << 20)] = torch.randn((min(1 << 20, n - s0), d), generator=g, device=device)
+        split = os.environ.get("SAF_Q_SPLIT", "1") != "0"
+        for name, nl, epi, scale in (("a9_softmax_L5_fp32_volume", 5, _abi.SAF_Q_SOFTMAX, 100.0),
+                                     ("a10_surgery_L63_fp32_volume", 63, _abi.SAF_Q_SURGERY, 1.0)):
+            t = text[:nl]
+            last = epi == _abi.SAF_Q_SOFTMAX
+            hold = {}
+            fn = lambda: hold.__setitem__("o", _query_scan(f32, t, epi, scale=scale, normalize=True, last_only=last))  # noqa: E731
+            fn()
+            fn()  # (two calls: the second still holds the first's [N, L] output, so both of the allocator's blocks exist before the timing)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            fn()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            kern = e0.elapsed_time(e1) * 1e-3 / 3
+            nbytes = n * d * 4 + nl * d * 4 + n * (1 if last else nl) * 4
+            issued = 2.0 * n * d * 32 * ((nl + 31) // 32) * (3 if split else 1)
+            mpeak = MFMA16_PEAK_TFLOPS if split else MFMA32_PEAK_TFLOPS
+            out[name] = {"ms": round(kern * 1e3, 3), "labels": nl,
+                         "workload": f"{nl} text labels over {n} voxel rows x {d} fp32, " + ("softmax, last column" if last else "feature surgery, [N, L] out"),
+                         "roofline": {"kernel": "query_split_kernel" if split else "query_mfma_kernel", "bound": "hbm",
+                                      "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "algorithmic_bytes_per_launch": int(nbytes),
+                                      "floors_ms": {"hbm": round(nbytes / (HBM_PEAK_GBS * 1e9) * 1e3, 2),
+                                                    ("fp16_mfma_x3" if split else "fp32_mfma"): round(issued / (mpeak * 1e12) * 1e3, 2)}}}
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r06", "split_scan_traffic.json")))
+                if split and d == 512:
+                    out[name]["roofline"]["traffic"] = tj["L5_softmax_last" if nl == 5 else "L63_surgery"]["hbm_bytes_per_launch"]
+                    out[name]["roofline"]["traffic_source"] = "profiles/r06/split_scan_traffic.json (this round, another box): " + tj["method"]
+            except Exception:  # noqa: BLE001
+                pass
+            hold.clear()
+        del f32
+        torch.cuda.empty_cache()
+
     big = torch.empty((n, (q + 63) // 64 * 64), dtype=torch.float16, device=device)[:, :q]  # (rows padded to whole 128-byte lines, as query_scan_wide allocates its own output)
 
     def scan_case(name, fn, n_q, out_bytes):
@@ -1424,11 +1471,12 @@ def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value)
     integrate() call, here through integrate_features() (backbone outputs resident).  The deferred window queue
     behind it (clipfusion._FusionVolumeMixin._fuse) copies each call's inputs into a staging ring and fuses 128
     frames at a time on the windowed path; a job = reset + n calls + the final flush, like a bulk step."""
-    n = min(a.api_b1, depth.shape[0])
+    n, nu = a.api_b1, depth.shape[0]  # (more calls than resident frames: the frames again, in order)
 
     def job():
         fusion.reset()
-        for i in range(n):
+        for k in range(n):
+            i = k % nu
             labs = None if label_maps is None else [label_maps[i]]
             fusion.integrate_features(depth[i:i + 1], rgb[i:i + 1], poses[i:i + 1], ks[i:i + 1], feat[i:i + 1], labs)
         fusion.flush()
@@ -1438,7 +1486,8 @@ def bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, bulk_value)
     if os.environ.get("SAF_BENCH_PROFILE_API") == "1":  # development: which calls of the loop block the host?
         ts = []
         fusion.reset()
-        for i in range(n):
+        for k in range(n):
+            i = k % nu
             t = time.perf_counter()
             fusion.integrate_features(depth[i:i + 1], rgb[i:i + 1], poses[i:i + 1], ks[i:i + 1], feat[i:i + 1],
                                       None if label_maps is None else [label_maps[i]])

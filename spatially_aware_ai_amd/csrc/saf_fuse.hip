@@ -870,7 +870,12 @@ PipeRes* pipe_acquire() {
   PipeRes* r = new PipeRes();
   r->device = dev;
   r->next = nullptr;
-  bool ok = hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking) == hipSuccess &&
+  // SAF_CLS_PRIORITY=1 (read when a device's first pipeline is made; development): the classification stream at the device's
+  // highest priority -- its launches run beside the row kernel AND, behind integrate(), beside the staging of later frames
+  int lo_pri = 0, hi_pri = 0;
+  const char* pe = getenv("SAF_CLS_PRIORITY");
+  const bool pri = pe && atoi(pe) != 0 && hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) == hipSuccess;
+  bool ok = (pri ? hipStreamCreateWithPriority(&r->aux, hipStreamNonBlocking, hi_pri) : hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking)) == hipSuccess &&
             hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&r->join, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&r->tiles, hipEventDisableTiming) == hipSuccess;

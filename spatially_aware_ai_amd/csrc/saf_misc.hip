@@ -224,27 +224,47 @@ __global__ __launch_bounds__(256) void sample_vertices_kernel(
 
 // One launch copies a frame's inputs into a slot of the staging ring behind integrate() (depth, rgb, pose, K, feature map,
 // label map): six tiny copy launches per frame would be most of the host's work per call and fill the stream's queue.
+// Round 6: a flat grid sized to the bytes (a workgroup = 256 lanes x 4 x 16 bytes of ONE segment) instead of 450 x 6 workgroups
+// of 4-byte copies, most of which found nothing to do: the ring's staging runs BESIDE the window's row kernel and the next
+// window's classification, and 2 700 workgroups per frame took the wave slots the classification lives in (its launches beside
+// 96 staging kernels: 7.2 ms each, without: 5.1 -- profiles/r06/api_steady_state.txt).
 struct StageArgs {
   const float* src[6];
   float* dst[6];
   int n[6];
+  int first_block[7];  // segment k owns workgroups [first_block[k], first_block[k + 1])
   // the feature map may be a permuted view ([D, npy, npx] element strides); everything else is contiguous
   int64_t fs0, fs1, fs2;
   int f1, f2;
 };
+constexpr int kStageUnroll = 4;  // 16-byte pieces per lane
 __global__ __launch_bounds__(256) void stage_frame_kernel(StageArgs a) {
-  const int seg = blockIdx.y;
+  int seg = 0;
+#pragma unroll
+  for (int k = 1; k < 6; ++k) seg += (int)blockIdx.x >= a.first_block[k];
   const int n = a.n[seg];
   const float* __restrict__ src = a.src[seg];
   float* __restrict__ dst = a.dst[seg];
-  if (!src) return;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    if (seg == 4) {
+  const int blk = blockIdx.x - a.first_block[seg];
+  if (seg == 4) {  // (a strided gather; 4 elements per lane and workgroup step as for the copies)
+    for (int i = blk * 256 * 4 * kStageUnroll + threadIdx.x, e = min(n, (blk + 1) * 256 * 4 * kStageUnroll); i < e; i += 256) {
       const int x = i % a.f2, y = (i / a.f2) % a.f1, c = i / (a.f2 * a.f1);
       dst[i] = src[(int64_t)c * a.fs0 + (int64_t)y * a.fs1 + (int64_t)x * a.fs2];
-    } else {
-      dst[i] = src[i];
     }
+    return;
+  }
+  const int i0 = blk * 256 * 4 * kStageUnroll;  // this workgroup's first element
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && i0 + 256 * 4 * kStageUnroll <= n) {
+    typedef float st_f4 __attribute__((ext_vector_type(4)));
+    const st_f4* s4 = reinterpret_cast<const st_f4*>(src + i0);
+    st_f4* d4 = reinterpret_cast<st_f4*>(dst + i0);
+    st_f4 v[kStageUnroll];
+#pragma unroll
+    for (int u = 0; u < kStageUnroll; ++u) v[u] = s4[u * 256 + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < kStageUnroll; ++u) d4[u * 256 + threadIdx.x] = v[u];
+  } else {  // a segment's last workgroup, pose / K, or rows that do not lie on 16-byte boundaries
+    for (int i = i0 + threadIdx.x, e = min(n, i0 + 256 * 4 * kStageUnroll); i < e; i += 256) dst[i] = src[i];
   }
 }
 
@@ -477,8 +497,13 @@ int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_st
   const int n[6] = {hw, 3 * hw, 16, 9, src->feat_map ? feat_channels * src->npy * src->npx : 0, src->label_map ? hw : 0};
   for (int k = 0; k < 6; ++k) { a.src[k] = s[k]; a.dst[k] = d[k]; a.n[k] = n[k]; }
   a.fs0 = feat_stride_c; a.fs1 = feat_stride_y; a.fs2 = feat_stride_x; a.f1 = src->npy; a.f2 = src->npx;
-  const int blocks = (3 * hw + 256 * 8 - 1) / (256 * 8);
-  hipLaunchKernelGGL(stage_frame_kernel, dim3(blocks > 0 ? blocks : 1, 6), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  a.first_block[0] = 0;
+  for (int k = 0; k < 6; ++k) {
+    const int per = 256 * 4 * kStageUnroll;
+    a.first_block[k + 1] = a.first_block[k] + (s[k] && n[k] > 0 ? (n[k] + per - 1) / per : 0);
+  }
+  if (a.first_block[6] <= 0) return SAF_OK;
+  hipLaunchKernelGGL(stage_frame_kernel, dim3(a.first_block[6]), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("stage_frame_kernel");
 }
 
