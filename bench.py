@@ -700,6 +700,14 @@ def main():
     api_b1 = None
     if a.api_b1 > 0 and rank == 0 and world == 1:
         api_b1 = bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, value)
+        # the same loop with `fusion.borrow_inputs = True`: the queue reads the calls' depth / rgb images where they lie instead of
+        # copying them into its ring (the caller does not write them before flush(): the reference's loop never does)
+        fusion.borrow_inputs = True
+        try:
+            bb = bench_api_b1(a, fusion, depth, rgb, poses, ks, feat, label_maps, value)
+            api_b1["borrowed_inputs"] = {k: bb[k] for k in ("value", "vs_bulk", "host_enqueue_us_per_call")}
+        finally:
+            fusion.borrow_inputs = False
 
     # ---- end-to-end: backbone + fuse through the reference-shaped Python API (reported separately) ----
     e2e = None

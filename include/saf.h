@@ -166,7 +166,9 @@ int saf_fuse_frames(const saf_volume* vol, const saf_frame* frames, int32_t n_fr
  * points to, in ONE launch: the host queue behind integrate() keeps the frames of small calls in a staging ring until a
  * window is full.  The source feature map is addressed through element strides (Clip.img_inference_tiled returns a
  * permuted view); feat_channels = channels to copy; everything else is contiguous.  src->feat_map may be NULL (the queue
- * computes the feature maps later, in one backbone batch per flush): nothing is copied for it. */
+ * computes the feature maps later, in one backbone batch per flush): nothing is copied for it.  depth, rgb and label_map may be
+ * NULL in BOTH `src` and `dst`: images the caller lends the queue where they lie (the frame descriptors of the later fuse call
+ * point at them) instead of having them copied. */
 int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_stride_c, int64_t feat_stride_y,
                     int64_t feat_stride_x, const saf_frame* dst, void* stream);
 

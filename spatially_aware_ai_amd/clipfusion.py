@@ -55,6 +55,11 @@ def _axis_tables(origin, voxel_size, nvox, index_offset=(0, 0, 0), x_planes=None
     return [(idx[a] * voxel_size + origin[a]).to(torch.float32).contiguous() for a in range(3)]
 
 
+# `fusion.borrow_inputs = True` (default: SAF_BORROW_INPUTS=1 in the environment, else False): the queue behind integrate() does
+# not copy a call's depth / rgb / label images into its staging ring but reads them where they are when their window is fused --
+# up to 512 frames later.  The caller promises not to WRITE those tensors until flush() (dropping them is fine: the queue holds
+# them); the reference's loop (a fresh batch per DataLoader step, clip_seem_fusion.py:303-313) keeps that promise by construction.
+_BORROW_DEFAULT = os.environ.get("SAF_BORROW_INPUTS", "0") == "1"
 _VOLUME_BUFFERS = frozenset(("tsdf", "rgb", "clip_feat", "weight", "tsdf_weight", "labels_one_hot", "fuse_stats"))
 
 
@@ -172,8 +177,9 @@ class _FusionVolumeMixin:
             t = t.float()
         return t.contiguous()
 
-    def _make_frames(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear):
-        """C descriptors for a batch; returns (ctypes array, keepalive list, npy, npx)."""
+    def _make_frames(self, depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear, borrowed=None):
+        """C descriptors for a batch; returns (ctypes array, keepalive list, npy, npx).  ``borrowed`` ([B, 3] int64, or None):
+        per frame the addresses of a caller's depth / rgb / label images that stand in for the batch's (0: none)."""
         depth_imgs = self._f32c(depth_imgs, "depth_imgs")
         rgb_imgs = self._f32c(rgb_imgs, "rgb_imgs")
         poses = self._f32c(poses, "poses")
@@ -215,6 +221,9 @@ class _FusionVolumeMixin:
         if lab_ptrs is not None:
             arr[:, 7] = lab_ptrs
         arr[:, 8] = int(bool(rgb_bilinear))
+        if borrowed is not None:
+            for col, k in ((1, 0), (2, 1), (7, 2)):
+                arr[:, col] = np.where(borrowed[:, k] != 0, borrowed[:, k], arr[:, col])
         return (_abi.SafFrame * bsz).from_buffer(arr), (depth_imgs, rgb_imgs, poses, K, feat, labs), npy, npx
 
     # -- the deferred window queue ---------------------------------------------------------------
@@ -295,6 +304,9 @@ class _FusionVolumeMixin:
                   # the frames staged and not yet handed over lie in slots [ring0, ring0 + _pending_n); free_ev[q]: the event
                   # behind the row kernel that reads quarter q's frames (None: free); held: quarters whose row kernel is owed
                   "ring0": 0, "free_ev": [None] * (self._QUEUE_FRAMES // _abi.SAF_WINDOW_FRAMES), "sess_frames": 0,
+                  # borrow_inputs: per slot the addresses of the caller's depth / rgb / label images that were NOT copied (0: the
+                  # ring's) and the tensors themselves, held until the slot is staged again (behind its row kernel's event)
+                  "bptr": np.zeros((n, 3), dtype=np.int64), "brefs": [None] * n,
                   "src": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0),
                   "dst": _abi.SafFrame(h, w, None, None, None, None, None, key[2][1], key[2][2], None, 0)}
             # base addresses and byte strides of the ring's slots (no tensor views per call)
@@ -311,6 +323,8 @@ class _FusionVolumeMixin:
                 and rgb_imgs.is_contiguous() and poses.is_contiguous() and K.is_contiguous() and
                 (label_maps is None or all(m.dtype == f32 and m.is_contiguous() for m in label_maps)))
             src, dst, base, step = st["src"], st["dst"], st["base"], st["step"]
+            # (a deferred backbone reads the queued frames' rgb from the ring: nothing to borrow there)
+            borrow = fast and lazy is None and bool(self.__dict__.get("borrow_inputs", _BORROW_DEFAULT))
             raw_stream = stream.cuda_stream
             win = _abi.SAF_WINDOW_FRAMES
             if fast:
@@ -339,9 +353,19 @@ class _FusionVolumeMixin:
                     dst.K, dst.feat_map = base[3] + slot * step[3], base[4] + slot * step[4]
                     if label_maps is not None:
                         src.label_map, dst.label_map = label_maps[i].data_ptr(), base[5] + slot * step[5]
+                    if borrow:  # the images stay where the caller has them: 5 MB per frame that are not copied
+                        st["bptr"][slot] = (src.depth, src.rgb, src.label_map or 0)
+                        st["brefs"][slot] = (depth_imgs, rgb_imgs, None if label_maps is None else label_maps[i])
+                        src.depth = src.rgb = src.label_map = dst.depth = dst.rgb = dst.label_map = None
+                    elif st["brefs"][slot] is not None:
+                        st["bptr"][slot] = 0
+                        st["brefs"][slot] = None
                     check(lib().saf_stage_frame(C.byref(src), key[2][0], fs[1], fs[2], fs[3], C.byref(dst), raw_stream),
                           "saf_stage_frame")
                 else:  # other dtypes / layouts: PyTorch copies convert
+                    if st["brefs"][slot] is not None:
+                        st["bptr"][slot] = 0
+                        st["brefs"][slot] = None
                     st["depth"][slot].copy_(depth_imgs[i], non_blocking=True)
                     st["rgb"][slot].copy_(rgb_imgs[i], non_blocking=True)
                     st["pose"][slot].copy_(poses[i], non_blocking=True)
@@ -425,7 +449,8 @@ class _FusionVolumeMixin:
             return
         sl = slice(lo, lo + n)
         labs = None if st["labels"] is None else st["labels"][sl]
-        arr, _keep, npy, npx = self._make_frames(st["depth"][sl], st["rgb"][sl], st["pose"][sl], st["K"][sl], st["feat"][sl], labs, st["key"][4])
+        arr, _keep, npy, npx = self._make_frames(st["depth"][sl], st["rgb"][sl], st["pose"][sl], st["K"][sl], st["feat"][sl], labs, st["key"][4],
+                                                 borrowed=st["bptr"][sl])
         vol = self._c_volume(for_fuse=True)
         ws = self._get_workspace(npy, npx, (int(st["depth"].shape[1]), int(st["depth"].shape[2])))
         L = lib()
@@ -567,7 +592,8 @@ class _FusionVolumeMixin:
                 f"({len(self._shard_stripes)} of them) of a merged job; all_gather it (distributed.gather_shards, or "
                 "merge_volumes(..., gather=True)) before fusing more frames"
             )
-        arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear)
+        arr, keep, npy, npx = self._make_frames(depth_imgs, rgb_imgs, poses, K, clip_feat_img, label_maps, rgb_bilinear,
+                                                borrowed=None if staged is None else self.__dict__["_stage"]["bptr"][staged[0]:staged[0] + staged[1]])
         vol = self._c_volume(for_fuse=True)
         ws = self._get_workspace(npy, npx, (int(depth_imgs.shape[1]), int(depth_imgs.shape[2])))
         L = lib()

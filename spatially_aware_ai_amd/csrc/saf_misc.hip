@@ -485,7 +485,8 @@ int saf_clear_unwritten_rows(const saf_volume* vol, int64_t first_voxel, int64_t
 
 int saf_stage_frame(const saf_frame* src, int32_t feat_channels, int64_t feat_stride_c, int64_t feat_stride_y,
                     int64_t feat_stride_x, const saf_frame* dst, void* stream) {
-  if (!src || !dst || !src->depth || !src->rgb || !src->pose || !src->K || !dst->depth || !dst->rgb || !dst->pose || !dst->K ||
+  // (depth / rgb / label map may be NULL on BOTH sides: images the caller lends the queue instead of having them copied)
+  if (!src || !dst || !src->pose || !src->K || !dst->pose || !dst->K || !src->depth != !dst->depth || !src->rgb != !dst->rgb ||
       src->height <= 0 || src->width <= 0 || (src->label_map && !dst->label_map) ||
       (src->feat_map && (!dst->feat_map || feat_channels <= 0 || src->npy <= 0 || src->npx <= 0)))
     return fail(SAF_E_INVALID, "stage_frame: bad arguments");
