@@ -210,17 +210,45 @@ __device__ __forceinline__ float4 load_row4(const void* __restrict__ base, int64
 #endif
 }
 
+// Reductions over the 32 lanes of a half without the LDS (round 6; rounds 1-5: five ds_bpermute steps each, 16 to 32 chains per
+// tile): quads, eights and sixteens by DPP inside the adds, the two 16-lane rows of the half by one v_permlane16_swap -- swapping a
+// value's odd rows with its own even rows leaves (row 0, row 0, row 2, row 2) and (row 1, row 1, row 3, row 3).
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane(float x) {  // quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float half_max(float x) {  // over the 32 lanes of this half
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
-  return x;
+  x = fmaxf(x, dpp_lane<0xB1>(x));
+  x = fmaxf(x, dpp_lane<0x4E>(x));
+  x = fmaxf(x, dpp_lane<0x141>(x));
+  x = fmaxf(x, dpp_lane<0x140>(x));
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, x), false, false);
+  return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
 }
 __device__ __forceinline__ float half_sum(float x) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o);
-  return x;
+  x += dpp_lane<0xB1>(x);
+  x += dpp_lane<0x4E>(x);
+  x += dpp_lane<0x141>(x);
+  x += dpp_lane<0x140>(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, x), false, false);
+  return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
 }
-
+// a value and its partner's 32 lanes away: v_permlane32_swap of a register with itself leaves (lower, lower) and (upper, upper)
+__device__ __forceinline__ float other_half_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, x), false, false);
+  return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+}
+__device__ __forceinline__ float other_half_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, x), false, false);
+  return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+}
+// lane `src` (a constant below 28) for the lower half of the wave, lane `src + 4` for the upper: the accumulator layout's row of
+// register i in either half -- two v_readlane and a select instead of a ds_bpermute
+template <typename T>
+__device__ __forceinline__ T row_of_half(T v, int src, int h) {
+  const int lo = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src), hi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src + 4);
+  return __builtin_bit_cast(T, h ? hi : lo);
+}
 
 // ---- epilogue on the MFMA accumulator layout: this lane holds column n = m (+32 t) of 16 rows.  `inv`: the factor of row m
 // (1 / norm); CS (the split scan): the row's and the columns' power-of-two scales 2^rexp, 2^cexp undone by one v_ldexp_f32,
@@ -245,8 +273,8 @@ __device__ __forceinline__ void scan_epilogue(const f32x16 (&acc)[TILES], float 
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int mi = (i & 3) + 8 * (i >> 2) + 4 * h;  // row of accumulator register i in this half
-    const float inv_i = __shfl(inv, mi);
-    const int rexp_i = CS ? __shfl(rexp, mi) : 0;
+    const float inv_i = row_of_half(inv, (i & 3) + 8 * (i >> 2), h);
+    const int rexp_i = CS ? row_of_half(rexp, (i & 3) + 8 * (i >> 2), h) : 0;
     const int64_t r = tile * 32 + mi;
     float val[TILES];
     bool ok[TILES];
@@ -425,7 +453,7 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
 //     that matters falls below its normal range (a feature 2^-16 of the row's largest still has its hi piece whole), and a row
 //     of any magnitude fp32 holds is scanned like any other.  Row norms come from the unscaled fp32 values as before.
 // Same loads, same register ring, same epilogue as the fp32 MFMA scan above (SAF_Q_SPLIT=0 selects that one).  Measured at
-// 256^3 x 512 fp32 (profiles/r06/split_scan_ab.txt): L = 63 surgery 10.95 -> 7.6 ms (round 5: 12.2), L = 5 softmax 6.9 -> 6.3.
+// 256^3 x 512 fp32 (profiles/r06/split_scan_ab.txt): L = 63 surgery 10.95 -> 7.6 ms (round 5: 12.2), L = 5 softmax 6.9 -> 5.9 (reductions without the LDS).
 // ------------------------------------------------------------------------------------------
 #ifndef SAF_QS_ABL
 #define SAF_QS_ABL 0
@@ -523,7 +551,7 @@ __global__ __launch_bounds__(TH) void query_split_kernel(const void* __restrict_
     bool seen = false;  // a feature of the row was not zero
     // a group's largest magnitude `gm` (this half's part) against the row's scale, before the group is cut
     auto fit = [&](float gm) {
-      gm = fmaxf(gm, __shfl_xor(gm, 32));
+      gm = other_half_max(gm);
       const bool need = ldexpf(gm, re) >= 32768.0f || (!seen && gm > 0.0f);
       if (__builtin_amdgcn_ballot_w64(need)) {
         const int ne = need ? (gm < INFINITY ? split_exponent(gm) : 0) : re;
@@ -612,7 +640,7 @@ __global__ __launch_bounds__(TH) void query_split_kernel(const void* __restrict_
                fmaxf(fmaxf(fabsf(a1.x), fabsf(a1.y)), fmaxf(fabsf(a1.z), fabsf(a1.w)))));
       step(a0, a1, k0 >> 4);
     }
-    ss += __shfl_xor(ss, 32);  // both halves of row m
+    ss = other_half_sum(ss);  // both halves of row m
     scan_epilogue<EPI, TILES, true>(acc, row_inverse(ss, normalize), re, ce, tile, n_rows, L, scale, wl, out, out_last,
                                     out_stride, out_col0, stage);
   }
