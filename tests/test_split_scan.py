@@ -158,3 +158,25 @@ def test_split_scan_strided_rows_and_non_finite():
     ok = np.ones(n, dtype=bool)
     ok[[5, 40]] = False
     np.testing.assert_array_equal(got_b[ok], got.astype(np.float32)[ok])
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 64, 257])
+def test_split_scan_few_rows_and_one_label(oracle, n):
+    """fewer rows than a tile, a tile and a row, whole tiles only (the staged 16-byte stores) -- with 1, 2 and 64 labels"""
+    d = 512
+    g = torch.Generator().manual_seed(n)
+    feats = torch.randn((n, d), generator=g)
+    for nl in (1, 2, 64):
+        text = torch.nn.functional.normalize(torch.randn((nl, d), generator=g), dim=-1)
+        _check_raw(feats, text, f"{n} rows, {nl} labels")
+        for epi, scale in ((_abi.SAF_Q_SURGERY, 1.0), (_abi.SAF_Q_SOFTMAX, 100.0)):
+            want = oracle.query_scan(feats, text, epi, scale=scale, normalize=True)
+            got = _scan(feats.cuda(), text.cuda(), epi, scale=scale, normalize=True)
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"epilogue {epi}, {n} rows, {nl} labels")
+            last = _query_last(feats.cuda(), text.cuda(), epi, scale)
+            np.testing.assert_allclose(last.cpu().numpy(), want.numpy()[:, -1], rtol=1e-4, atol=2e-6)
+
+
+def _query_last(feats, text, epi, scale):
+    from spatially_aware_ai_amd.clipfusion import _query_scan
+    return _query_scan(feats, text, epi, scale=scale, normalize=True, last_only=True)
