@@ -763,9 +763,10 @@ __global__ __launch_bounds__(256) void finish_rows_kernel(float* __restrict__ ou
 
 template <int EPI>
 int launch_mfma_blocks(int ft, const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
-                       float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s) {
-  for (int c0 = 0; c0 < L; c0 += 64) {
-    const int lb = L - c0 < 64 ? L - c0 : 64;
+                       float scale, int normalize, const float* wts, float* out, float* out_last, hipStream_t s, int bw) {
+  // bw: labels per block -- 64, or 32 where two 32-label tiles of this width do not fit the LDS (feat_dim 768 / 1024: round 6)
+  for (int c0 = 0; c0 < L; c0 += bw) {
+    const int lb = L - c0 < bw ? L - c0 : bw;
     int rc = launch_mfma<SAF_Q_SCORES>(ft, feats, n_rows, fstride, D, text + (int64_t)c0 * tstride, lb, tstride, scale, normalize,
                                        wts ? wts + c0 : nullptr, out, nullptr, s, (int64_t)L, c0);
     if (rc) return rc;
@@ -821,12 +822,17 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
   const bool mfma = mfma_ok(ft, feat_stride, feat_dim, n_text, feats);
   // more than 64 labels: block by block on the MFMA scan where it takes a 64-label block of this shape and the caller wants the
   // whole [N, L] matrix (the blocks' scores need somewhere to meet)
-  const bool blocks = !mfma && n_text > 64 && out != nullptr && mfma_ok(ft, feat_stride, feat_dim, 64, feats);
+  // ... and where feat_dim is too wide for two label tiles in LDS (768, 1024 channels: OpenCLIP's larger towers) 32 at a time -- one
+  // pass over the volume per block still beats the one-wave-per-row kernel by far
+  const int bw = mfma || out == nullptr ? 0
+                 : (n_text > 64 && mfma_ok(ft, feat_stride, feat_dim, 64, feats)) ? 64
+                 : (n_text > 32 && mfma_ok(ft, feat_stride, feat_dim, 32, feats)) ? 32 : 0;
+  const bool blocks = bw != 0;
   switch (epilogue) {
     case SAF_Q_SCORES:
       if (blocks)
         return launch_mfma_blocks<SAF_Q_SCORES>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
-                                                nullptr, out, out_last, s);
+                                                nullptr, out, out_last, s, bw);
       if (mfma)
         return launch_mfma<SAF_Q_SCORES>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale,
                                          normalize, nullptr, out, out_last, s);
@@ -835,7 +841,7 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
     case SAF_Q_SOFTMAX:
       if (blocks)
         return launch_mfma_blocks<SAF_Q_SOFTMAX>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale, normalize,
-                                                 nullptr, out, out_last, s);
+                                                 nullptr, out, out_last, s, bw);
       if (mfma)
         return launch_mfma<SAF_Q_SOFTMAX>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, scale,
                                           normalize, nullptr, out, out_last, s);
@@ -851,7 +857,7 @@ int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_
       if (rc) return rc;
       if (blocks)
         return launch_mfma_blocks<SAF_Q_SURGERY>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, 1.0f, normalize,
-                                                 wts, out, out_last, s);
+                                                 wts, out, out_last, s, bw);
       if (mfma)
         return launch_mfma<SAF_Q_SURGERY>(ft, f, n_rows, feat_stride, feat_dim, text, n_text, text_stride, 1.0f,
                                           normalize, wts, out, out_last, s);

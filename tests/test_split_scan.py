@@ -180,3 +180,19 @@ def test_split_scan_few_rows_and_one_label(oracle, n):
 def _query_last(feats, text, epi, scale):
     from spatially_aware_ai_amd.clipfusion import _query_scan
     return _query_scan(feats, text, epi, scale=scale, normalize=True, last_only=True)
+
+
+@pytest.mark.parametrize("d,nl", [(768, 63), (1024, 40), (1024, 100)])
+def test_split_scan_wide_features_in_blocks_of_32(oracle, d, nl):
+    """feat_dim 768 / 1024 (OpenCLIP's larger towers): two 32-label tiles do not fit the LDS, so more than 32 labels run 32 at a time on
+    the matrix cores with a finishing pass (rounds 1-5: the one-wave-per-row kernel)"""
+    n = 2051
+    g = torch.Generator().manual_seed(d + nl)
+    feats = torch.randn((n, d), generator=g)
+    feats[3] = 0.0
+    text = torch.nn.functional.normalize(torch.randn((nl, d), generator=g), dim=-1)
+    _check_raw(feats, text, f"D = {d}, {nl} labels")
+    for epi, scale in ((_abi.SAF_Q_SURGERY, 1.0), (_abi.SAF_Q_SOFTMAX, 100.0), (_abi.SAF_Q_SCORES, 3.0)):
+        want = oracle.query_scan(feats, text, epi, scale=scale, normalize=True)
+        got = _scan(feats.cuda(), text.cuda(), epi, scale=scale, normalize=True)
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"epilogue {epi}, D = {d}, {nl} labels")
