@@ -462,7 +462,7 @@ __global__ __launch_bounds__(TH) void query_mfma_kernel(const void* __restrict__
 #define SAF_QS_STAGE 1  // 0: the score matrix stored a row's 32 columns at a time (A/B)
 #endif
 #ifndef SAF_QS_CHAIN
-#define SAF_QS_CHAIN 0  // 1: the ring runs on from tile to tile (measured: no gain, profiles/r06/split_scan_ab.txt)
+#define SAF_QS_CHAIN 1  // 0: a fresh ring per tile, the next group's loads behind a condition (rounds 1-6: every wait a vmcnt(0..7))
 #endif
 typedef _Float16 h8x __attribute__((ext_vector_type(8)));
 typedef _Float16 h2x __attribute__((ext_vector_type(2)));
@@ -481,7 +481,7 @@ __device__ __forceinline__ void split2(float y0, float y1, uint32_t& hi, uint32_
 }
 
 template <int EPI, int FT, int TILES, int TH>
-__global__ __launch_bounds__(TH) void query_split_kernel(const void* __restrict__ feats, int64_t n_rows, int64_t fstride, int D,
+__global__ __launch_bounds__(TH, 2) void query_split_kernel(const void* __restrict__ feats, int64_t n_rows, int64_t fstride, int D,
                                                          const float* __restrict__ text, int L, int64_t tstride, float scale,
                                                          int normalize, const float* __restrict__ wts, float* __restrict__ out,
                                                          float* __restrict__ out_last, int64_t out_stride, int out_col0,
@@ -520,10 +520,13 @@ __global__ __launch_bounds__(TH) void query_split_kernel(const void* __restrict_
   const int n_groups = D / (8 * kQGroup);  // full prefetch groups; the remainder is handled pair by pair
   const int64_t n_tiles = (n_rows + 31) / 32;
   const unsigned char* tb = s_split + (size_t)m * rs_bytes + h * 32;
-  // SAF_QS_CHAIN=1 (off: measured, no gain -- the CU's other seven waves cover a tile's first latency): where the groups of a row
-  // fill the ring a whole number of times the ring runs on from tile to tile, a tile's last groups and its epilogue with the
-  // first groups of the wave's NEXT tile in flight.
-  const bool chain = SAF_QS_CHAIN && n_groups >= kQSlots && n_groups % kQSlots == 0;
+  // The ring, made to work (round 6, late): with the next group's loads behind a condition (`is there a next group?`) the compiler's
+  // wait-count pass cannot know how many loads are younger than the group it is about to multiply and waits for ALL of them --
+  // vmcnt(7) .. vmcnt(0) in every build of rounds 1-6, the "ring" one group deep and nothing in flight under the MFMAs (which is
+  // why three slots, or four, never changed anything).  Where a row is a whole number of PAIRS of groups (feat_dim a multiple of
+  // 128) the two slots are loaded by unconditional code -- behind a tile's last group comes the wave's NEXT tile's first (behind
+  // the last tile: a row nobody uses) -- and the waits count 8 younger loads: vmcnt(15) .. vmcnt(8).
+  const bool chain = SAF_QS_CHAIN && kQSlots == 2 && n_groups >= 2 && n_groups % 2 == 0;
   const int64_t tile0 = (int64_t)blockIdx.x * (TH / 64) + wave, tile_step = (int64_t)gridDim.x * (TH / 64);
   auto row_base = [&](int64_t tile) {
     int64_t row = tile * 32 + m;
@@ -603,7 +606,28 @@ __global__ __launch_bounds__(TH) void query_split_kernel(const void* __restrict_
 #endif
       }
     };
-    if (!chain) {
+    auto multiply = [&](const float4 (&grp)[kQGroup], int g) {  // one group of a row: its scale, then its k-steps
+      float gm = 0.0f;
+#pragma unroll
+      for (int q = 0; q < kQGroup; ++q) {
+        const float4 a = grp[q];
+        gm = fmaxf(fmaxf(gm, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+      }
+      fit(gm);
+#pragma unroll
+      for (int q = 0; q < kQGroup; q += 2) step(grp[q], grp[q + 1], (g * kQGroup + q) >> 1);
+    };
+    if (chain) {
+      for (int g = 0; g < n_groups; g += 2) {
+#pragma unroll
+        for (int q = 0; q < kQGroup; ++q) ring[1 % kQSlots][q] = load_row4<FT>(feats, base + 8 * ((g + 1) * kQGroup + q));
+        multiply(ring[0], g);
+        const int64_t from = g + 2 < n_groups ? base + 8 * ((g + 2) * kQGroup) : base_next;
+#pragma unroll
+        for (int q = 0; q < kQGroup; ++q) ring[0][q] = load_row4<FT>(feats, from + 8 * q);
+        multiply(ring[1 % kQSlots], g + 1);
+      }
+    } else {
 #pragma unroll
       for (int sl = 0; sl + 1 < kQSlots; ++sl) {
         if (sl < n_groups) {
@@ -611,27 +635,18 @@ __global__ __launch_bounds__(TH) void query_split_kernel(const void* __restrict_
           for (int q = 0; q < kQGroup; ++q) ring[sl][q] = load_row4<FT>(feats, base + 8 * (sl * kQGroup + q));
         }
       }
-    }
-    for (int g0 = 0; g0 < n_groups; g0 += kQSlots) {
+      for (int g0 = 0; g0 < n_groups; g0 += kQSlots) {
 #pragma unroll
-      for (int sl = 0; sl < kQSlots; ++sl) {
-        const int g = g0 + sl;
-        if (g >= n_groups) break;
-        const int gl = g + kQSlots - 1;
-        if (gl < n_groups || chain) {
-          const int64_t from = gl < n_groups ? base + 8 * (gl * kQGroup) : base_next + 8 * ((gl - n_groups) * kQGroup);
+        for (int sl = 0; sl < kQSlots; ++sl) {
+          const int g = g0 + sl;
+          if (g >= n_groups) break;
+          const int gl = g + kQSlots - 1;
+          if (gl < n_groups) {
 #pragma unroll
-          for (int q = 0; q < kQGroup; ++q) ring[(sl + kQSlots - 1) % kQSlots][q] = load_row4<FT>(feats, from + 8 * q);
+            for (int q = 0; q < kQGroup; ++q) ring[(sl + kQSlots - 1) % kQSlots][q] = load_row4<FT>(feats, base + 8 * (gl * kQGroup + q));
+          }
+          multiply(ring[sl], g);
         }
-        float gm = 0.0f;
-#pragma unroll
-        for (int q = 0; q < kQGroup; ++q) {
-          const float4 a = ring[sl][q];
-          gm = fmaxf(fmaxf(gm, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
-        }
-        fit(gm);
-#pragma unroll
-        for (int q = 0; q < kQGroup; q += 2) step(ring[sl][q], ring[sl][q + 1], (g * kQGroup + q) >> 1);
       }
     }
     for (int k0 = 8 * kQGroup * n_groups; k0 < D; k0 += 16) {  // D not a multiple of 64
@@ -646,11 +661,215 @@ __global__ __launch_bounds__(TH) void query_split_kernel(const void* __restrict_
   }
 }
 
-template <int EPI, int FT, int TILES, int TH, bool SPLIT>
+// ------------------------------------------------------------------------------------------
+// The split scan over a 16-BIT volume (bf16: BASELINE config 3's; fp16).  Through the kernel above a 16-bit row is widened to fp32
+// and cut again -- the same 45 vector instructions per k-step for half the bytes, and 8-byte loads: L = 63 over a 256^3 x 512 bf16
+// volume took 6.9 ms where the fp32 volume takes 7.6.  Here a lane's 8 values of a k-step ARE one 16-byte load in the matrix
+// instruction's own layout (k = 16 p + 8 h + j: the labels' pieces lie in LDS in that order), and a feature needs ONE fp16 piece:
+//   * fp16: the value itself -- no conversion at all, the row norm from v_fma_mix_f32 (v_dot2_f32_f16 was 3 % off: not used);
+//   * bf16: its 8 significant bits fit fp16's 11, so `fp16(x * 2^e)` is exact wherever it is normal -- under the running
+//     power-of-two scale of the kernel above (largest magnitude of the row so far in [2^13, 2^14)) that is every feature down to
+//     2^-27 of the row's largest; below that fp16's denormal spacing leaves an error of 2^-38 of the row's largest.
+// Two MFMAs per 16 k and 32 labels (a.hi, a.lo of the LABEL's two pieces); the score's error is the labels' cut alone, 2^-22.
+// ------------------------------------------------------------------------------------------
+constexpr int kQGroup16 = 8;  // k-steps (16 bytes of every row each) per prefetch group: 128 features
+
+template <int EPI, int FT, int TILES, int TH>
+__global__ __launch_bounds__(TH, 2) void query_split16_kernel(const void* __restrict__ feats, int64_t n_rows, int64_t fstride, int D,
+                                                           const float* __restrict__ text, int L, int64_t tstride, float scale,
+                                                           int normalize, const float* __restrict__ wts, float* __restrict__ out,
+                                                           float* __restrict__ out_last, int64_t out_stride, int out_col0,
+                                                           int stage_on) {
+  static_assert(FT == SAF_F16 || FT == SAF_BF16, "16-bit volumes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_split[];  // as query_split_kernel's, the pieces in plain k order
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rs_bytes = 4 * D + 16;
+  int* s_ce = reinterpret_cast<int*>(s_split + (size_t)TILES * 32 * rs_bytes);
+  float* stage = stage_on ? reinterpret_cast<float*>(s_ce + TILES * 32) + (size_t)wave * (TILES * 256) : nullptr;
+  for (int n = wave; n < TILES * 32; n += TH / 64) {
+    float mx = 0.0f;
+    if (n < L)
+      for (int k = lane; k < D; k += 64) mx = fmaxf(mx, fabsf(text[(int64_t)n * tstride + k]));
+    mx = wave_max(mx);
+    const int be = mx > 0.0f && mx < INFINITY ? split_exponent(mx) : 0;
+    if (lane == 0) s_ce[n] = be;
+    for (int k = lane; k < D; k += 64) {
+      const float y = n < L ? ldexpf(text[(int64_t)n * tstride + k], be) : 0.0f;
+      const _Float16 hi = (_Float16)y, lo = (_Float16)(y - (float)hi);
+      _Float16* dst = reinterpret_cast<_Float16*>(s_split + (size_t)n * rs_bytes + (k >> 4) * 64 + ((k >> 3) & 1) * 32) + (k & 7);
+      dst[0] = hi;
+      dst[8] = lo;
+    }
+  }
+  __syncthreads();
+  const int m = lane & 31, h = lane >> 5;
+  float wl[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) wl[t] = wts && m + 32 * t < L ? wts[m + 32 * t] : 1.0f;
+  int ce[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) ce[t] = s_ce[m + 32 * t];
+  const int n_steps = D >> 4, n_groups = n_steps / kQGroup16;
+  const int64_t n_tiles = (n_rows + 31) / 32;
+  const unsigned char* tb = s_split + (size_t)m * rs_bytes + h * 32;
+  const uint16_t* f16 = static_cast<const uint16_t*>(feats);
+  typedef unsigned int q16_u4 __attribute__((ext_vector_type(4)));
+  const bool chain = SAF_QS_CHAIN && kQSlots == 2 && n_groups >= 2 && n_groups % 2 == 0;
+  const int64_t tile0 = (int64_t)blockIdx.x * (TH / 64) + wave, tile_step = (int64_t)gridDim.x * (TH / 64);
+  q16_u4 ring[kQSlots][kQGroup16];
+  if (chain && tile0 < n_tiles) {
+    int64_t row = tile0 * 32 + m;
+    if (row >= n_rows) row = n_rows - 1;
+#pragma unroll
+    for (int q = 0; q < kQGroup16; ++q) ring[0][q] = *reinterpret_cast<const q16_u4*>(f16 + row * fstride + 8 * h + 16 * q);
+  }
+  for (int64_t tile = tile0; tile < n_tiles; tile += tile_step) {
+    int64_t row = tile * 32 + m;
+    if (row >= n_rows) row = n_rows - 1;  // padded lanes recompute the last row, never stored
+    const uint16_t* rp = f16 + row * fstride + 8 * h;
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    float ss = 0.0f;
+    int re = 0;         // bf16: the row's scale is 2^re, following its running maximum (query_split_kernel); fp16: none
+    bool seen = false;
+    auto fit = [&](float gm) {
+      gm = other_half_max(gm);
+      const bool need = ldexpf(gm, re) >= 32768.0f || (!seen && gm > 0.0f);
+      if (__builtin_amdgcn_ballot_w64(need)) {
+        const int ne = need ? (gm < INFINITY ? split_exponent(gm) : 0) : re;
+        const float fac = need && seen ? ldexpf(1.0f, ne - re) : 1.0f;
+        re = ne;
+        seen = seen || gm > 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float f = __shfl(fac, (i & 3) + 8 * (i >> 2) + 4 * h);
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) acc[t][i] *= f;
+        }
+      }
+    };
+    auto widen = [](uint32_t w, float& x0, float& x1) {  // two bf16 -> fp32
+      x0 = __builtin_bit_cast(float, w << 16);
+      x1 = __builtin_bit_cast(float, w & 0xffff0000u);
+    };
+    // (bf16) the largest magnitude of a group, in the integer domain: below the sign bit a bf16's bits order its magnitude, so the
+    // group's maximum is 32 v_and + v_pk_max_u16 and ONE conversion -- widening the values here as well kept a second copy of the
+    // group alive until its k-steps (the optimiser shares the widening): 105 spilled registers at two label tiles
+    auto group_max_bits = [&](const q16_u4& a, uint32_t mx) {
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const us2 u = __builtin_bit_cast(us2, w[j] & 0x7fff7fffu), v = __builtin_bit_cast(us2, mx);
+        const us2 r = {u.x > v.x ? u.x : v.x, u.y > v.y ? u.y : v.y};
+        mx = __builtin_bit_cast(uint32_t, r);
+      }
+      return mx;
+    };
+    auto bits_max = [](uint32_t mx) {  // the larger half as fp32 (a NaN among the values: the row is NaN whatever its scale)
+      const uint32_t lo = mx & 0xffffu, hi = mx >> 16;
+      return __builtin_bit_cast(float, (lo > hi ? lo : hi) << 16);
+    };
+    auto step = [&](const q16_u4& a, int p) {
+      q16_u4 hi;
+      if (FT == SAF_F16) {
+        hi = a;
+        // (the words by name: `a[j]` under the unrolled loop read word 0 four times here -- the row norms of fp16 volumes were off
+        //  by a few percent until the parity tests said so)
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const h2x v = __builtin_bit_cast(h2x, w[j]);  // (v_fma_mix_f32: fp16 operands, fp32 product and sum)
+          ss = __builtin_fmaf((float)v.x, (float)v.x, ss);
+          ss = __builtin_fmaf((float)v.y, (float)v.y, ss);
+        }
+      } else {
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x0, x1;
+          widen(w[j], x0, x1);
+          ss = __builtin_fmaf(x0, x0, ss);
+          ss = __builtin_fmaf(x1, x1, ss);
+          const h2x v = {(_Float16)ldexpf(x0, re), (_Float16)ldexpf(x1, re)};
+          hi[j] = __builtin_bit_cast(uint32_t, v);
+        }
+      }
+      const h8x ah = __builtin_bit_cast(h8x, hi);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        const q16_u4* bp = reinterpret_cast<const q16_u4*>(tb + (size_t)t * 32 * rs_bytes + p * 64);
+        const h8x bh = __builtin_bit_cast(h8x, bp[0]), bl = __builtin_bit_cast(h8x, bp[1]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+      }
+    };
+    auto multiply = [&](const q16_u4 (&grp)[kQGroup16], int g) {
+      if (FT == SAF_BF16) {
+        uint32_t mx = 0u;
+#pragma unroll
+        for (int q = 0; q < kQGroup16; ++q) mx = group_max_bits(grp[q], mx);
+        fit(bits_max(mx));
+      }
+#pragma unroll
+      for (int q = 0; q < kQGroup16; ++q) step(grp[q], g * kQGroup16 + q);
+    };
+    if (chain) {  // (see query_split_kernel: unconditional loads, counted waits)
+      int64_t nrow = (tile + tile_step < n_tiles ? tile + tile_step : tile) * 32 + m;
+      if (nrow >= n_rows) nrow = n_rows - 1;
+      const uint16_t* rpn = f16 + nrow * fstride + 8 * h;
+      for (int g = 0; g < n_groups; g += 2) {
+#pragma unroll
+        for (int q = 0; q < kQGroup16; ++q) ring[1 % kQSlots][q] = *reinterpret_cast<const q16_u4*>(rp + 16 * ((g + 1) * kQGroup16 + q));
+        multiply(ring[0], g);
+        const uint16_t* from = g + 2 < n_groups ? rp + 16 * ((g + 2) * kQGroup16) : rpn;
+#pragma unroll
+        for (int q = 0; q < kQGroup16; ++q) ring[0][q] = *reinterpret_cast<const q16_u4*>(from + 16 * q);
+        multiply(ring[1 % kQSlots], g + 1);
+      }
+    } else {
+#pragma unroll
+      for (int sl = 0; sl + 1 < kQSlots; ++sl) {
+        if (sl < n_groups) {
+#pragma unroll
+          for (int q = 0; q < kQGroup16; ++q) ring[sl][q] = *reinterpret_cast<const q16_u4*>(rp + 16 * (sl * kQGroup16 + q));
+        }
+      }
+      for (int g0 = 0; g0 < n_groups; g0 += kQSlots) {
+#pragma unroll
+        for (int sl = 0; sl < kQSlots; ++sl) {
+          const int g = g0 + sl;
+          if (g >= n_groups) break;
+          const int gl = g + kQSlots - 1;
+          if (gl < n_groups) {
+#pragma unroll
+            for (int q = 0; q < kQGroup16; ++q)
+              ring[(sl + kQSlots - 1) % kQSlots][q] = *reinterpret_cast<const q16_u4*>(rp + 16 * (gl * kQGroup16 + q));
+          }
+          multiply(ring[sl], g);
+        }
+      }
+    }
+    for (int p = n_groups * kQGroup16; p < n_steps; ++p) {  // D not a multiple of 128
+      const q16_u4 a = *reinterpret_cast<const q16_u4*>(rp + 16 * p);
+      if (FT == SAF_BF16) fit(bits_max(group_max_bits(a, 0u)));
+      step(a, p);
+    }
+    ss = other_half_sum(ss);  // both halves of row m
+    scan_epilogue<EPI, TILES, true>(acc, row_inverse(ss, normalize), re, ce, tile, n_rows, L, scale, wl, out, out_last,
+                                    out_stride, out_col0, stage);
+  }
+}
+
+template <int EPI, int FT, int TILES, int TH, int SPLIT>  // SPLIT: 0 the exact-fp32 scan, 1 the split scan, 2 its 16-bit-volume form
 int launch_mfma_th(const void* feats, int64_t n_rows, int64_t fstride, int D, const float* text, int L, int64_t tstride,
                    float scale, int normalize, const float* wts, float* out, float* out_last, int per_cu, size_t shmem, hipStream_t s,
                    int64_t out_stride, int out_col0) {
-  auto fn = SPLIT ? query_split_kernel<EPI, FT, TILES, TH> : query_mfma_kernel<EPI, FT, TILES, TH>;
+  auto fn = SPLIT == 2 ? query_split16_kernel<EPI, (FT == SAF_F32 ? SAF_F16 : FT), TILES, TH>
+            : SPLIT ? query_split_kernel<EPI, FT, TILES, TH> : query_mfma_kernel<EPI, FT, TILES, TH>;
   constexpr int kWavesTh = TH / 64;
   int64_t blocks = ((n_rows + 31) / 32 + kWavesTh - 1) / kWavesTh;
   const int64_t cap = (int64_t)device_cus() * (per_cu < 1 ? 1 : per_cu);
@@ -668,7 +887,7 @@ int launch_mfma_th(const void* feats, int64_t n_rows, int64_t fstride, int D, co
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(TH), shmem, s, feats, n_rows, fstride, D, text, L,
                      tstride, scale, normalize, wts, out, out_last, out_stride > 0 ? out_stride : (int64_t)L, out_col0, stage ? 1 : 0);
-  return check_launch(SPLIT ? "query_split_kernel" : "query_mfma_kernel");
+  return check_launch(SPLIT == 2 ? "query_split16_kernel" : SPLIT ? "query_split_kernel" : "query_mfma_kernel");
 }
 
 // SAF_Q_SPLIT (read per call): 0 = the fp32 MFMA scan for every shape (development / A-B); default: the split scan where it applies
@@ -688,8 +907,11 @@ int launch_mfma_t(const void* feats, int64_t n_rows, int64_t fstride, int D, con
   const char* th_env = getenv("SAF_Q_THREADS");
   const bool wide = th_env ? atoi(th_env) == 512 : per_cu <= 1;
 #define SAF_Q_GO(TH, SP) launch_mfma_th<EPI, FT, TILES, TH, SP>(feats, n_rows, fstride, D, text, L, tstride, scale, normalize, wts, out, out_last, per_cu, shmem, s, out_stride, out_col0)
-  if (split) return wide ? SAF_Q_GO(512, true) : SAF_Q_GO(256, true);
-  return wide ? SAF_Q_GO(512, false) : SAF_Q_GO(256, false);
+  // a 16-bit volume whose rows lie on 16-byte boundaries: one load per k-step in the matrix instruction's layout, one piece per feature
+  const char* e16 = getenv("SAF_Q_SPLIT16");  // (0: through the fp32 form, development / A-B)
+  if (split && FT != SAF_F32 && fstride % 8 == 0 && !(e16 && atoi(e16) == 0)) return wide ? SAF_Q_GO(512, 2) : SAF_Q_GO(256, 2);
+  if (split) return wide ? SAF_Q_GO(512, 1) : SAF_Q_GO(256, 1);
+  return wide ? SAF_Q_GO(512, 0) : SAF_Q_GO(256, 0);
 #undef SAF_Q_GO
 }
 

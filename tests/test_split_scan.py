@@ -196,3 +196,46 @@ def test_split_scan_wide_features_in_blocks_of_32(oracle, d, nl):
         want = oracle.query_scan(feats, text, epi, scale=scale, normalize=True)
         got = _scan(feats.cuda(), text.cuda(), epi, scale=scale, normalize=True)
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"epilogue {epi}, D = {d}, {nl} labels")
+
+
+@pytest.mark.parametrize("fdt", [torch.bfloat16, torch.float16])
+def test_split_scan_16bit_volumes_of_any_magnitude(fdt):
+    """The 16-bit-volume form (query_split16_kernel): one fp16 piece per feature.  bf16 rows span fp32's range and go under the
+    running scale; fp16 rows go as they are, denormals and 65504 included.  Against float64 of the SAME 16-bit values."""
+    d, nl = 512, 63
+    g = torch.Generator().manual_seed(21)
+    rows = torch.randn((10, 64, d), generator=g)
+    if fdt == torch.bfloat16:
+        rows[0] *= 1e30
+        rows[1] *= 1e-30
+        rows[2, :, 128:] *= 1e5                            # a step behind the first group of 128
+        rows[3] *= torch.logspace(-6, 9, d)[None]
+        rows[4, :, :128] = 0.0
+        rows[5] *= torch.logspace(9, -6, d)[None]
+        rows[6] *= (10.0 ** torch.randint(-20, 20, (64, 1), generator=g).float())
+        rows[7] = 0.0
+        rows[7, :, -1] = -2.5
+        rows[8] *= 1e-38                                   # bf16 denormals
+    else:
+        rows[0] *= 1.0e4                                   # up to ~5e4
+        rows[0].clamp_(-65504, 65504)
+        rows[1] *= 1e-6                                    # fp16 denormals
+        rows[2, :, 128:] *= 1e3
+        rows[3] *= torch.logspace(-7, 3, d)[None]
+        rows[4, :, :128] = 0.0
+        rows[7] = 0.0
+        rows[7, :, -1] = 65504.0
+    feats = rows.view(-1, d).to(fdt)
+    text = torch.randn((nl, d), generator=g)
+    text[0] *= 1e6
+    text[1] *= 1e-6
+    text[2] = 0.0
+    _check_raw(feats, text, f"{fdt} magnitudes", acc=ACC_WORST)
+    # the same through a view whose rows are not on 16-byte boundaries (row stride 520 - 4 elements): the fp32-widening form takes it
+    wide = torch.zeros((feats.shape[0], d + 4), dtype=fdt)
+    wide[:, :d] = feats
+    got = _scan(wide.cuda()[:, :d], text.cuda()).double().cpu().numpy()
+    f64, t64 = feats.float().double().numpy(), text.double().numpy()
+    mag = _raw_bound(f64, t64)
+    ok = mag < 1e37
+    assert (np.abs(got - f64 @ t64.T)[ok] <= (mag * (CUT + ACC_WORST))[ok] + 1e-44).all()
