@@ -1089,12 +1089,17 @@ def side_workloads(a, device, L, frames_A, npy, npx):
         for s0 in range(0, n, 1 << 20):
             f32[s0:s0 + (1 << 20)] = torch.randn((min(1 << 20, n - s0), d), generator=g, device=device)
         split = os.environ.get("SAF_Q_SPLIT", "1") != "0"
-        for name, nl, epi, scale in (("a9_softmax_L5_fp32_volume", 5, _abi.SAF_Q_SOFTMAX, 100.0),
-                                     ("a10_surgery_L63_fp32_volume", 63, _abi.SAF_Q_SURGERY, 1.0)):
+        b16 = torch.empty((n, d), dtype=torch.bfloat16, device=device)  # config 3's volume dtype: the 16-bit form of the scan
+        for s0 in range(0, n, 1 << 20):
+            b16[s0:s0 + (1 << 20)] = f32[s0:s0 + (1 << 20)].to(torch.bfloat16)
+        for name, nl, epi, scale, vol_t in (("a9_softmax_L5_fp32_volume", 5, _abi.SAF_Q_SOFTMAX, 100.0, f32),
+                                            ("a10_surgery_L63_fp32_volume", 63, _abi.SAF_Q_SURGERY, 1.0, f32),
+                                            ("a10_surgery_L63_bf16_volume", 63, _abi.SAF_Q_SURGERY, 1.0, b16)):
             t = text[:nl]
+            esz = vol_t.element_size()
             last = epi == _abi.SAF_Q_SOFTMAX
             hold = {}
-            fn = lambda: hold.__setitem__("o", _query_scan(f32, t, epi, scale=scale, normalize=True, last_only=last))  # noqa: E731
+            fn = lambda: hold.__setitem__("o", _query_scan(vol_t, t, epi, scale=scale, normalize=True, last_only=last))  # noqa: E731
             fn()
             fn()  # (two calls: the second still holds the first's [N, L] output, so both of the allocator's blocks exist before the timing)
             torch.cuda.synchronize()
@@ -1106,26 +1111,26 @@ def side_workloads(a, device, L, frames_A, npy, npx):
             e1.record()
             torch.cuda.synchronize()
             kern = e0.elapsed_time(e1) * 1e-3 / 3
-            nbytes = n * d * 4 + nl * d * 4 + n * (1 if last else nl) * 4
-            issued = 2.0 * n * d * 32 * ((nl + 31) // 32) * (3 if split else 1)
+            nbytes = n * d * esz + nl * d * 4 + n * (1 if last else nl) * 4
+            issued = 2.0 * n * d * 32 * ((nl + 31) // 32) * ((2 if esz == 2 else 3) if split else 1)
             mpeak = MFMA16_PEAK_TFLOPS if split else MFMA32_PEAK_TFLOPS
             out[name] = {"ms": round(kern * 1e3, 3), "labels": nl,
-                         "workload": f"{nl} text labels over {n} voxel rows x {d} fp32, " + ("softmax, last column" if last else "feature surgery, [N, L] out"),
-                         "roofline": {"kernel": "query_split_kernel" if split else "query_mfma_kernel", "bound": "hbm",
+                         "workload": f"{nl} text labels over {n} voxel rows x {d} {'fp32' if esz == 4 else 'bf16'}, " + ("softmax, last column" if last else "feature surgery, [N, L] out"),
+                         "roofline": {"kernel": ("query_split16_kernel" if esz == 2 else "query_split_kernel") if split else "query_mfma_kernel", "bound": "hbm",
                                       "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                                       "algorithmic_bytes_per_launch": int(nbytes),
                                       "floors_ms": {"hbm": round(nbytes / (HBM_PEAK_GBS * 1e9) * 1e3, 2),
-                                                    ("fp16_mfma_x3" if split else "fp32_mfma"): round(issued / (mpeak * 1e12) * 1e3, 2)}}}
+                                                    (("fp16_mfma_x2" if esz == 2 else "fp16_mfma_x3") if split else "fp32_mfma"): round(issued / (mpeak * 1e12) * 1e3, 2)}}}
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r06", "split_scan_traffic.json")))
-                if split and d == 512:
+                if split and d == 512 and esz == 4:
                     out[name]["roofline"]["traffic"] = tj["L5_softmax_last" if nl == 5 else "L63_surgery"]["hbm_bytes_per_launch"]
                     out[name]["roofline"]["traffic_source"] = "profiles/r06/split_scan_traffic.json (this round, another box): " + tj["method"]
             except Exception:  # noqa: BLE001
                 pass
             hold.clear()
-        del f32
+        del f32, b16
         torch.cuda.empty_cache()
 
     big = torch.empty((n, (q + 63) // 64 * 64), dtype=torch.float16, device=device)[:, :q]  # (rows padded to whole 128-byte lines, as query_scan_wide allocates its own output)
