@@ -913,6 +913,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
                        // measured in round 6, results identical, SLOWER: 21.2 / 21.5 -> 22.7 / 22.95 ms on one box (profiles/r06/
                        // wide_scan_paired_stores_ab.txt) -- the epilogue sits at the issue port's limit: a ds_write, two ds_read
                        // and their wait per row block and pair of tiles cost more than the 13 GB of half-line write traffic they remove
+                       // 2 (round 6, later): the low half held in four registers for one tile, the two halves stored back to back (heat maps and raw
+                       // scores; no LDS, no extra instruction).  The counters say pairing removes the amplification (34.2 GB written); the clock
+                       // says nobody was waiting for it: 21.0-21.2 -> 21.6 ms, raw scores 19.3 -> 19.7-19.9 (same file).  Not kept either.
 #endif
 #ifndef SAF_W3_PREFETCH
 #define SAF_W3_PREFETCH 1  // the next row block's first pieces through the LDS (query_wide3_kernel, kPref); 0: every row from HBM at the block change
@@ -936,8 +939,9 @@ struct W3State {
                      // block the fp32-output instantiations kept the whole struct in scratch memory)
   int best_q[2];
   const float* inv_lds;  // QUERY_MAX: the wave's 32 (scale / norm) values in LDS, by row of the wave
-  unsigned char* pair_lds;  // SAF_W3_PAIR: the wave's 4 KiB of output lines in LDS ([row block][row][128 bytes]), or nullptr
+  unsigned char* pair_lds;  // SAF_W3_PAIR=1: the wave's 4 KiB of output lines in LDS ([row block][row][128 bytes]), or nullptr
   int pair;                 // this step's epilogue tile: 0 = stores its half lines itself, 1 = low half, staged only, 2 = high half: stage, then full lines
+  uint32_t hold[2][4];      // SAF_W3_PAIR=2: the low half's 16 bytes per row block, in registers until the high half is ready
 };
 
 template <int OT, int EPI>
@@ -1128,7 +1132,17 @@ __device__ __forceinline__ void w3_piece(int k, const Wide2Args& wa, const f32x4
         typedef unsigned int w3_u4 __attribute__((ext_vector_type(4)));
         const w3_u4 w = {rx[0], ry[0], rx[1], ry[1]};
         const int col0 = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;  // the lane's 8 consecutive columns of the tile
-        if (SAF_W3_PAIR && EPI == SAF_QW_VS_BACKGROUND && st.pair != 0) {
+        if (SAF_W3_PAIR == 2 && (EPI == SAF_QW_VS_BACKGROUND || EPI == SAF_QW_SCORES) && st.pair != 0) {
+          // the line's two halves leave back to back: the low half waited one tile in four registers
+          if (st.pair == 1) {
+            st.hold[rb][0] = w[0]; st.hold[rb][1] = w[1]; st.hold[rb][2] = w[2]; st.hold[rb][3] = w[3];
+          } else {
+            uint16_t* o = static_cast<uint16_t*>(wa.out) + t.row[rb] * wa.ostride + colt + col0;
+            const w3_u4 lo = {st.hold[rb][0], st.hold[rb][1], st.hold[rb][2], st.hold[rb][3]};
+            *reinterpret_cast<w3_u4*>(o - kWTile) = lo;
+            *reinterpret_cast<w3_u4*>(o) = w;
+          }
+        } else if (SAF_W3_PAIR == 1 && EPI == SAF_QW_VS_BACKGROUND && st.pair != 0) {
           // the row's line in LDS: this tile's 64 bytes in its half; the high half then reads whole lines back -- lane l takes
           // 16 bytes (l & 7) of row (l >> 3) + 8 h -- and a wave's store instruction writes eight full 128-byte lines
           unsigned char* line = st.pair_lds + (rb * 16 + c) * 128 + (st.pair == 2 ? 64 : 0) + col0 * 2;
@@ -1241,9 +1255,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   st.inv_lds = s_inv;
   // SAF_W3_PAIR: 4 KiB of output lines per wave behind the tiles (the heat maps use no row prefetch region); lines must be lines:
   // output rows 128-byte aligned
-  constexpr bool kPair = SAF_W3_PAIR && EPI == SAF_QW_VS_BACKGROUND && OT != SAF_F32;
+  constexpr bool kPair = ((SAF_W3_PAIR == 1 && EPI == SAF_QW_VS_BACKGROUND) ||
+                          (SAF_W3_PAIR == 2 && (EPI == SAF_QW_VS_BACKGROUND || EPI == SAF_QW_SCORES))) && OT != SAF_F32;
   const bool pair_ok = kPair && vec_ok && (((uintptr_t)wa.out & 127) == 0) && ((wa.ostride * 2) % 128 == 0);
-  st.pair_lds = kPair ? s_tiles + 2 * kWTile * ROWB + 1024 + wave * 4096 : nullptr;
+  st.pair_lds = kPair && SAF_W3_PAIR == 1 ? s_tiles + 2 * kWTile * ROWB + 1024 + wave * 4096 : nullptr;
   st.pair = 0;
   bool pair_staged = false;  // the previous tile's halves wait in the LDS (wave-uniform)
   cur.qt = 0;
@@ -1388,7 +1403,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // and not the workgroup's very last one, whose epilogue runs behind the loop); high half: completes what was staged
       st.pair = 0;
       if (fast && pair_ok) {
-        const int ot = prev.qt - 1;
+        const int ot = EPI == SAF_QW_VS_BACKGROUND ? prev.qt - 1 : prev.qt;  // the output tile: two of them make a 128-byte line
         if ((ot & 1) == 0) st.pair = (prev.qt + 1 < n_qt && (prev.qt + 2) * kWTile <= wa.Q && step + 1 < n_steps) ? 1 : 0;
         else st.pair = pair_staged ? 2 : 0;
       }
@@ -1545,7 +1560,7 @@ int launch_wide3(const Wide2Args& wa, hipStream_t s) {
   // two text tiles, 1 KiB of 1/norms (QUERY_MAX), and at D = 512 eleven 1 KiB pieces per wave of the next block's rows (kPref)
   constexpr size_t shmem = 2 * (size_t)kWTile * (KS * 32 + 16) + 1024 +
                            ((KS == 32 && SAF_W3_PREFETCH && (EPI == SAF_QW_SCORES || EPI == SAF_QW_QUERY_MAX)) ? 8 * 11 * 1024 : 0) +
-                           ((SAF_W3_PAIR && EPI == SAF_QW_VS_BACKGROUND && OT != SAF_F32) ? 8 * 4096 : 0);
+                           ((SAF_W3_PAIR == 1 && EPI == SAF_QW_VS_BACKGROUND && OT != SAF_F32) ? 8 * 4096 : 0);
   auto fn = query_wide3_kernel<FT, OT, KS, EPI>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
