@@ -328,6 +328,11 @@ enum saf_query_normalize {
  *   out        [n_rows, n_text] f32
  *   out_last   optional [n_rows] f32: only the last column (query_mesh.py:38); out may be NULL then
  *   workspace  device scratch of saf_query_workspace_bytes(n_text, epilogue) bytes (may be NULL if 0)
+ * Numerics (ABI 3, round 6): for feat_dim % 16 == 0 and up to 64 labels (or more, 64 / 32 at a time, when `out` is given) the dot
+ * products run on fp16 matrix instructions with fp32 accumulation -- fp32 operands cut into two fp16 pieces under power-of-two
+ * scales (per label; per feature row, following the row's running maximum), 16-bit features as one piece: a score is within
+ * 3 x 2^-22 of sum_k |f_k t_k| of the exact dot product for rows and labels of any magnitude the dtype holds (the reference's scores
+ * are compared at 1e-4).  SAF_Q_SPLIT=0 in the environment (read per call): the exact-fp32 matrix instructions instead.
  */
 int saf_query_scan(const void* feats, int32_t feat_dtype, int64_t n_rows, int64_t feat_stride,
                    int32_t feat_dim, const float* text, int32_t n_text, int64_t text_stride,
