@@ -1122,6 +1122,22 @@ def side_workloads(a, device, L, frames_A, npy, npx):
                                       "algorithmic_bytes_per_launch": int(nbytes),
                                       "floors_ms": {"hbm": round(nbytes / (HBM_PEAK_GBS * 1e9) * 1e3, 2),
                                                     (("fp16_mfma_x2" if esz == 2 else "fp16_mfma_x3") if split else "fp32_mfma"): round(issued / (mpeak * 1e12) * 1e3, 2)}}}
+            if split:  # the same scan on the exact-fp32 matrix instructions (SAF_Q_SPLIT is read per call), for the record
+                os.environ["SAF_Q_SPLIT"] = "0"
+                try:
+                    fn()
+                    torch.cuda.synchronize()
+                    e0.record()
+                    fn()
+                    fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    out[name]["exact_fp32_mfma_ms"] = round(e0.elapsed_time(e1) / 2, 3)
+                    out[name]["note"] = ("fp32 scores from fp16 matrix instructions (operands cut into fp16 pieces under power-of-two scales, fp32 "
+                                         "accumulation; error <= 3 x 2^-22 of sum |a b| per score: tests/test_split_scan.py); "
+                                         "`exact_fp32_mfma_ms`: the same call under SAF_Q_SPLIT=0 (v_mfma_f32_32x32x2_f32)")
+                finally:
+                    del os.environ["SAF_Q_SPLIT"]
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r06", "split_scan_traffic.json")))
                 if split and d == 512 and esz == 4:
