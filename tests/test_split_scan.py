@@ -239,3 +239,15 @@ def test_split_scan_16bit_volumes_of_any_magnitude(fdt):
     mag = _raw_bound(f64, t64)
     ok = mag < 1e37
     assert (np.abs(got - f64 @ t64.T)[ok] <= (mag * (CUT + ACC_WORST))[ok] + 1e-44).all()
+
+
+@pytest.mark.parametrize("fdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [16, 144, 272, 1024])
+def test_split_scan_16bit_other_widths(fdt, d):
+    """16-bit volumes whose rows are not a whole number of 128-feature groups (no group at all; one group and a k-step; two groups --
+    the ring with unconditional loads -- and a k-step behind them) and 1024 channels"""
+    n, nl = 777, 29
+    g = torch.Generator().manual_seed(d)
+    feats = (torch.randn((n, d), generator=g) * 3.0).to(fdt)
+    text = torch.randn((nl, d), generator=g)
+    _check_raw(feats, text, f"D = {d}, {fdt}")
