@@ -506,6 +506,9 @@ class _FusionVolumeMixin:
         if final:
             self._finish_session()
             st["ring0"] = 0  # (every quarter now carries the event of the finish, or of the call on the current stream)
+            if any(r is not None for r in st["brefs"]):  # lent images: read by now as far as this stream can tell -- let them go
+                st["brefs"] = [None] * len(st["brefs"])
+                st["bptr"][:] = 0
         else:
             st["ring0"] = (lo + n) % self._QUEUE_FRAMES  # the next frames follow in the ring (a session's windows are its quarters)
 
